@@ -1,0 +1,149 @@
+/* mt_hip.h -- C ABI of libmt_hip.so, the MI355X (gfx950) hot path of
+ * cs4247/music-transcription:  30 s waveform chunk -> log-mel -> CNN-RNN -> 88-pitch logits.
+ *
+ * The reference has no FFI layer (it is pure Python on torch); each entry point
+ * below names the reference call site whose arithmetic it replaces.  The Python
+ * host (music-transcription_amd/) binds these with ctypes; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensor
+ *     .data_ptr()), row-major contiguous, unless the name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - return value: 0 on success, negative MT_E* on error, never throws; the
+ *     message of the last error on the calling thread is at mt_last_error();
+ *   - no entry point allocates device memory or synchronises the device: scratch
+ *     comes in as (workspace, workspace_bytes), sizes come from the *_bytes queries;
+ *   - thread-compatible (one stream per caller thread), no mutable global state.
+ */
+#ifndef MT_HIP_H
+#define MT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MT_OK            0
+#define MT_EINVAL       -1   /* bad argument / unsupported shape                 */
+#define MT_EWORKSPACE   -2   /* workspace too small                              */
+#define MT_EHIP         -3   /* HIP runtime error (launch, memset, ...)          */
+#define MT_EUNSUPPORTED -4   /* configuration outside what the kernels implement */
+
+#define MT_N_FFT 2048        /* librosa default the reference relies on (main.py:117-122) */
+#define MT_N_PITCH 88
+
+typedef void* mt_stream_t;
+
+int         mt_version(void);
+const char* mt_last_error(void);
+/* Number of HIP devices visible, or negative error.  Does not create a context. */
+int         mt_device_count(void);
+
+/* ------------------------------------------------------------------ frontend
+ * Replaces librosa.feature.melspectrogram + librosa.power_to_db as called at
+ * main.py:117-125, data/dataset.py:155-156 and :195-196:
+ *   center zero-pad n_fft/2, frames of 2048 @ hop, periodic Hann, |rFFT|^2,
+ *   Slaney mel filterbank (fmin 0, fmax sr/2, norm 'slaney'), 10*log10(max(1e-10,S)),
+ *   clamp to (per-chunk max - 80 dB).                                             */
+
+/* Host-side tables (no GPU needed): dense filterbank (n_mels x 1025) as
+ * librosa.filters.mel builds it; used by tests and by mt_mel_plan_init. */
+int    mt_mel_filterbank_host(float* fb_host, int sr, int n_mels);
+int    mt_mel_num_frames(int n_samples, int hop);           /* 1 + n_samples / hop */
+
+/* Device-resident immutable tables for one (sr, hop, n_mels). */
+size_t mt_mel_plan_bytes(int n_mels);
+int    mt_mel_plan_init(void* plan, size_t plan_bytes, int sr, int hop, int n_mels, mt_stream_t stream);
+
+/* wave[B][n_samples] f32 -> mel_db[B][n_mels][T] f32 (T = mt_mel_num_frames).
+ * chunk_max_power[B] (f32 bit patterns, >= 0) receives each chunk's max mel POWER.
+ * apply_clamp != 0: mel_db is final (clamped at max-80 dB), as power_to_db returns it.
+ * apply_clamp == 0: mel_db is left unclamped; the consumer (mt_conv1_*) applies
+ *                   max(x, 10*log10(max(1e-10, chunk_max_power[b])) - 80) on load.  */
+int    mt_mel_db_f32(const void* plan, int hop, int n_mels, const float* wave, int B, int n_samples,
+                     float* mel_db, float* chunk_max_power, int apply_clamp, mt_stream_t stream);
+
+/* ------------------------------------------------------------------ CNN blocks
+ * CNNRNNModel.cnn (cnn_rnn_model.py:29-39; Large: conv1, :178-183), eval mode; BatchNorm
+ * running statistics are folded into (w, bias) by the host at load_state_dict time.
+ * conv1: mel[B][n_mels][T] f32 (+ optional per-chunk dB floor from chunk_max_power, may be
+ *        NULL) -> act1[B][n_mels/2][T][32] bf16, channels-last.
+ *        w = folded Conv2d(1,32,3x3) weights [32][9] f32, bias [32] f32.
+ * conv2: act1 -> X0[(t*B+b)*ldx + fo*64 + co] bf16 (the LSTM layer-0 GEMM A matrix; the
+ *        reference's feature order c*F+f, cnn_rnn_model.py:60-62, is absorbed into W_ih's
+ *        column order at pack time).  w2 = folded Conv2d(32,64,3x3) [64][tap=kh*3+kw][32] bf16. */
+int    mt_conv1_bn_relu_pool(const float* mel, const float* chunk_max_power, const float* w, const float* bias,
+                             void* act1, int B, int n_mels, int T, mt_stream_t stream);
+int    mt_conv2_bn_relu_pool(const void* act1, const void* w2, const float* bias, void* X0, int ldx,
+                             int B, int F1, int T, mt_stream_t stream);
+
+/* ------------------------------------------------------------------ GEMM (bf16 MFMA, f32 accumulate)
+ * C[M][N] (f32) = A[M][K] (bf16) * W[N][K]^T (bf16) + bias[N] (f32, may be NULL).
+ * lda/ldw/ldc in elements.  The caller's A buffer must be readable up to row
+ * roundup(M,128)-1 and W up to row roundup(N,128)-1 (pad rows may hold anything finite or
+ * not: they only feed discarded outputs); K % 64 == 0.  Replaces the nn.Linear / nn.LSTM
+ * input-projection matmuls (cnn_rnn_model.py:45-52,:55,:212-228,:250-256).               */
+int    mt_gemm_bf16_f32acc(const void* A, int lda, const void* W, int ldw, const float* bias,
+                           float* C, int ldc, int M, int N, int K, mt_stream_t stream);
+/* LSTM input projection for BOTH directions of one layer: X[(t*B+b)][K] bf16, W_ih =
+ * [fwd 4H rows; reverse 4H rows][K] bf16, bias[8H] = b_ih + b_hh, output in the layout
+ * the recurrence streams: gx[b/32][t][dir][j/8][gate][j%8][b%32] f32 (mt_lstm_gx_bytes). */
+int    mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
+                       int B, int T, int H, int K, mt_stream_t stream);
+/* Final projection with the reference's transpose fused: logits[b][n][t], rows m = t*B+b. */
+int    mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
+                      int B, int T, int N, int K, mt_stream_t stream);
+
+/* ------------------------------------------------------------------ bidirectional LSTM recurrence
+ * nn.LSTM(batch_first, bidirectional) as the reference runs it in fp32
+ * (cnn_rnn_model.py:45-52,:69-70): gate order i,f,g,o, zero initial state.
+ * w_hh = [fwd; reverse] x [4H][H] f32.  hx receives every step's h in the MFMA-operand
+ * layout hx[b/32][t][dir][j/8][(j%2)*32 + b%32][(j%8)/2].  sync_ws: mt_lstm_sync_bytes();
+ * after the stream has drained its word 0 is 0 (ok) or 1 + step (hand-off timeout).      */
+size_t mt_lstm_gx_bytes(int B, int T, int H);
+size_t mt_lstm_hx_bytes(int B, int T, int H);
+size_t mt_lstm_sync_bytes(int B, int H);
+int    mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
+                         int B, int T, int H, mt_stream_t stream);
+/* hx -> X[(t*B+b)*ldx + dir*H + j] bf16 (next GEMM's A) / y[b][t][dir*H + j] f32 (torch layout). */
+int    mt_lstm_relayout_bf16(const float* hx, void* X, int ldx, int B, int T, int H, mt_stream_t stream);
+int    mt_lstm_unpack_f32(const float* hx, float* y, int B, int T, int H, mt_stream_t stream);
+
+/* ------------------------------------------------------------------ whole-model forward
+ * CNNRNNModel.forward in eval mode (cnn_rnn_model.py:57-74).  All pointers are device
+ * pointers to tensors the host packed once from a reference state_dict
+ * (music-transcription_amd/model.py: pack_cnnrnn).                                        */
+#define MT_MAX_LSTM_LAYERS 8
+typedef struct {
+    int n_mels;                              /* input mel bins                                    */
+    int hidden;                              /* LSTM hidden size H (multiple of 8, <= 1024)       */
+    int layers;                              /* LSTM layers (<= MT_MAX_LSTM_LAYERS)               */
+    int reserved;
+    const float* conv1_w;                    /* [32][9]  BN-folded                                */
+    const float* conv1_b;                    /* [32]                                              */
+    const void*  conv2_w;                    /* bf16 [64][9][32] BN-folded                        */
+    const float* conv2_b;                    /* [64]                                              */
+    const void*  w_ih[MT_MAX_LSTM_LAYERS];   /* bf16 [roundup(8H,128)][K_l]; layer 0 columns in   */
+                                             /*   fo*64+co order, K_0 = (n_mels/4)*64;            */
+                                             /*   K_l = roundup(2H,64), zero-padded, for l > 0    */
+    const float* b_gates[MT_MAX_LSTM_LAYERS];/* f32 [8H] = b_ih + b_hh, [fwd; reverse]            */
+    const float* w_hh[MT_MAX_LSTM_LAYERS];   /* f32 [2][4H][H]                                    */
+    const void*  fc_w;                       /* bf16 [128][roundup(2H,64)], rows >= 88 zero       */
+    const float* fc_b;                       /* f32 [88]                                          */
+} mt_cnnrnn_weights;
+
+size_t mt_cnnrnn_workspace_bytes(const mt_cnnrnn_weights* w, int B, int T);
+size_t mt_cnnrnn_status_offset(const mt_cnnrnn_weights* w, int B, int T, int layer);
+/* mel[B][n_mels][T] f32 (dB; chunk_max_power may be NULL when mel is already clamped)
+ * -> logits[B][88][T] f32.                                                                */
+int    mt_cnnrnn_forward(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power,
+                         int B, int T, float* logits, void* workspace, size_t workspace_bytes,
+                         mt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MT_HIP_H */

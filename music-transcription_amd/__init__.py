@@ -1,0 +1,12 @@
+"""music_transcription_amd -- MI355X-native hot path of cs4247/music-transcription.
+
+mel frontend -> CNN-RNN forward -> 88-pitch logits, as hand-written gfx950 kernels in
+libmt_hip.so behind the reference's Python surface (TranscriptionModel, audio_to_mel).
+Importing this package requires the built library; nothing here falls back to CPU code.
+"""
+from . import _lib                                   # noqa: F401  (raises if libmt_hip.so is missing)
+from ._lib import MtError                            # noqa: F401
+from .frontend import MelFrontend, audio_to_mel, get_frontend, mel_filterbank, num_frames   # noqa: F401
+from .model import CNNRNNModel, CNNRNNModelLarge, TranscriptionModel                          # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,98 @@
+"""ctypes binding of libmt_hip.so (the C ABI declared in include/mt_hip.h).
+
+The product path has no CPU or torch fallback: if the shared library is missing,
+importing this module raises, and every wrapper raises MtError on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmt_hip.so")
+MAX_LSTM_LAYERS = 8
+N_PITCH = 88
+
+
+class MtError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libmt_hip.so (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise MtError("building libmt_hip.so failed")
+    return LIB_PATH
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"or `make -C {os.path.join(_HERE, 'csrc')}` (needs hipcc)")
+
+lib = C.CDLL(LIB_PATH)
+
+vp, sz, i32, f32p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
+
+
+class CnnRnnWeights(C.Structure):
+    """mt_cnnrnn_weights (include/mt_hip.h)."""
+    _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("reserved", i32),
+                ("conv1_w", vp), ("conv1_b", vp), ("conv2_w", vp), ("conv2_b", vp),
+                ("w_ih", vp * MAX_LSTM_LAYERS), ("b_gates", vp * MAX_LSTM_LAYERS), ("w_hh", vp * MAX_LSTM_LAYERS),
+                ("fc_w", vp), ("fc_b", vp)]
+
+
+_SIGS = {
+    "mt_version": (i32, []),
+    "mt_last_error": (C.c_char_p, []),
+    "mt_device_count": (i32, []),
+    "mt_mel_filterbank_host": (i32, [vp, i32, i32]),
+    "mt_mel_num_frames": (i32, [i32, i32]),
+    "mt_mel_plan_bytes": (sz, [i32]),
+    "mt_mel_plan_init": (i32, [vp, sz, i32, i32, i32, vp]),
+    "mt_mel_db_f32": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, i32, vp]),
+    "mt_conv1_bn_relu_pool": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mt_conv2_bn_relu_pool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_gemm_bf16_f32acc": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_gemm_lstm_gx": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_gemm_logits": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_lstm_gx_bytes": (sz, [i32, i32, i32]),
+    "mt_lstm_hx_bytes": (sz, [i32, i32, i32]),
+    "mt_lstm_sync_bytes": (sz, [i32, i32]),
+    "mt_lstm_bidir_fwd": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "mt_lstm_relayout_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "mt_lstm_unpack_f32": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mt_cnnrnn_workspace_bytes": (sz, [C.POINTER(CnnRnnWeights), i32, i32]),
+    "mt_cnnrnn_status_offset": (sz, [C.POINTER(CnnRnnWeights), i32, i32, i32]),
+    "mt_cnnrnn_forward": (i32, [C.POINTER(CnnRnnWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
+}
+EXPORTS = tuple(_SIGS)
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here = header and library disagree
+    _fn.restype, _fn.argtypes = _res, _args
+
+
+def last_error() -> str:
+    return (lib.mt_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise MtError(f"{what or 'libmt_hip'} failed (code {rc}): {last_error()}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a contiguous torch tensor, or NULL for None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libmt_hip takes contiguous buffers"
+    return t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

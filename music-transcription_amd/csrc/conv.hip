@@ -1,0 +1,176 @@
+// CNN frontend of CNNRNNModel (cnn_rnn_model.py:29-39) for gfx950, eval mode:
+//   conv1: Conv2d(1->32, 3x3, pad 1) + BatchNorm2d + ReLU + MaxPool2d((2,1))
+//   conv2: Conv2d(32->64, 3x3, pad 1) + BatchNorm2d + ReLU + MaxPool2d((2,1))
+// BatchNorm (running statistics) is folded into the conv weights at pack time.
+//
+// Data layout in HBM (channels-last, chosen for the MFMA implicit GEMM):
+//   mel   [B][F][T]            f32   (F = n_mels; optional per-chunk dB floor applied on load)
+//   act1  [B][F/2][T][32]      bf16  (one 64-B line per (f,t) position)
+//   X0    [T*B + pad][F/4*64]  bf16  row m = t*B + b, column fo*64 + co  -- this IS the
+//                                    A matrix of the LSTM layer-0 input projection; the
+//                                    reference's feature order c*F+f (cnn_rnn_model.py:60-62)
+//                                    is absorbed by permuting W_ih's columns at pack time.
+#include "mt_common.h"
+
+namespace mt {
+
+// ---------------------------------------------------------------- conv1 (Cin = 1, direct, fp32 VALU)
+// One thread per pooled output position (b, fo, t): 4x3 input patch, 32 channels x 2 rows x 9 taps.
+// Bandwidth-bound: reads 4 B/position of mel, writes 64 B/position (one full line per thread).
+__global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ mel, const unsigned* __restrict__ chunk_max,
+                                                    const float* __restrict__ w /*[32][9]*/, const float* __restrict__ bias /*[32]*/,
+                                                    bf16_t* __restrict__ act1, int F, int T, int Fo) {
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int fo = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (t >= T || fo >= Fo) return;
+    float floor_db = -3.0e38f;
+    if (chunk_max) floor_db = 10.0f * log10f(fmaxf(__uint_as_float(chunk_max[b]), 1e-10f)) - 80.0f;
+    const float* m = mel + (size_t)b * F * T;
+    float p[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int f = 2 * fo - 1 + r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int tt = t - 1 + c;
+            const bool in = (f >= 0 && f < F && tt >= 0 && tt < T);
+            p[r][c] = in ? fmaxf(m[(size_t)f * T + tt], floor_db) : 0.0f;   // zero padding is applied after the clamp
+        }
+    }
+    unsigned packed[16];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        float a0 = bias[c], a1 = bias[c];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float wv = w[c * 9 + kh * 3 + kw];
+                a0 = fmaf(wv, p[kh][kw], a0);
+                a1 = fmaf(wv, p[kh + 1][kw], a1);
+            }
+        const float v = fmaxf(fmaxf(a0, a1), 0.0f);
+        if (c & 1) packed[c >> 1] |= ((unsigned)f32_to_bf16(v)) << 16;
+        else packed[c >> 1] = f32_to_bf16(v);
+    }
+    uint4* dst = (uint4*)(act1 + (((size_t)b * Fo + fo) * T + t) * 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = make_uint4(packed[4 * i], packed[4 * i + 1], packed[4 * i + 2], packed[4 * i + 3]);
+}
+
+// ---------------------------------------------------------------- conv2 (32 -> 64, MFMA implicit GEMM)
+// Workgroup tile: 32 pre-pool frequency rows (16 pooled) x 16 frames x 64 output channels,
+// K = 9 taps x 32 input channels = 288.  v_mfma_f32_32x32x16_bf16:
+//   M-tile (32 rows) = one pooled frequency row: row r -> (frame t_l = r & 15, f parity = r >> 4),
+//     so the two rows that MaxPool2d((2,1)) merges sit in the SAME lane (registers 4q+p and 4(q+2)+p);
+//   N-tile (32 cols) = 32 output channels;  K-step (16) = half the input channels of one tap.
+// LDS: input tile [34 rows][20 cols][32 ci] bf16 with the 16-B chunk index XOR-ed by (col>>2)&3
+// (row pitch 20 positions: a multiple of 4, so the bank of a fragment read depends only on the
+// column and the 16 lanes of a ds_read_b128 group, which hold 16 distinct frames, never collide),
+// and the folded weights [64 co][288 + 8 pad] bf16 (592-B row stride: conflict-free B-fragment reads).
+constexpr int C2_TF = 16, C2_TT = 16;                 // pooled rows, frames per tile
+constexpr int C2_ROWS = 2 * C2_TF + 2, C2_PITCH = 20; // input tile rows, positions per row
+constexpr int C2_IN_BYTES = C2_ROWS * C2_PITCH * 64;
+constexpr int C2_WSTRIDE = 296;                       // bf16 elements per co row in LDS
+constexpr int C2_W_BYTES = 64 * C2_WSTRIDE * 2;
+
+__global__ __launch_bounds__(256) void conv2_kernel(const bf16_t* __restrict__ act1, const bf16_t* __restrict__ w2 /*[64][9][32]*/,
+                                                    const float* __restrict__ bias /*[64]*/, bf16_t* __restrict__ X0,
+                                                    int B, int F1, int T, int Fo2, int ldx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* in_s = smem;
+    char* w_s = smem + C2_IN_BYTES;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int t0 = blockIdx.x * C2_TT, fo0 = blockIdx.y * C2_TF, b = blockIdx.z;
+    const int f_base = 2 * fo0 - 1;                   // input row of tile row 0
+    // ---- stage weights: 64 rows x 36 chunks of 16 B
+    for (int id = tid; id < 64 * 36; id += 256) {
+        const int co = id / 36, ch = id % 36;
+        *(uint4*)(w_s + co * (C2_WSTRIDE * 2) + ch * 16) = *(const uint4*)(w2 + (size_t)co * 288 + ch * 8);
+    }
+    // ---- stage input tile: 34 rows x 18 cols x 4 chunks, zero outside the image
+    for (int id = tid; id < C2_ROWS * 18 * 4; id += 256) {
+        const int ch = id & 3, pos = id >> 2, col = pos % 18, row = pos / 18;
+        const int f = f_base + row, t = t0 - 1 + col;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (f >= 0 && f < F1 && t >= 0 && t < T) v = *(const uint4*)(act1 + (((size_t)b * F1 + f) * T + t) * 32 + ch * 8);
+        *(uint4*)(in_s + (row * C2_PITCH + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = v;
+    }
+    __syncthreads();
+
+    const int ntile = wv & 1, mgrp = wv >> 1;         // wave: 32 channels x 8 pooled rows
+    const int r = lane & 31, h = lane >> 5;
+    const int t_l = r & 15, fbit = r >> 4;
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
+
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        const int col = t_l + kw;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 bfrag = *(const bf16x8*)(w_s + (ntile * 32 + r) * (C2_WSTRIDE * 2) + (tap * 32 + s2 * 16 + h * 8) * 2);
+            const int chunk = (s2 * 2 + h) ^ ((col >> 2) & 3);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int row = 2 * (mgrp * 8 + mi) + fbit + kh;
+                const bf16x8 afrag = *(const bf16x8*)(in_s + (row * C2_PITCH + col) * 64 + (chunk << 4));
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[mi], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: + folded bias, MaxPool over the f pair, ReLU, bf16, X0[(t*B+b)][fo*64+co]
+    const int co = ntile * 32 + r;
+    const float bv = bias[co];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int fo = fo0 + mgrp * 8 + mi;
+        if (fo >= Fo2) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int tl = p + 8 * q + 4 * h, t = t0 + tl;
+                const float v = fmaxf(fmaxf(acc[mi][4 * q + p], acc[mi][4 * (q + 2) + p]) + bv, 0.0f);
+                if (t < T) X0[((size_t)t * B + b) * ldx + fo * 64 + co] = f32_to_bf16(v);
+            }
+    }
+}
+
+}  // namespace mt
+
+using namespace mt;
+
+extern "C" int mt_conv1_bn_relu_pool(const float* mel, const float* chunk_max_power, const float* w, const float* bias,
+                                     void* act1, int B, int n_mels, int T, mt_stream_t stream) {
+    MT_REQUIRE(mel && w && bias && act1, MT_EINVAL, "mt_conv1_bn_relu_pool: null pointer");
+    MT_REQUIRE(B > 0 && n_mels >= 2 && T > 0, MT_EINVAL, "mt_conv1_bn_relu_pool: bad dims B=%d n_mels=%d T=%d", B, n_mels, T);
+    const int Fo = n_mels / 2;
+    dim3 grid(cdiv(T, 64), cdiv(Fo, 4), B);
+    hipLaunchKernelGGL(conv1_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel, (const unsigned*)chunk_max_power, w, bias,
+                       (bf16_t*)act1, n_mels, T, Fo);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_conv2_bn_relu_pool(const void* act1, const void* w2, const float* bias, void* X0, int ldx,
+                                     int B, int F1, int T, mt_stream_t stream) {
+    MT_REQUIRE(act1 && w2 && bias && X0, MT_EINVAL, "mt_conv2_bn_relu_pool: null pointer");
+    MT_REQUIRE(B > 0 && F1 >= 2 && T > 0 && ldx >= (F1 / 2) * 64, MT_EINVAL, "mt_conv2_bn_relu_pool: bad dims");
+    const int Fo2 = F1 / 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C2_IN_BYTES + C2_W_BYTES));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(T, C2_TT), cdiv(Fo2, C2_TF), B);
+    hipLaunchKernelGGL(conv2_kernel, grid, dim3(256), C2_IN_BYTES + C2_W_BYTES, (hipStream_t)stream, (const bf16_t*)act1,
+                       (const bf16_t*)w2, bias, (bf16_t*)X0, B, F1, T, Fo2, ldx);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}

@@ -1,0 +1,91 @@
+// Whole-model forward of CNNRNNModel (cnn_rnn_model.py:57-74), eval mode, on one stream:
+//   mel -> conv1 -> conv2 -> [GEMM (input projection) -> persistent recurrence -> re-layout] x layers
+//       -> GEMM (fc, transposed store) -> logits (B, 88, T)
+// All intermediates live in the caller's workspace; nothing is allocated or synchronised here.
+#include "mt_common.h"
+
+extern "C" {
+int mt_conv1_bn_relu_pool(const float*, const float*, const float*, const float*, void*, int, int, int, mt_stream_t);
+int mt_conv2_bn_relu_pool(const void*, const void*, const float*, void*, int, int, int, int, mt_stream_t);
+int mt_gemm_lstm_gx(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
+int mt_gemm_logits(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
+int mt_lstm_bidir_fwd(const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
+int mt_lstm_relayout_bf16(const float*, void*, int, int, int, int, mt_stream_t);
+size_t mt_lstm_gx_bytes(int, int, int);
+size_t mt_lstm_hx_bytes(int, int, int);
+size_t mt_lstm_sync_bytes(int, int);
+}
+
+namespace mt {
+struct CnnRnnPlan {
+    int F1, Fo2, K0, K1, M, Mpad;
+    size_t act1, x0, x1, gx, hx, sync, sync_stride, total;
+};
+static CnnRnnPlan plan(const mt_cnnrnn_weights* w, int B, int T) {
+    CnnRnnPlan p;
+    p.F1 = w->n_mels / 2; p.Fo2 = p.F1 / 2;
+    p.K0 = p.Fo2 * 64;
+    p.K1 = (int)align_up((size_t)2 * w->hidden, 64);
+    p.M = T * B; p.Mpad = (int)align_up((size_t)p.M, 128);
+    size_t o = 0;
+    p.act1 = o; o += align_up((size_t)B * p.F1 * T * 32 * 2, 256);
+    p.x0 = o;   o += align_up((size_t)p.Mpad * p.K0 * 2, 256);
+    p.x1 = o;   o += align_up((size_t)p.Mpad * p.K1 * 2, 256);
+    p.gx = o;   o += align_up(mt_lstm_gx_bytes(B, T, w->hidden), 256);
+    p.hx = o;   o += align_up(mt_lstm_hx_bytes(B, T, w->hidden), 256);
+    p.sync_stride = align_up(mt_lstm_sync_bytes(B, w->hidden), 256);
+    p.sync = o; o += p.sync_stride * w->layers;
+    p.total = o;
+    return p;
+}
+}  // namespace mt
+
+using namespace mt;
+
+static int check_weights(const mt_cnnrnn_weights* w) {
+    MT_REQUIRE(w, MT_EINVAL, "cnnrnn: null weights");
+    MT_REQUIRE(w->n_mels >= 4 && w->layers >= 1 && w->layers <= MT_MAX_LSTM_LAYERS, MT_EINVAL,
+               "cnnrnn: bad config n_mels=%d layers=%d", w->n_mels, w->layers);
+    MT_REQUIRE(w->hidden >= 8 && w->hidden % 8 == 0 && w->hidden <= 1024, MT_EUNSUPPORTED,
+               "cnnrnn: hidden size %d unsupported (multiple of 8, <= 1024)", w->hidden);
+    MT_REQUIRE(w->conv1_w && w->conv1_b && w->conv2_w && w->conv2_b && w->fc_w && w->fc_b, MT_EINVAL, "cnnrnn: null weight pointer");
+    for (int l = 0; l < w->layers; ++l)
+        MT_REQUIRE(w->w_ih[l] && w->b_gates[l] && w->w_hh[l], MT_EINVAL, "cnnrnn: null LSTM weight pointer (layer %d)", l);
+    return MT_OK;
+}
+
+extern "C" size_t mt_cnnrnn_workspace_bytes(const mt_cnnrnn_weights* w, int B, int T) {
+    if (check_weights(w) != MT_OK || B <= 0 || T <= 0) return 0;
+    return plan(w, B, T).total;
+}
+
+// Offset of layer l's LSTM sync block inside the workspace (word 0 = hand-off status, 0 = ok).
+extern "C" size_t mt_cnnrnn_status_offset(const mt_cnnrnn_weights* w, int B, int T, int layer) {
+    if (check_weights(w) != MT_OK || B <= 0 || T <= 0) return 0;
+    const CnnRnnPlan p = plan(w, B, T);
+    return p.sync + p.sync_stride * layer;
+}
+
+extern "C" int mt_cnnrnn_forward(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
+                                 float* logits, void* workspace, size_t workspace_bytes, mt_stream_t stream) {
+    int rc = check_weights(w);
+    if (rc != MT_OK) return rc;
+    MT_REQUIRE(mel && logits && workspace, MT_EINVAL, "mt_cnnrnn_forward: null pointer");
+    MT_REQUIRE(B > 0 && T > 0, MT_EINVAL, "mt_cnnrnn_forward: bad dims B=%d T=%d", B, T);
+    const CnnRnnPlan p = plan(w, B, T);
+    MT_REQUIRE(workspace_bytes >= p.total, MT_EWORKSPACE, "mt_cnnrnn_forward: workspace %zu < %zu bytes", workspace_bytes, p.total);
+    char* ws = (char*)workspace;
+    const int H = w->hidden;
+    if ((rc = mt_conv1_bn_relu_pool(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, stream)) != MT_OK) return rc;
+    if ((rc = mt_conv2_bn_relu_pool(ws + p.act1, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, p.F1, T, stream)) != MT_OK) return rc;
+    if (p.K1 != 2 * H) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, (hipStream_t)stream));
+    for (int l = 0; l < w->layers; ++l) {
+        const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
+        const int K = l == 0 ? p.K0 : p.K1;
+        if ((rc = mt_gemm_lstm_gx(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, stream)) != MT_OK) return rc;
+        if ((rc = mt_lstm_bidir_fwd((const float*)(ws + p.gx), w->w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * l,
+                                    p.sync_stride, B, T, H, stream)) != MT_OK) return rc;
+        if ((rc = mt_lstm_relayout_bf16((const float*)(ws + p.hx), ws + p.x1, p.K1, B, T, H, stream)) != MT_OK) return rc;
+    }
+    return mt_gemm_logits(ws + p.x1, p.K1, w->fc_w, p.K1, w->fc_b, logits, B, T, MT_N_PITCH, p.K1, stream);
+}

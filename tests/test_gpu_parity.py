@@ -1,0 +1,183 @@
+"""GPU parity tests: the HIP path (through the C ABI of libmt_hip.so) against the CPU oracle
+on the same seeded inputs, and against the committed reference-generated goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import frontend_ref as FR
+from oracle import model_ref as R
+
+
+@pytest.fixture(scope="module")
+def mta():
+    import music_transcription_amd as m
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return m
+
+
+def _mel_in(B, nm, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(B, 1, nm, T, generator=g) * 60.0 - 70.0 + 10.0 * torch.randn(B, 1, nm, 1, generator=g))
+
+
+# ------------------------------------------------------------------ frontend
+MEL_MAX_TOL_DB = 5e-2    # worst bin (fp32 FFT cancellation noise on bins ~80 dB below the chunk peak)
+MEL_MEAN_TOL_DB = 2e-4
+
+
+@pytest.mark.parametrize("B,N,n_mels,hop", [(2, 480000, 320, 512), (3, 48000, 229, 512), (1, 16000, 64, 256),
+                                            (2, 1000, 32, 512), (1, 479744, 320, 512), (1, 123457, 80, 512)])
+def test_mel_matches_oracle(mta, B, N, n_mels, hop):
+    wave = FR.synth_audio(B, N, seed=N % 97)
+    fe = mta.MelFrontend(16000, n_mels, hop, "cuda")
+    mel, cmax = fe(torch.from_numpy(wave).cuda(), clamp=True)
+    ref = FR.audio_to_mel_batch(wave, 16000, n_mels, hop)
+    got = mel.cpu().numpy()
+    assert got.shape == ref.shape
+    d = np.abs(got - ref)
+    assert d.max() < MEL_MAX_TOL_DB and d.mean() < MEL_MEAN_TOL_DB, (d.max(), d.mean())
+    # per-chunk max of the mel power
+    pmax = np.array([FR.melspectrogram(w, 16000, n_mels, hop).max() for w in wave])
+    assert np.allclose(cmax.cpu().numpy(), pmax, rtol=2e-5)
+
+
+def test_mel_edge_signals(mta):
+    fe = mta.MelFrontend(16000, 320, 512, "cuda")
+    z, _ = fe(torch.zeros(1, 480000, device="cuda"))
+    assert np.abs(z.cpu().numpy() + 100.0).max() < 2e-5                      # silence
+    imp = np.zeros((1, 480000), np.float32); imp[0, 12345] = 1.0
+    m, _ = fe(torch.from_numpy(imp).cuda())
+    assert np.abs(m.cpu().numpy() - FR.audio_to_mel_batch(imp)).max() < MEL_MAX_TOL_DB
+    half = np.concatenate([FR.synth_audio(1, 240000, seed=3)[0], np.zeros(240000, np.float32)])[None]
+    m, _ = fe(torch.from_numpy(half).cuda())
+    ref = FR.audio_to_mel_batch(half)
+    assert np.abs(m.cpu().numpy() - ref).max() < MEL_MAX_TOL_DB
+    assert np.allclose(m.cpu().numpy()[0, 0, :, 600:], ref.max() - 80.0, atol=1e-3)   # clamp floor active
+
+
+def test_mel_unclamped_plus_chunk_max_equals_clamped(mta):
+    wave = torch.from_numpy(FR.synth_audio(2, 48000, seed=11)).cuda()
+    wave[1] *= 1e-3                                                          # per-CHUNK max, not per batch
+    fe = mta.MelFrontend(16000, 320, 512, "cuda")
+    a, cm = fe(wave, clamp=True)
+    b, cm2 = fe(wave, clamp=False)
+    floor = 10.0 * torch.log10(torch.clamp(cm2, min=1e-10)) - 80.0
+    assert torch.equal(torch.maximum(b, floor[:, None, None, None]), a)
+    assert float(a[1].max()) < float(a[0].max()) - 40
+
+
+def test_audio_to_mel_dropin(mta):
+    w = FR.synth_audio(1, 480000, seed=5)[0]
+    m = mta.audio_to_mel(w)
+    assert m.shape == (1, 1, 320, 938) and m.dtype == torch.float32 and not m.is_cuda
+    assert np.abs(m.numpy()[0, 0] - FR.audio_to_mel(w)).max() < MEL_MAX_TOL_DB
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 88, 1024), (4096, 4096, 512)])
+def test_gemm_bf16(mta, M, N, K):
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(M + N + K)
+    Mp, Np = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    A = torch.randn(Mp, K, generator=g).bfloat16().cuda()
+    W = torch.randn(Np, K, generator=g).bfloat16().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    Cc = torch.zeros(M, N, device="cuda")
+    check(lib.mt_gemm_bf16_f32acc(ptr(A), K, ptr(W), K, ptr(bias), ptr(Cc), N, M, N, K, stream_ptr()))
+    ref = A[:M].float().double().cpu() @ W[:N].float().double().cpu().t() + bias.double().cpu()
+    err = (Cc.double().cpu() - ref).abs().max().item()
+    assert err < 2e-4 * np.sqrt(K), err          # fp32 accumulation of exact bf16 products
+
+
+# ------------------------------------------------------------------ LSTM layer (input projection + recurrence)
+@pytest.mark.parametrize("B,T,H,K", [(2, 20, 16, 64), (5, 33, 32, 128), (32, 40, 512, 1024), (33, 12, 256, 192), (1, 50, 64, 64)])
+def test_lstm_layer_matches_oracle(mta, B, T, H, K):
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + H)
+    bound = 1.0 / np.sqrt(H)
+    u = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * bound
+    x = torch.randn(B, T, K, generator=g).bfloat16().float()          # exactly representable inputs
+    w_ih = [u(4 * H, K).bfloat16().float() for _ in range(2)]
+    w_hh = [u(4 * H, H) for _ in range(2)]
+    b_ih = [u(4 * H) for _ in range(2)]
+    b_hh = [u(4 * H) for _ in range(2)]
+    ref = torch.cat([R.lstm_dir(x, w_ih[d], w_hh[d], b_ih[d], b_hh[d], bool(d), R.Opts()) for d in range(2)], -1)
+    M = T * B
+    Mp, Np = (M + 127) // 128 * 128, (8 * H + 127) // 128 * 128
+    X = torch.zeros(Mp, K); X[:M] = x.transpose(0, 1).reshape(M, K)    # row m = t*B + b
+    Wp = torch.zeros(Np, K); Wp[:8 * H] = torch.cat(w_ih, 0)
+    X, Wp = X.bfloat16().cuda(), Wp.bfloat16().cuda()
+    bg = torch.cat([b_ih[0] + b_hh[0], b_ih[1] + b_hh[1]]).cuda()
+    whh = torch.stack(w_hh).contiguous().cuda()
+    gx = torch.empty(lib.mt_lstm_gx_bytes(B, T, H) // 4, device="cuda")
+    hx = torch.full((lib.mt_lstm_hx_bytes(B, T, H) // 4,), float("nan"), device="cuda")
+    sync = torch.empty(lib.mt_lstm_sync_bytes(B, H), dtype=torch.uint8, device="cuda")
+    y = torch.empty(B, T, 2 * H, device="cuda")
+    s = stream_ptr()
+    check(lib.mt_gemm_lstm_gx(ptr(X), K, ptr(Wp), K, ptr(bg), ptr(gx), B, T, H, K, s))
+    check(lib.mt_lstm_bidir_fwd(ptr(gx), ptr(whh), ptr(hx), ptr(sync), sync.numel(), B, T, H, s))
+    check(lib.mt_lstm_unpack_f32(ptr(hx), ptr(y), B, T, H, s))
+    torch.cuda.synchronize()
+    assert int(sync[:4].view(torch.int32).item()) == 0, "hand-off timeout"
+    err = (y.cpu() - ref).abs().max().item()
+    assert err < 2e-5, err
+    # next layer's A matrix
+    K1 = (2 * H + 63) // 64 * 64
+    X1 = torch.zeros(Mp, K1, dtype=torch.bfloat16, device="cuda")
+    check(lib.mt_lstm_relayout_bf16(ptr(hx), ptr(X1), K1, B, T, H, s))
+    want = y.transpose(0, 1).reshape(M, 2 * H).bfloat16()
+    assert torch.equal(X1[:M, :2 * H], want)
+
+
+# ------------------------------------------------------------------ whole model
+@pytest.mark.parametrize("tag", ["small_a", "small_b"])
+def test_cnnrnn_small_vs_reference_golden(mta, golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, "small_models.npz"))
+    nm, hs, nl, B, T, wseed, xseed = [int(v) for v in z[f"{tag}_cfg"]]
+    sd = R.make_state_dict("cnn_rnn", nm, hs, nl, wseed)
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = _mel_in(B, nm, T, xseed)
+    with torch.no_grad():
+        got = model.model(x.cuda(), check_status=True).cpu()
+        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_bf16=True))
+    golden = torch.from_numpy(z[f"{tag}_logits"])
+    assert got.shape == golden.shape
+    assert (got - emu).abs().max().item() < 2e-3          # same bf16 input rounding: only fp32 ordering differs
+    assert (got - golden).abs().max().item() < 3e-2       # vs the fp32 reference itself (bf16 GEMM inputs)
+    pred = model.predict(x.cuda(), threshold=0.5).cpu()
+    flips = (pred != R.predict(golden, 0.5)).float().mean().item()
+    assert flips < 0.02
+
+
+def test_cnnrnn_canonical_vs_reference_golden(mta, golden_dir):
+    c = np.load(os.path.join(golden_dir, "canonical_models.npz"))
+    for tag in ("small_937", "small_938"):
+        nm, hs, nl, B, T, wseed, xseed = [int(v) for v in c[f"{tag}_cfg"]]
+        sd = R.make_state_dict("cnn_rnn", nm, hs, nl, wseed)
+        model = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda")
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        x = _mel_in(B, nm, T, xseed)
+        with torch.no_grad():
+            got = model.model(x.cuda(), check_status=True).cpu().numpy()
+        d = np.abs(got[:, ::5, ::7] - c[f"{tag}_sample"])
+        assert d.max() < 3e-2, d.max()
+        assert abs(got.mean() - c[f"{tag}_stats"][0]) < 2e-3
+
+
+def test_errors_are_loud(mta):
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=32, hidden_size=16, num_layers=1, device="cuda").eval()
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 1, 32, 10))                  # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        mta.TranscriptionModel("nope")
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 1, 31, 10, device="cuda"))
+    with torch.no_grad():
+        assert model(torch.zeros(2, 1, 32, 0, device="cuda")).shape == (2, 88, 1)
