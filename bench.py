@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- 30 s audio chunks/s through the MI355X hot path (mel frontend + CNNRNNModel forward).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of `--batch` synthetic 30 s / 16 kHz chunks
+already resident in HBM (BASELINE.json configs[1]: CNNRNNModel (36M) inference, batch = 32):
+    waveform (B, 480000) f32 -> mt_mel_db_f32 -> conv1 -> conv2 -> 3 x (bf16 MFMA input projection
+    -> persistent fp32 bi-LSTM recurrence -> re-layout) -> fc -> logits (B, 88, 938) f32.
+Chunks are independent (main.py:258-266 keeps no cross-chunk state), so N GPUs run N independent
+batches with no data-path collective (weak scaling); the only collectives are the timing barrier
+and a MAX over ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the kernel that dominates the step, timed with HIP events on the launch stream
+                  inside the timed region (events recorded natively by mt_cnnrnn_forward_ex);
+  stages       -- the same for every kernel of the step;
+  cpu_baseline -- the CPU oracle (a port of the reference path, oracle/*.py) timed on this node's
+                  host cores on a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# chip peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense; spec)
+PEAK_HBM_GBS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_F32_MATRIX_TFLOPS = 157.3
+
+N_SAMPLES, SR, HOP, N_MELS, HIDDEN, LAYERS = 480000, 16000, 512, 320, 512, 3
+
+
+def stage_table(B, T, n_mels, H, L):
+    """(name, bound, work per launch, unit of work) for each timed stage, in launch order.
+    Algorithmic figures: SURVEY 8(d) / DESIGN.md 'Kernels'."""
+    F1, Fo2 = n_mels // 2, n_mels // 4
+    M = B * T
+    st = [("mel_kernel", "hbm", B * (4 * N_SAMPLES + 4 * n_mels * T), "B"),
+          ("conv1_kernel", "hbm", B * (4 * n_mels * T + 2 * 32 * F1 * T), "B"),
+          ("conv2_kernel", "mfma", 2.0 * B * (2 * Fo2) * T * 64 * 288, "FLOP")]
+    for l in range(L):
+        K = Fo2 * 64 if l == 0 else 2 * H
+        st.append((f"gemm_lstm_gx_l{l}", "mfma", 2.0 * M * 8 * H * K, "FLOP"))
+        st.append((f"lstm_rec_l{l}", "mfma_f32", 2.0 * M * 8 * H * H, "FLOP"))
+        st.append((f"lstm_relayout_l{l}", "hbm", M * 2 * H * (4 + 2), "B"))
+    st.append(("gemm_logits", "mfma", 2.0 * M * 88 * 2 * H, "FLOP"))
+    return st
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota and by the
+    GPU box's per-GPU CPU share (16).  os.cpu_count() alone oversubscribes a quota'd container."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("MT_BENCH_CPU_THREADS", "16"))))
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import music_transcription_amd as mta
+    from oracle import frontend_ref, model_ref
+
+    B, K, W = args.batch, args.steps, args.warmup
+    T = mta.num_frames(N_SAMPLES, HOP)
+    # seeded synthetic input: noise + decaying piano-range sinusoids; seed = 1234 + rank.
+    # Four distinct chunks tiled to the batch keep host-side synthesis short; the kernels see B chunks.
+    base = frontend_ref.synth_audio(min(B, 4), N_SAMPLES, seed=1234 + rank)
+    wave = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B].copy()).to(dev)
+    sd = model_ref.make_state_dict("cnn_rnn", N_MELS, HIDDEN, LAYERS, seed=0)
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=N_MELS, hidden_size=HIDDEN, num_layers=LAYERS, device=str(dev))
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    net = model.model
+    fe = mta.MelFrontend(SR, N_MELS, HOP, dev)
+    mel = torch.empty(B, 1, N_MELS, T, device=dev)
+    cmax = torch.empty(B, device=dev)
+
+    nst = 3 + 3 * LAYERS
+    ev_mel = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K)]
+    ev_net = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K)]
+    for row in ev_mel + ev_net:          # create the underlying hipEvent_t handles before the timed region
+        for e in row:
+            e.record()
+
+    def step(i=None):
+        if i is not None:
+            ev_mel[i][0].record()
+        fe(wave, clamp=False, out=mel, chunk_max=cmax)        # unclamped dB + per-chunk max; conv1 clamps on load
+        if i is not None:
+            ev_mel[i][1].record()
+        with torch.no_grad():
+            return net(mel, chunk_max_power=cmax, events=None if i is None else ev_net[i])
+
+    log(f"rank {rank}/{world}: setup done, B={B} T={T}; warmup {W}, steps {K}")
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        logits = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    net.raise_on_handoff_timeout(B, T)
+    log(f"timed region: {elapsed:.3f} s for {K} steps")
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        # ---- per-kernel times from the events recorded inside the timed region
+        table = stage_table(B, T, N_MELS, HIDDEN, LAYERS)
+        ms = [float(np.mean([ev_mel[i][0].elapsed_time(ev_mel[i][1]) for i in range(K)]))]
+        for s in range(nst):
+            ms.append(float(np.mean([ev_net[i][s].elapsed_time(ev_net[i][s + 1]) for i in range(K)])))
+        stages = []
+        for (name, bound, work, unit), t_ms in zip(table, ms):
+            if unit == "B":
+                ach, peak, u = work / (t_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+            else:
+                ach = work / (t_ms * 1e-3) / 1e12
+                peak, u = (PEAK_F32_MATRIX_TFLOPS if bound == "mfma_f32" else PEAK_BF16_TFLOPS), "TFLOP/s"
+            stages.append({"kernel": name, "bound": "hbm" if bound == "hbm" else "mfma", "ms": round(t_ms, 4),
+                           "achieved": round(ach, 2), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
+                           "work_per_launch": work, "work_unit": unit,
+                           "mfma_dtype": {"mfma": "bf16", "mfma_f32": "f32"}.get(bound)})
+        # dominant kernel = largest share of the step; the three recurrence launches are one kernel
+        groups = {}
+        for s in stages:
+            key = s["kernel"].rsplit("_l", 1)[0] if "_l" in s["kernel"] else s["kernel"]
+            g = groups.setdefault(key, {"ms": 0.0, "work": 0.0, "n": 0, "ref": s})
+            g["ms"] += s["ms"]; g["work"] += s["work_per_launch"]; g["n"] += 1
+        dom_key = max(groups, key=lambda k: groups[k]["ms"])
+        g = groups[dom_key]
+        avg_ms, avg_work = g["ms"] / g["n"], g["work"] / g["n"]
+        ref = g["ref"]
+        ach = avg_work / (avg_ms * 1e-3) / (1e9 if ref["work_unit"] == "B" else 1e12)
+        roofline = {"kernel": dom_key, "bound": ref["bound"], "achieved": round(ach, 2), "peak": ref["peak"],
+                    "unit": ref["unit"], "frac": round(ach / ref["peak"], 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": g["n"],
+                    "share_of_step": round(g["ms"] / sum(ms), 3), "mfma_dtype": ref["mfma_dtype"]}
+
+        # ---- CPU baseline: the oracle (port of the reference path) on this node's host cores
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cores = host_cores()
+            log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
+            torch.set_num_threads(cores)
+            w_np = wave[:1].cpu().numpy()
+            def cpu_chunk():
+                m = frontend_ref.audio_to_mel_batch(w_np, SR, N_MELS, HOP)          # main.py:117-125
+                with torch.no_grad():
+                    return model_ref.cnnrnn_forward(sd, torch.from_numpy(m), model_ref.Opts(fast_lstm=True))
+            t1 = time.perf_counter(); ref_logits = cpu_chunk(); first = time.perf_counter() - t1
+            log(f"cpu baseline: first chunk {first:.2f} s")
+            n = int(max(2, min(24, 15.0 / max(first, 1e-3))))
+            t1 = time.perf_counter()
+            for _ in range(n):
+                cpu_chunk()
+            dt = time.perf_counter() - t1
+            cpu = {"value": round(n / dt, 3), "unit": "chunks/s", "cores": cores, "kind": "port",
+                   "sample": f"{n} chunks, batch 1 (the reference's main.py:258 loop): numpy STFT/mel/dB + fp32 torch-CPU "
+                             f"CNNRNNModel forward (oracle/frontend_ref.py + oracle/model_ref.py), {cores} threads"}
+            # the timed GPU logits for chunk 0 must agree with the oracle (same weights, same audio)
+            err = float((logits[0].cpu() - ref_logits[0]).abs().max())
+            cpu["max_abs_logit_diff_vs_gpu"] = round(err, 5)
+
+        out = {"metric": "30 s audio chunks/sec (mel+CNNRNN forward)", "value": round(world * B * K / elapsed, 2),
+               "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16 MFMA GEMM inputs, f32 accumulate; f32 FFT, conv1 and LSTM recurrence",
+               "data": "synthetic",
+               "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
+                                      "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
+                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)"},
+               "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

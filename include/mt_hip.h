@@ -142,6 +142,13 @@ size_t mt_cnnrnn_status_offset(const mt_cnnrnn_weights* w, int B, int T, int lay
 int    mt_cnnrnn_forward(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power,
                          int B, int T, float* logits, void* workspace, size_t workspace_bytes,
                          mt_stream_t stream);
+/* Same, recording the caller's hipEvent_t handles (events[0] before the first kernel, then
+ * one after each stage: conv1, conv2, (input-projection GEMM, recurrence, re-layout) x layers,
+ * fc) so that a benchmark can time each kernel on the launch stream.  events may be NULL.   */
+int    mt_cnnrnn_num_stages(int layers);
+int    mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power,
+                            int B, int T, float* logits, void* workspace, size_t workspace_bytes,
+                            void* const* events, int n_events, mt_stream_t stream);
 
 #ifdef __cplusplus
 }

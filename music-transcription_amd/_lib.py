@@ -69,6 +69,8 @@ _SIGS = {
     "mt_cnnrnn_workspace_bytes": (sz, [C.POINTER(CnnRnnWeights), i32, i32]),
     "mt_cnnrnn_status_offset": (sz, [C.POINTER(CnnRnnWeights), i32, i32, i32]),
     "mt_cnnrnn_forward": (i32, [C.POINTER(CnnRnnWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
+    "mt_cnnrnn_num_stages": (i32, [i32]),
+    "mt_cnnrnn_forward_ex": (i32, [C.POINTER(CnnRnnWeights), vp, vp, i32, i32, vp, vp, sz, C.POINTER(vp), i32, vp]),
 }
 EXPORTS = tuple(_SIGS)
 for _name, (_res, _args) in _SIGS.items():

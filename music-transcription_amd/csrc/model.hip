@@ -66,8 +66,20 @@ extern "C" size_t mt_cnnrnn_status_offset(const mt_cnnrnn_weights* w, int B, int
     return p.sync + p.sync_stride * layer;
 }
 
-extern "C" int mt_cnnrnn_forward(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
-                                 float* logits, void* workspace, size_t workspace_bytes, mt_stream_t stream) {
+// Stage boundaries at which mt_cnnrnn_forward_ex records the caller's events (bench.py times kernels with them).
+static inline int rec(void* const* events, int n_events, int& idx, hipStream_t st) {
+    if (events && idx < n_events) {
+        MT_CHECK_HIP(hipEventRecord((hipEvent_t)events[idx], st));
+    }
+    ++idx;
+    return MT_OK;
+}
+
+extern "C" int mt_cnnrnn_num_stages(int layers) { return 3 + 3 * layers; }   // conv1, conv2, (gemm, rec, relayout) x L, fc
+
+extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
+                                    float* logits, void* workspace, size_t workspace_bytes,
+                                    void* const* events, int n_events, mt_stream_t stream) {
     int rc = check_weights(w);
     if (rc != MT_OK) return rc;
     MT_REQUIRE(mel && logits && workspace, MT_EINVAL, "mt_cnnrnn_forward: null pointer");
@@ -76,16 +88,30 @@ extern "C" int mt_cnnrnn_forward(const mt_cnnrnn_weights* w, const float* mel, c
     MT_REQUIRE(workspace_bytes >= p.total, MT_EWORKSPACE, "mt_cnnrnn_forward: workspace %zu < %zu bytes", workspace_bytes, p.total);
     char* ws = (char*)workspace;
     const int H = w->hidden;
+    hipStream_t st = (hipStream_t)stream;
+    int ei = 0;
+    if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;                      // event 0: start
     if ((rc = mt_conv1_bn_relu_pool(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, stream)) != MT_OK) return rc;
+    if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     if ((rc = mt_conv2_bn_relu_pool(ws + p.act1, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, p.F1, T, stream)) != MT_OK) return rc;
+    if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     if (p.K1 != 2 * H) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, (hipStream_t)stream));
     for (int l = 0; l < w->layers; ++l) {
         const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
         const int K = l == 0 ? p.K0 : p.K1;
         if ((rc = mt_gemm_lstm_gx(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, stream)) != MT_OK) return rc;
+        if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
         if ((rc = mt_lstm_bidir_fwd((const float*)(ws + p.gx), w->w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * l,
                                     p.sync_stride, B, T, H, stream)) != MT_OK) return rc;
+        if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
         if ((rc = mt_lstm_relayout_bf16((const float*)(ws + p.hx), ws + p.x1, p.K1, B, T, H, stream)) != MT_OK) return rc;
+        if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     }
-    return mt_gemm_logits(ws + p.x1, p.K1, w->fc_w, p.K1, w->fc_b, logits, B, T, MT_N_PITCH, p.K1, stream);
+    if ((rc = mt_gemm_logits(ws + p.x1, p.K1, w->fc_w, p.K1, w->fc_b, logits, B, T, MT_N_PITCH, p.K1, stream)) != MT_OK) return rc;
+    return rec(events, n_events, ei, st);
+}
+
+extern "C" int mt_cnnrnn_forward(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
+                                 float* logits, void* workspace, size_t workspace_bytes, mt_stream_t stream) {
+    return mt_cnnrnn_forward_ex(w, mel, chunk_max_power, B, T, logits, workspace, workspace_bytes, nullptr, 0, stream);
 }

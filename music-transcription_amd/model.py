@@ -119,7 +119,7 @@ class CNNRNNModel(nn.Module, _HipForward):
         w.fc_w, w.fc_b = ptr(t["fc_w"]), ptr(t["fc_b"])
         return {"tensors": t, "struct": w}
 
-    def forward(self, x, chunk_max_power: Optional[torch.Tensor] = None, check_status: bool = False):
+    def forward(self, x, chunk_max_power: Optional[torch.Tensor] = None, check_status: bool = False, events=None):
         self._require_cuda(x)
         if self.training or (torch.is_grad_enabled() and x.requires_grad):
             raise NotImplementedError("the HIP path implements the eval-mode forward; the training step "
@@ -140,9 +140,14 @@ class CNNRNNModel(nn.Module, _HipForward):
                 raise _lib.MtError("mt_cnnrnn_workspace_bytes: " + _lib.last_error())
             self._ws = {key: torch.empty(nbytes, dtype=torch.uint8, device=x.device)}   # keep one shape resident
         ws = self._ws[key]
+        ev_arr, n_ev = None, 0
+        if events is not None:   # torch.cuda.Event(enable_timing=True) objects, already created (recorded once)
+            import ctypes
+            n_ev = len(events)
+            ev_arr = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in events])
         with torch.cuda.device(x.device):
-            check(lib.mt_cnnrnn_forward(w, ptr(x), ptr(chunk_max_power), B, T, ptr(logits), ptr(ws), ws.numel(),
-                                        _lib.stream_ptr()), "mt_cnnrnn_forward")
+            check(lib.mt_cnnrnn_forward_ex(w, ptr(x), ptr(chunk_max_power), B, T, ptr(logits), ptr(ws), ws.numel(),
+                                           ev_arr, n_ev, _lib.stream_ptr()), "mt_cnnrnn_forward")
         if check_status:
             self.raise_on_handoff_timeout(B, T)
         return logits
