@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent batches in flight per GPU (each step is issued whole on stream i %% streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -110,8 +112,10 @@ def main():
     model.eval()
     net = model.model
     fe = mta.MelFrontend(SR, N_MELS, HOP, dev)
-    mel = torch.empty(B, 1, N_MELS, T, device=dev)
-    cmax = torch.empty(B, device=dev)
+    NS = max(1, args.streams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
+    cmax = [torch.empty(B, device=dev) for _ in range(NS)]
 
     nst = 3 + 3 * LAYERS
     ev_mel = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K)]
@@ -120,25 +124,27 @@ def main():
         for e in row:
             e.record()
 
-    def step(i=None):
-        if i is not None:
-            ev_mel[i][0].record()
-        fe(wave, clamp=False, out=mel, chunk_max=cmax)        # unclamped dB + per-chunk max; conv1 clamps on load
-        if i is not None:
-            ev_mel[i][1].record()
-        with torch.no_grad():
-            return net(mel, chunk_max_power=cmax, events=None if i is None else ev_net[i])
+    def step(j, i=None):
+        """One whole pass (mel + forward) over one batch, issued on stream j % NS."""
+        s = j % NS
+        with torch.cuda.stream(streams[s]), torch.no_grad():
+            if i is not None:
+                ev_mel[i][0].record()
+            fe(wave, clamp=False, out=mel[s], chunk_max=cmax[s])   # unclamped dB + per-chunk max; conv1 clamps on load
+            if i is not None:
+                ev_mel[i][1].record()
+            return net(mel[s], chunk_max_power=cmax[s], events=None if i is None else ev_net[i])
 
     log(f"rank {rank}/{world}: setup done, B={B} T={T}; warmup {W}, steps {K}")
-    for _ in range(W):
-        step()
+    for j in range(max(W, NS if W else 0)):
+        step(j)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        logits = step(i)
+        logits = step(i, i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -216,7 +222,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
                                       "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
-                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)"},
+                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)", "streams_per_gpu": NS},
                "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
         print(json.dumps(out))
     if world > 1:

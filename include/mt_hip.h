@@ -98,11 +98,14 @@ int    mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const floa
                       int B, int T, int N, int K, mt_stream_t stream);
 
 /* ------------------------------------------------------------------ bidirectional LSTM recurrence
- * nn.LSTM(batch_first, bidirectional) as the reference runs it in fp32
- * (cnn_rnn_model.py:45-52,:69-70): gate order i,f,g,o, zero initial state.
- * w_hh = [fwd; reverse] x [4H][H] f32.  hx receives every step's h in the MFMA-operand
- * layout hx[b/32][t][dir][j/8][(j%2)*32 + b%32][(j%8)/2].  sync_ws: mt_lstm_sync_bytes();
- * after the stream has drained its word 0 is 0 (ok) or 1 + step (hand-off timeout).      */
+ * nn.LSTM(batch_first, bidirectional) as the reference runs it (cnn_rnn_model.py:45-52,
+ * :69-70): gate order i,f,g,o, zero initial state; fp32 state/gates/accumulation, W_hh h as a
+ * split-precision bf16x3 product (fp32-equivalent to ~1e-6 per gate).  H % 16 == 0, H <= 1024.
+ * w_hh = [fwd; reverse] x [4H][H] f32.  hx receives every step's h as bf16 hi/lo pieces in
+ * the MFMA-operand layout hx[b/32][t][dir][k/16][hi|lo][((k/8)%2)*32 + b%32][k%8] (the hi
+ * pieces are bf16(h), the next GEMM's operand).  sync_ws: mt_lstm_sync_bytes(); after the
+ * stream has drained its word 0 is 0 (ok), 1 + step (flag spin timed out) or
+ * 0x40000000 + step (payload spin timed out).                                              */
 size_t mt_lstm_gx_bytes(int B, int T, int H);
 size_t mt_lstm_hx_bytes(int B, int T, int H);
 size_t mt_lstm_sync_bytes(int B, int H);
@@ -119,7 +122,7 @@ int    mt_lstm_unpack_f32(const float* hx, float* y, int B, int T, int H, mt_str
 #define MT_MAX_LSTM_LAYERS 8
 typedef struct {
     int n_mels;                              /* input mel bins                                    */
-    int hidden;                              /* LSTM hidden size H (multiple of 8, <= 1024)       */
+    int hidden;                              /* LSTM hidden size H (multiple of 16, <= 1024)      */
     int layers;                              /* LSTM layers (<= MT_MAX_LSTM_LAYERS)               */
     int reserved;
     const float* conv1_w;                    /* [32][9]  BN-folded                                */

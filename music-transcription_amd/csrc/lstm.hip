@@ -1,6 +1,9 @@
-// Bidirectional LSTM recurrence for gfx950 (persistent kernel), fp32 throughout as in the
-// reference (cnn_rnn_model.py:69-70 forces the LSTM to fp32; gate order i,f,g,o; zero
-// initial state; the reverse direction consumes t = T-1 .. 0).
+// Bidirectional LSTM recurrence for gfx950 (persistent kernel).  The reference runs the LSTM in
+// fp32 (cnn_rnn_model.py:69-70; gate order i,f,g,o; zero initial state; the reverse direction
+// consumes t = T-1 .. 0).  Here state, gates and accumulation are fp32 and the W_hh h product is
+// split-precision bf16 ("bf16x3": W = Whi + Wlo, h = hhi + hlo, three MFMAs, dropped term
+// <= 2^-16 relative): fp32-equivalent to ~1e-6 on a gate, 5x fewer matrix-pipe cycles than the
+// f32-input MFMA, and the published h (hi piece) is already the next GEMM's bf16 operand.
 //
 // One launch = one LSTM layer, both directions, all batch groups.  The input projections
 // W_ih x_t + b_ih + b_hh come from the GEMM (gemm.hip, EPI_LSTM_GX); this kernel does the
@@ -11,22 +14,26 @@
 // and keeps its 32 x H slice of W_hh in REGISTERS as MFMA A-operands for the whole sequence.
 // Per step every workgroup needs the full h_{t-1} (H x 32 batch, 64 KB at H = 512), produced
 // by all S workgroups of its direction: an all-gather through L2 per step.
-//   * v_mfma_f32_32x32x2_f32 (exact f32 FMA chain): D[gate row][batch] += W[row][k] * h[k][batch],
+//   * v_mfma_f32_32x32x16_bf16 x 3 per 16-wide k-step: D[gate row][batch] += W[row][k] * h[k][batch],
 //     K split over the 4 waves, partial tiles summed through LDS;
 //   * gate rows are ordered row = 8q + 4h + p  <->  unit 2q + h, gate p, so that after the
 //     cross-wave sum lane (batch b, half h) of wave q holds all four gates of ONE unit:
 //     the cell update is lane-local, c_t lives in a register;
-//   * h_t is published in the exact MFMA B-operand layout ([k-block][lane][4] floats:
-//     lane = (k parity)*32 + batch, element i <-> k = 8 kb + 2 i + parity), one 1-KB block per
-//     workgroup per step, so consumers fetch it with one 16-B load per lane per k-block;
-//   * the published blocks of ALL steps are kept (hx[g][t][d][kb][64][4]): they are the layer's
-//     output, re-laid out for the next GEMM by lstm_relayout_kernel, so nothing else is stored
-//     on the critical path and no slot is ever reused (no WAR hazard between steps).
-// Hand-off (MI355X_MICROARCH.md, "Valid forms", write-through row): payload stores are sc1,
-// every storing wave drains vmcnt(0), workgroup barrier, ONE lane stores the monotonic step
-// flag (relaxed, agent scope = sc1); consumers poll all S flags of their direction with ONE
-// wave (relaxed sc1 loads, s_sleep between polls), workgroup barrier, then every h load is an
-// sc1 buffer load (bypasses the per-CU L1, which is never refreshed by other CUs' stores).
+//   * h_t is published in the exact MFMA B-operand layout, as bf16 hi and lo pieces
+//     (hx[g][t][d][k-step][hi|lo][lane = (k half)*32 + batch][8 bf16], 1 KB per workgroup per
+//     step), so consumers fetch it with two 16-B loads per lane per k-step;
+//   * the published blocks of ALL steps are kept: they are the layer's output, re-laid out for
+//     the next GEMM by lstm_relayout_kernel, so nothing else is stored on the critical path and
+//     no slot is ever reused (no WAR hazard between steps).
+// Hand-off (MI355X_MICROARCH.md, "Valid forms", write-through row): the workgroup's 1-KB block is
+// assembled in LDS and written by ONE wave as one 16-B-per-lane sc1 (write-through) store; that
+// wave drains vmcnt(0) and its lane 0 stores the monotonic step flag (relaxed, agent scope).
+// Consumers poll the S flags of their direction with ONE wave, one memory round trip per poll
+// (flags and the abort word in the same burst), workgroup barrier, then every payload load is
+// an sc1 buffer load (bypasses the per-CU L1, which is never refreshed by other CUs' stores).
+// Belt and braces: hx is filled with the poison pattern 0xFFFFFFFF (never a hidden state,
+// |h| < 1) before every launch, and a consumer that still sees a poisoned dword redoes its
+// loads -- so a flag that overtook its payload costs time, never correctness.
 // Every spin is bounded: on timeout the workgroup raises the abort word, which every other
 // workgroup's spin also watches, and all workgroups drain.
 #include "mt_common.h"
@@ -46,40 +53,69 @@ struct LstmArgs {
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh(x) = 2 sigmoid(2x) - 1: absolute error ~1e-7 (v_exp_f32 based), saturates cleanly for |x| large
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }
+constexpr unsigned H_POISON = 0xFFFFFFFFu;   // never the bit pattern of a hidden state (|h| < 1)
 
-template <int NKBW>   // k-blocks (8 hidden units each) per wave: ceil(H/8/4)
+// Diagnostic build only (-DMT_LSTM_DIAG): per-phase wall-clock shares of a step, accumulated by wave 0
+// lane 0 of every workgroup into mt_lstm_diag[workgroup][phase] (10 ns ticks).  Never in the shipped build.
+#ifdef MT_LSTM_DIAG
+__device__ unsigned long long mt_lstm_diag[1024][8];
+#define DIAG_STAMP(i) do { if (tid == 0) { const long long n_ = __builtin_amdgcn_s_memrealtime(); dg[i] += n_ - tl; tl = n_; } } while (0)
+#else
+#define DIAG_STAMP(i) do { } while (0)
+#endif
+
+// split an fp32 value into two bf16 pieces: x ~= hi + lo with |x - hi - lo| <= 2^-17 |x|
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+    hi = f32_to_bf16(x);
+    lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+
+template <int NKSW>   // 16-wide k-steps per wave: ceil(H/16/4)
 __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][16][64];
+    __shared__ __attribute__((aligned(16))) bf16_t hs[2][32][8];       // [hi|lo][batch][unit]
     __shared__ int abort_s;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int kb = blockIdx.x, d = blockIdx.y, g = blockIdx.z + a.g0;
-    const int H = a.H, T = a.T, nkb = H >> 3;
+    const int H = a.H, T = a.T, nkb = H >> 3, nks = H >> 4;
     const int b = lane & 31, hh = lane >> 5;
     const int Bg = min(32, a.B - g * 32);            // valid batch rows of this group
 
-    // ---- W_hh slice as MFMA A-operands: lane (row r, k parity hh); row r = 8q + 4h + p
+    // ---- W_hh slice as MFMA A-operands (bf16 hi + lo): lane (row r, k half hh) holds
+    //      W[row][16 ks + 8 hh + j], j = 0..7; row r = 8q + 4h + p <-> unit 2q + h, gate p
     const int r = lane & 31, q = r >> 3, rh = (r >> 2) & 1, p = r & 3;
     const int wrow = p * H + kb * 8 + 2 * q + rh;
     const float* wsrc = a.w_hh + ((size_t)d * 4 * H + wrow) * H;
-    float wreg[NKBW * 4];
+    bf16x8 whi[NKSW], wlo[NKSW];
 #pragma unroll
-    for (int kbi = 0; kbi < NKBW; ++kbi) {
-        const int blk = wv * NKBW + kbi;
+    for (int i = 0; i < NKSW; ++i) {
+        const int ks = wv * NKSW + i;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wreg[kbi * 4 + i] = (blk < nkb) ? wsrc[blk * 8 + 2 * i + hh] : 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            bf16_t hi = 0, lo = 0;
+            if (ks < nks) split_bf16(wsrc[ks * 16 + 8 * hh + j], hi, lo);
+            whi[i][j] = (short)hi;
+            wlo[i][j] = (short)lo;
+        }
     }
 
     // this thread's cell: unit jl = 2*wv + hh of the workgroup, batch row b
     const int jl = 2 * wv + hh;
     float c = 0.0f;
-    const size_t gd_blocks = (size_t)T * 2 * nkb;                       // blocks per batch group
+    const size_t gd_blocks = (size_t)T * 2 * nkb;                       // 1-KB blocks per batch group
     const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
-    float* hx_g = a.hx + (size_t)g * gd_blocks * 256;
+    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 1024;
     // buffer resource over this group's hx (all t, both d): offsets stay < 2^31
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 1024), 0x00020000);
     unsigned* flags = a.flags + ((size_t)g * 2 + d) * nkb;
     if (tid == 0) abort_s = 0;
     __syncthreads();
+#ifdef MT_LSTM_DIAG
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tl = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (int s = 0; s < T; ++s) {
         const int t = d ? (T - 1 - s) : s;
@@ -94,69 +130,138 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
         if (s > 0) {
-            // ---- wait until every workgroup of this direction has published step s-1
+            // ---- wait until every workgroup of this direction has published step s-1.  One round trip per
+            //      poll: every lane loads one flag and, in the same burst, a second flag (H > 512) or the abort word.
             if (wv == 0) {
-                const long long t0 = __builtin_amdgcn_s_memrealtime();
+                const unsigned* p1 = flags + (lane < nkb ? lane : nkb - 1);
+                const unsigned* p2 = (lane + 64 < nkb) ? flags + lane + 64 : a.status;
+                const bool p2_is_flag = (lane + 64 < nkb);
+                long long t0 = 0;
                 bool ok = false;
-                while (true) {
-                    bool mine = true;
-                    for (int i = lane; i < nkb; i += 64)
-                        mine &= (__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)s);
-                    if (__all(mine)) { ok = true; break; }
-                    if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > LSTM_SPIN_LIMIT_TICKS) {
-                        if (lane == 0) __hip_atomic_store(a.status, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
+                for (unsigned it = 0;; ++it) {
+                    const unsigned v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned v2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ready = (v1 >= (unsigned)s) && (!p2_is_flag || v2 >= (unsigned)s);
+                    if (__any(!p2_is_flag && v2 != 0)) break;                         // another workgroup gave up
+                    if (__all(ready)) { ok = true; break; }
+                    if ((it & 255u) == 255u) {
+                        const long long now = __builtin_amdgcn_s_memrealtime();
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > LSTM_SPIN_LIMIT_TICKS) {
+                            if (lane == 0) __hip_atomic_store(a.status, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
                     }
-                    __builtin_amdgcn_s_sleep(1);
                 }
                 if (!ok && lane == 0) abort_s = 1;
             }
+            DIAG_STAMP(0);
             __syncthreads();
+            DIAG_STAMP(1);
             if (abort_s) return;                       // uniform: every wave of the workgroup leaves
-            // ---- gather h_{t-1}: one 16-B sc1 load per lane per k-block, then the MFMA chain
-            f32x4 hv[NKBW];
+            // ---- gather h_{t-1} (hi and lo pieces: two 16-B sc1 loads per lane per k-step) and run the
+            //      split-precision MFMA chain  W h ~= Whi hhi + Whi hlo + Wlo hhi  (f32 accumulate).
+            //      A word still holding the poison pattern means its store has not landed: redo (rare, bounded).
             const int hbase = ((tprev * 2 + d) * nkb) * 1024 + lane * 16;
+            long long t1 = 0;
+            for (unsigned it = 0;; ++it) {
+                typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+                u32x4 rhi[NKSW], rlo[NKSW];
 #pragma unroll
-            for (int kbi = 0; kbi < NKBW; ++kbi) {
-                const int blk = wv * NKBW + kbi;
-                if (blk < nkb) {
-                    hv[kbi] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + blk * 1024, 0, 16 /*sc1*/));
-                } else {
-                    hv[kbi] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int i = 0; i < NKSW; ++i) {
+                    const int ks = wv * NKSW + i;
+                    if (ks < nks) {
+                        rhi[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 2048, 0, 16 /*sc1*/);
+                        rlo[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 2048 + 1024, 0, 16 /*sc1*/);
+                    } else {
+                        rhi[i] = u32x4{0, 0, 0, 0};
+                        rlo[i] = u32x4{0, 0, 0, 0};
+                    }
+                }
+                unsigned worst = 0;
+#pragma unroll
+                for (int i = 0; i < NKSW; ++i) {
+                    worst = max(max(worst, max(rhi[i][0], rhi[i][1])), max(rhi[i][2], rhi[i][3]));
+                    worst = max(max(worst, max(rlo[i][0], rlo[i][1])), max(rlo[i][2], rlo[i][3]));
+                    const bf16x8 hhi = __builtin_bit_cast(bf16x8, rhi[i]), hlo = __builtin_bit_cast(bf16x8, rlo[i]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[i], hhi, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[i], hlo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[i], hhi, acc, 0, 0, 0);
+                }
+                if (!__any(worst == H_POISON)) break;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                if ((it & 255u) == 255u) {
+                    const long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t1 == 0) t1 = now;
+                    else if (now - t1 > LSTM_SPIN_LIMIT_TICKS) {
+                        if (lane == 0) {
+                            __hip_atomic_store(a.status, 0x40000000u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            abort_s = 1;
+                        }
+                        break;
+                    }
                 }
             }
-#pragma unroll
-            for (int kbi = 0; kbi < NKBW; ++kbi)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kbi * 4 + i], hv[kbi][i], acc, 0, 0, 0);
         }
+#ifdef MT_LSTM_DIAG
+        asm volatile("" :: "v"(acc[0]));
+#endif
+        DIAG_STAMP(2);
         // ---- sum the four K-slices through LDS; wave wv finishes gate rows 8wv + 4h + p
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[wv][e][lane] = acc[e];
         __syncthreads();
+        DIAG_STAMP(3);
+        if (abort_s) return;                           // a payload spin gave up (status word says where)
         float pre[4];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp)
             pre[pp] = ((red[0][4 * wv + pp][lane] + red[1][4 * wv + pp][lane]) +
                        (red[2][4 * wv + pp][lane] + red[3][4 * wv + pp][lane])) + gxv[pp];
         // ---- cell update (PyTorch LSTM): c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')
-        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
         c = fmaf(fg, c, ig * gg);
-        const float hval = og * tanhf(c);
-        // ---- publish: block [lane = hh*32 + b][i = wv]  (unit 8kb + 2 wv + hh  <->  k = 8kb + 2i + parity)
-        const int hoff = (((t * 2 + d) * nkb) + kb) * 1024 + lane * 16 + wv * 4;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hval), hrsrc, hoff, 0, 16 /*sc1*/);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains
-        __syncthreads();                                          // (also fences `red` for the next step)
-        if (tid == 0) __hip_atomic_store(flags + kb, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float hval = og * tanhf_(c);
+#ifdef MT_LSTM_DIAG
+        asm volatile("" :: "v"(hval));
+#endif
+        DIAG_STAMP(4);
+        // ---- publish h as bf16 hi/lo pieces in the MFMA B-operand layout.  Units 8kb..8kb+7 are the k-half
+        //      (kb & 1) of k-step kb >> 1: lanes (kb&1)*32 + batch of the [64 lanes][8 bf16] hi block and of
+        //      the lo block.  The two 512-B pieces are assembled in LDS and written by ONE wave as a single
+        //      16-B-per-lane sc1 store (whole 128-B lines); being the only storing wave it also signals.
+        {
+            bf16_t hi, lo;
+            split_bf16(hval, hi, lo);
+            hs[0][b][jl] = hi;
+            hs[1][b][jl] = lo;
+        }
+        DIAG_STAMP(5);
+        __syncthreads();                                          // pieces assembled; every wave is done with `red`
+        if (wv == 0) {
+            typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+            const u32x4 piece = *(const u32x4*)(&hs[hh][b][0]);    // lanes 0-31: hi, lanes 32-63: lo
+            const int hoff = ((t * 2 + d) * nkb) * 1024 + (kb >> 1) * 2048 + hh * 1024 + ((kb & 1) * 32 + b) * 16;
+            __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1*/);
+#ifndef MT_LSTM_NO_DRAIN
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pieces have reached memory before the flag says so
+#endif
+            if (lane == 0) __hip_atomic_store(flags + kb, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        DIAG_STAMP(6);
     }
+#ifdef MT_LSTM_DIAG
+    if (tid == 0) {
+        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (int i = 0; i < 8; ++i) mt_lstm_diag[wg & 1023][i] = dg[i];
+    }
+#endif
 }
 
-// hx[g][t][d][kb][64][4] f32  ->  X[(t*B + b)][d*H + j] bf16  (next layer's GEMM A matrix)
-// One thread per (m, d, kb): gathers the 8 units of a k-block (two 16-B pieces) and writes 16 B.
-__global__ void lstm_relayout_kernel(const float* __restrict__ hx, bf16_t* __restrict__ X, int ldx, int B, int T, int H) {
+// Layer output for (g, t, d): nks blocks of 2 KB: [hi | lo][lane = (k half)*32 + batch][8 bf16], k = 16 ks + 8 half + j.
+// hx -> X[(t*B + b)][d*H + k] bf16 (next layer's GEMM A matrix) = the hi pieces (bf16(h), round-to-nearest).
+__global__ void lstm_relayout_kernel(const bf16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, int B, int T, int H) {
     const int nkb = H >> 3;
     const size_t total = (size_t)T * B * 2 * nkb;
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
@@ -164,33 +269,29 @@ __global__ void lstm_relayout_kernel(const float* __restrict__ hx, bf16_t* __res
         const int d = (id / nkb) & 1;
         const size_t m = id / (2 * nkb);
         const int t = m / B, b = m - (size_t)t * B, g = b >> 5, bl = b & 31;
-        const float* src = hx + ((((size_t)g * T + t) * 2 + d) * nkb + kb) * 256;
-        const f32x4 even = *(const f32x4*)(src + bl * 4);          // k = 8kb + 0,2,4,6
-        const f32x4 odd = *(const f32x4*)(src + (32 + bl) * 4);    // k = 8kb + 1,3,5,7
-        uint4 o;
-        o.x = pack_bf16x2(even[0], odd[0]); o.y = pack_bf16x2(even[1], odd[1]);
-        o.z = pack_bf16x2(even[2], odd[2]); o.w = pack_bf16x2(even[3], odd[3]);
-        *(uint4*)(X + m * ldx + d * H + kb * 8) = o;
+        const bf16_t* src = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 512 + (size_t)(kb >> 1) * 1024 + ((kb & 1) * 32 + bl) * 8;
+        *(uint4*)(X + m * ldx + d * H + kb * 8) = *(const uint4*)src;
     }
 }
 
-// hx -> y[b][t][d*H + j] f32 (the reference's batch_first LSTM output; used by tests and the Large model)
-__global__ void lstm_unpack_kernel(const float* __restrict__ hx, float* __restrict__ y, int B, int T, int H) {
+// hx -> y[b][t][d*H + k] f32 = hi + lo (the reference's batch_first LSTM output; tests and the Large model)
+__global__ void lstm_unpack_kernel(const bf16_t* __restrict__ hx, float* __restrict__ y, int B, int T, int H) {
+    const int nkb = H >> 3;
     const size_t total = (size_t)T * B * 2 * H;
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        const int j = id % H;
+        const int k = id % H;
         const int d = (id / H) & 1;
         const size_t bt = id / (2 * H);
         const int t = bt % T, b = bt / T, g = b >> 5, bl = b & 31;
-        const int kb = j >> 3, k = j & 7;
-        y[id] = hx[((((size_t)g * T + t) * 2 + d) * (H >> 3) + kb) * 256 + ((k & 1) * 32 + bl) * 4 + (k >> 1)];
+        const bf16_t* blk = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 512 + (size_t)(k >> 4) * 1024;
+        const int e = (((k >> 3) & 1) * 32 + bl) * 8 + (k & 7);
+        y[id] = bf16_to_f32(blk[e]) + bf16_to_f32(blk[512 + e]);
     }
 }
 
-
-template <int NKBW>
+template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, hipStream_t st) {
-    hipLaunchKernelGGL(lstm_rec_kernel<NKBW>, dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lstm_rec_kernel<NKSW>, dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -208,27 +309,27 @@ extern "C" size_t mt_lstm_sync_bytes(int B, int H) { return align_up(64 + (size_
 extern "C" int mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                                  int B, int T, int H, mt_stream_t stream) {
     MT_REQUIRE(gx && w_hh && hx && sync_ws, MT_EINVAL, "mt_lstm_bidir_fwd: null pointer");
-    MT_REQUIRE(B > 0 && T > 0 && H >= 8 && H % 8 == 0 && H <= 1024, MT_EUNSUPPORTED,
-               "mt_lstm_bidir_fwd: hidden size %d unsupported (multiple of 8, <= 1024)", H);
+    MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 1024, MT_EUNSUPPORTED,
+               "mt_lstm_bidir_fwd: hidden size %d unsupported (multiple of 16, <= 1024)", H);
     MT_REQUIRE(sync_bytes >= mt_lstm_sync_bytes(B, H), MT_EWORKSPACE, "mt_lstm_bidir_fwd: sync workspace too small");
     const int nkb = H >> 3, ng = cdiv(B, 32);
     MT_REQUIRE((size_t)T * 2 * nkb * 1024 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_bidir_fwd: T*H too large for one buffer descriptor");
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
+    MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
     LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 64), (unsigned*)sync_ws, B, T, H, 0};
     // every workgroup of a launch must be resident (they wait on each other): at most 256 workgroups
     // (one per CU) per launch; further batch groups run as further launches on the same stream.
     const int per_launch = (256 / (2 * nkb)) > 0 ? (256 / (2 * nkb)) : 1;
-    const int nkbw = cdiv(nkb, 4);
+    const int nksw = cdiv(nkb / 2, 4);
     for (int g0 = 0; g0 < ng; g0 += per_launch) {
         a.g0 = g0;
         const int n = (ng - g0) < per_launch ? (ng - g0) : per_launch;
-        if (nkbw <= 1) launch_rec<1>(a, n, st);
-        else if (nkbw <= 2) launch_rec<2>(a, n, st);
-        else if (nkbw <= 4) launch_rec<4>(a, n, st);
-        else if (nkbw <= 8) launch_rec<8>(a, n, st);
-        else if (nkbw <= 16) launch_rec<16>(a, n, st);
-        else launch_rec<32>(a, n, st);
+        if (nksw <= 1) launch_rec<1>(a, n, st);
+        else if (nksw <= 2) launch_rec<2>(a, n, st);
+        else if (nksw <= 4) launch_rec<4>(a, n, st);
+        else if (nksw <= 8) launch_rec<8>(a, n, st);
+        else launch_rec<16>(a, n, st);
         MT_CHECK_LAUNCH();
     }
     return MT_OK;
@@ -238,16 +339,23 @@ extern "C" int mt_lstm_relayout_bf16(const float* hx, void* X, int ldx, int B, i
     MT_REQUIRE(hx && X && ldx >= 2 * H && ldx % 8 == 0, MT_EINVAL, "mt_lstm_relayout_bf16: bad arguments");
     const size_t total = (size_t)T * B * 2 * (H >> 3);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(lstm_relayout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, hx, (bf16_t*)X, ldx, B, T, H);
+    hipLaunchKernelGGL(lstm_relayout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hx, (bf16_t*)X, ldx, B, T, H);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
+
+#ifdef MT_LSTM_DIAG
+extern "C" int mt_lstm_diag_read(unsigned long long* host_out /*[1024][8]*/) {
+    MT_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mt_lstm_diag), sizeof(unsigned long long) * 1024 * 8));
+    return MT_OK;
+}
+#endif
 
 extern "C" int mt_lstm_unpack_f32(const float* hx, float* y, int B, int T, int H, mt_stream_t stream) {
     MT_REQUIRE(hx && y, MT_EINVAL, "mt_lstm_unpack_f32: null pointer");
     const size_t total = (size_t)T * B * 2 * H;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(lstm_unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, hx, y, B, T, H);
+    hipLaunchKernelGGL(lstm_unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hx, y, B, T, H);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

@@ -46,8 +46,8 @@ static int check_weights(const mt_cnnrnn_weights* w) {
     MT_REQUIRE(w, MT_EINVAL, "cnnrnn: null weights");
     MT_REQUIRE(w->n_mels >= 4 && w->layers >= 1 && w->layers <= MT_MAX_LSTM_LAYERS, MT_EINVAL,
                "cnnrnn: bad config n_mels=%d layers=%d", w->n_mels, w->layers);
-    MT_REQUIRE(w->hidden >= 8 && w->hidden % 8 == 0 && w->hidden <= 1024, MT_EUNSUPPORTED,
-               "cnnrnn: hidden size %d unsupported (multiple of 8, <= 1024)", w->hidden);
+    MT_REQUIRE(w->hidden >= 16 && w->hidden % 16 == 0 && w->hidden <= 1024, MT_EUNSUPPORTED,
+               "cnnrnn: hidden size %d unsupported (multiple of 16, <= 1024)", w->hidden);
     MT_REQUIRE(w->conv1_w && w->conv1_b && w->conv2_w && w->conv2_b && w->fc_w && w->fc_b, MT_EINVAL, "cnnrnn: null weight pointer");
     for (int l = 0; l < w->layers; ++l)
         MT_REQUIRE(w->w_ih[l] && w->b_gates[l] && w->w_hh[l], MT_EINVAL, "cnnrnn: null LSTM weight pointer (layer %d)", l);

@@ -78,8 +78,8 @@ class CNNRNNModel(nn.Module, _HipForward):
     # ---- weight packing (once per load_state_dict): layouts documented in include/mt_hip.h
     def _pack(self, device) -> Dict[str, object]:
         H, L, Fo2 = self.hidden_size, self.num_layers, self.n_mels // 4
-        if H % 8 or H > 1024:
-            raise NotImplementedError(f"hidden_size={H}: the recurrence kernel needs a multiple of 8, <= 1024")
+        if H % 16 or H > 1024:
+            raise NotImplementedError(f"hidden_size={H}: the recurrence kernel needs a multiple of 16, <= 1024")
         if L > _lib.MAX_LSTM_LAYERS:
             raise NotImplementedError(f"num_layers={L} > {_lib.MAX_LSTM_LAYERS}")
         dev = dict(device=device)
@@ -133,12 +133,15 @@ class CNNRNNModel(nn.Module, _HipForward):
         w = pk["struct"]
         x = x.contiguous().float()
         logits = torch.empty(B, self.output_dim, T, dtype=torch.float32, device=x.device)
-        key = (B, T)
+        # one workspace per (shape, stream): forwards issued on different streams may overlap on the GPU
+        key = (B, T, torch.cuda.current_stream(x.device).cuda_stream)
         if key not in self._ws:
             nbytes = lib.mt_cnnrnn_workspace_bytes(w, B, T)
             if nbytes == 0:
                 raise _lib.MtError("mt_cnnrnn_workspace_bytes: " + _lib.last_error())
-            self._ws = {key: torch.empty(nbytes, dtype=torch.uint8, device=x.device)}   # keep one shape resident
+            for k in [k for k in self._ws if k[:2] != (B, T)] + list(self._ws)[: max(0, len(self._ws) - 7)]:
+                self._ws.pop(k, None)                       # keep one shape resident, at most 8 streams
+            self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         ws = self._ws[key]
         ev_arr, n_ev = None, 0
         if events is not None:   # torch.cuda.Event(enable_timing=True) objects, already created (recorded once)
@@ -154,13 +157,16 @@ class CNNRNNModel(nn.Module, _HipForward):
 
     def raise_on_handoff_timeout(self, B, T):
         """Synchronises; raises if a recurrence hand-off spin hit its bound (see csrc/lstm.hip)."""
-        ws, w = self._ws[(B, T)], self._packed["struct"]
+        w = self._packed["struct"]
         torch.cuda.synchronize()
-        for l in range(self.num_layers):
-            off = lib.mt_cnnrnn_status_offset(w, B, T, l)
-            st = int(ws[off:off + 4].view(torch.int32).item())
-            if st != 0:
-                raise _lib.MtError(f"LSTM layer {l}: inter-workgroup hand-off timed out at step {st - 1}")
+        for key, ws in self._ws.items():
+            if key[:2] != (B, T):
+                continue
+            for l in range(self.num_layers):
+                off = lib.mt_cnnrnn_status_offset(w, B, T, l)
+                st = int(ws[off:off + 4].view(torch.int32).item())
+                if st != 0:
+                    raise _lib.MtError(f"LSTM layer {l}: inter-workgroup hand-off timed out at step {st - 1}")
 
 
 class CNNRNNModelLarge(nn.Module, _HipForward):

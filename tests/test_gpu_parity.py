@@ -129,8 +129,11 @@ def test_lstm_layer_matches_oracle(mta, B, T, H, K):
     K1 = (2 * H + 63) // 64 * 64
     X1 = torch.zeros(Mp, K1, dtype=torch.bfloat16, device="cuda")
     check(lib.mt_lstm_relayout_bf16(ptr(hx), ptr(X1), K1, B, T, H, s))
-    want = y.transpose(0, 1).reshape(M, 2 * H).bfloat16()
-    assert torch.equal(X1[:M, :2 * H], want)
+    # X1 holds the hi pieces = bf16(h); y = hi + lo, so bf16(y) == hi except on exact rounding ties
+    want = y.transpose(0, 1).reshape(M, 2 * H)
+    got = X1[:M, :2 * H].float()
+    assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 1e-30).all()
+    assert (got.bfloat16() != want.bfloat16()).float().mean().item() < 1e-2
 
 
 # ------------------------------------------------------------------ whole model
