@@ -153,6 +153,25 @@ int    mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel, const 
                             int B, int T, float* logits, void* workspace, size_t workspace_bytes,
                             void* const* events, int n_events, mt_stream_t stream);
 
+/* ------------------------------------------------------------------ loss, prediction, F1
+ * Masked BCE-with-logits (transcription_model.py:110-162,:196-217):
+ *   loss[0] (=, or += when accumulate) weight * sum_{valid} bce(logit, target) / max(n_valid_frames*P, 1)
+ *   grad (may be NULL) = d loss / d logits = weight * (sigmoid(x) - y) * mask / denom.
+ * lengths (int64, device, may be NULL = all frames valid); n_valid_frames = sum_b min(lengths[b], T)
+ * (or B*T), known to the host.  workspace: mt_bce_workspace_bytes().  Bitwise reproducible.  */
+size_t mt_bce_workspace_bytes(void);
+int    mt_bce_masked_fwd_bwd(const float* logits, const float* targets, const long long* lengths,
+                             long long n_valid_frames, float weight, int accumulate, float* loss, float* grad,
+                             void* workspace, size_t workspace_bytes, int B, int P, int T, mt_stream_t stream);
+/* onset/offset targets from a roll (transcription_model.py:176-185): rows x T, diff along T. */
+int    mt_onset_offset_targets(const float* roll, float* onset, float* offset, long long rows, int T,
+                               mt_stream_t stream);
+/* roll = (sigmoid(logits) > threshold) as float {0,1} (transcription_model.py:262-265, main.py:153-156). */
+int    mt_predict_threshold(const float* logits, float* roll, long long n, float threshold, mt_stream_t stream);
+/* counts[b] = {TP, FP, FN} (uint64) over the first lengths[b] frames (evaluate.py:361-373). */
+int    mt_f1_counts(const float* pred, const float* target, const long long* lengths,
+                    unsigned long long* counts, int B, int P, int T, mt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

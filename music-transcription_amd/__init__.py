@@ -8,5 +8,8 @@ from . import _lib                                   # noqa: F401  (raises if li
 from ._lib import MtError                            # noqa: F401
 from .frontend import MelFrontend, audio_to_mel, get_frontend, mel_filterbank, num_frames   # noqa: F401
 from .model import CNNRNNModel, CNNRNNModelLarge, TranscriptionModel                          # noqa: F401
+from . import ops                                                                             # noqa: F401
+from .ops import compute_loss, framewise_f1, mean_f1, predict_from_logits                     # noqa: F401
+from .data import CachedMaestroDataset, collate_fn, write_cache_chunk, write_cache_metadata   # noqa: F401
 
 __version__ = "0.1.0"

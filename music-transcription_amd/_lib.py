@@ -66,6 +66,11 @@ _SIGS = {
     "mt_lstm_bidir_fwd": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "mt_lstm_relayout_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "mt_lstm_unpack_f32": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mt_bce_workspace_bytes": (sz, []),
+    "mt_bce_masked_fwd_bwd": (i32, [vp, vp, vp, C.c_longlong, C.c_float, i32, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "mt_onset_offset_targets": (i32, [vp, vp, vp, C.c_longlong, i32, vp]),
+    "mt_predict_threshold": (i32, [vp, vp, C.c_longlong, C.c_float, vp]),
+    "mt_f1_counts": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "mt_cnnrnn_workspace_bytes": (sz, [C.POINTER(CnnRnnWeights), i32, i32]),
     "mt_cnnrnn_status_offset": (sz, [C.POINTER(CnnRnnWeights), i32, i32, i32]),
     "mt_cnnrnn_forward": (i32, [C.POINTER(CnnRnnWeights), vp, vp, i32, i32, vp, vp, sz, vp]),

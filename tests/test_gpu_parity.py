@@ -184,3 +184,47 @@ def test_errors_are_loud(mta):
         model(torch.zeros(1, 1, 31, 10, device="cuda"))
     with torch.no_grad():
         assert model(torch.zeros(2, 1, 32, 0, device="cuda")).shape == (2, 88, 1)
+
+
+# ------------------------------------------------------------------ loss / predict / F1
+def test_loss_matches_reference_golden(mta, golden_dir):
+    g = np.load(os.path.join(golden_dir, "loss.npz"))
+    logits = torch.from_numpy(g["logits"]).cuda()
+    B, P, T = logits.shape
+    targets = torch.from_numpy(np.unpackbits(g["targets"])[: B * P * T].reshape(B, P, T).astype(np.float32)).cuda()
+    lengths = torch.from_numpy(g["lengths"])
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=32, hidden_size=16, num_layers=1, device="cuda")
+    assert abs(float(model.compute_loss(logits, targets)) - float(g["loss_nolen"])) < 2e-6
+    assert abs(float(model.compute_loss(logits, targets, lengths)) - float(g["loss_len"])) < 2e-6
+    d = {"frame": logits, "onset": logits * 0.5 - 1.0, "offset": -logits + 0.25}
+    assert abs(float(model.compute_loss(d, targets)) - float(g["loss_dict_nolen"])) < 2e-6
+    assert abs(float(model.compute_loss(d, targets, lengths)) - float(g["loss_dict_len"])) < 2e-6
+    assert float(model.compute_loss(logits, targets, torch.tensor([0, 0, 0]))) == 0.0
+    lg = logits.clone().requires_grad_(True)
+    model.compute_loss(lg, targets, lengths).backward()
+    assert np.abs(lg.grad.cpu().numpy() - g["grad_len"]).max() < 1e-8
+    on, off = mta.ops.onset_offset_targets(targets)
+    ron, roff = R.onset_offset_targets(targets.cpu())
+    assert torch.equal(on.cpu(), ron) and torch.equal(off.cpu(), roff)
+    # bitwise reproducible
+    assert float(model.compute_loss(logits, targets, lengths)) == float(model.compute_loss(logits, targets, lengths))
+
+
+def test_predict_and_f1(mta, golden_dir):
+    z = np.load(os.path.join(golden_dir, "small_models.npz"))
+    logits = torch.from_numpy(z["small_a_logits"])
+    B, P, T = logits.shape
+    for th in (0.3, 0.5, 0.7):
+        want = np.unpackbits(z[f"small_a_pred{int(th * 10)}"])[: B * P * T].reshape(B, P, T)
+        got = mta.predict_from_logits(logits.cuda(), th).cpu().numpy()
+        assert (got != want).mean() < 1e-4 and set(np.unique(got)) <= {0.0, 1.0}
+    g = np.load(os.path.join(golden_dir, "f1.npz"))
+    yt = torch.from_numpy(g["y_true"]).reshape(-1, 88, 20).cuda()
+    yp = torch.from_numpy(g["y_pred"]).reshape(-1, 88, 20).cuda()
+    got = mta.framewise_f1(yp, yt)
+    assert np.abs(np.array(got) - g["f1"]).max() < 1e-12
+    assert got[0] == 0.0                                             # zero_division=0
+    lens = torch.tensor([20, 7, 0, 13, 20, 1, 20, 19])
+    want = [R.f1_binary(yt[i, :, :int(L)].cpu(), yp[i, :, :int(L)].cpu()) for i, L in enumerate(lens)]
+    assert np.allclose(mta.framewise_f1(yp, yt, lens), want, atol=1e-12)
+    assert abs(mta.mean_f1(yp, yt, lens) - R.mean_f1(yp.cpu(), yt.cpu(), lens)) < 1e-12
