@@ -54,16 +54,19 @@ int         mt_device_count(void);
 int    mt_mel_filterbank_host(float* fb_host, int sr, int n_mels);
 int    mt_mel_num_frames(int n_samples, int hop);           /* 1 + n_samples / hop */
 
-/* Device-resident immutable tables for one (sr, hop, n_mels). */
+/* Device-resident immutable tables for one (sr, hop, n_mels); `desc` (host memory, filled by
+ * mt_mel_plan_init) carries what the launcher needs to know about them. */
+typedef struct { int sr, hop, n_mels, ell_rows; } mt_mel_desc;
 size_t mt_mel_plan_bytes(int n_mels);
-int    mt_mel_plan_init(void* plan, size_t plan_bytes, int sr, int hop, int n_mels, mt_stream_t stream);
+int    mt_mel_plan_init(void* plan, size_t plan_bytes, int sr, int hop, int n_mels, mt_mel_desc* desc,
+                        mt_stream_t stream);
 
 /* wave[B][n_samples] f32 -> mel_db[B][n_mels][T] f32 (T = mt_mel_num_frames).
  * chunk_max_power[B] (f32 bit patterns, >= 0) receives each chunk's max mel POWER.
  * apply_clamp != 0: mel_db is final (clamped at max-80 dB), as power_to_db returns it.
  * apply_clamp == 0: mel_db is left unclamped; the consumer (mt_conv1_*) applies
  *                   max(x, 10*log10(max(1e-10, chunk_max_power[b])) - 80) on load.  */
-int    mt_mel_db_f32(const void* plan, int hop, int n_mels, const float* wave, int B, int n_samples,
+int    mt_mel_db_f32(const void* plan, const mt_mel_desc* desc, const float* wave, int B, int n_samples,
                      float* mel_db, float* chunk_max_power, int apply_clamp, mt_stream_t stream);
 
 /* ------------------------------------------------------------------ CNN blocks

@@ -38,6 +38,11 @@ lib = C.CDLL(LIB_PATH)
 vp, sz, i32, f32p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
 
 
+class MelDesc(C.Structure):
+    """mt_mel_desc (include/mt_hip.h)."""
+    _fields_ = [("sr", i32), ("hop", i32), ("n_mels", i32), ("ell_rows", i32)]
+
+
 class CnnRnnWeights(C.Structure):
     """mt_cnnrnn_weights (include/mt_hip.h)."""
     _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("reserved", i32),
@@ -53,8 +58,8 @@ _SIGS = {
     "mt_mel_filterbank_host": (i32, [vp, i32, i32]),
     "mt_mel_num_frames": (i32, [i32, i32]),
     "mt_mel_plan_bytes": (sz, [i32]),
-    "mt_mel_plan_init": (i32, [vp, sz, i32, i32, i32, vp]),
-    "mt_mel_db_f32": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, i32, vp]),
+    "mt_mel_plan_init": (i32, [vp, sz, i32, i32, i32, C.POINTER(MelDesc), vp]),
+    "mt_mel_db_f32": (i32, [vp, C.POINTER(MelDesc), vp, i32, i32, vp, vp, i32, vp]),
     "mt_conv1_bn_relu_pool": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mt_conv2_bn_relu_pool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_bf16_f32acc": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),

@@ -22,6 +22,7 @@
 #include "mt_common.h"
 #include <math.h>
 #include <vector>
+#include <algorithm>
 #include <string.h>
 
 namespace mt {
@@ -32,8 +33,13 @@ constexpr int XREG = 33 * 32;     // floats per half-wave exchange region
 constexpr float AMIN = 1e-10f;
 constexpr float TOP_DB = 80.0f;
 
+// Sparse mel filterbank in a padded ELL form keyed to the kernel's work split: lane l of a half-wave
+// reduces filters m = l + 32 i (i = 0 .. NI-1).  For group i every lane runs the same trip count
+// lmax[i] = max_l len(l + 32 i); w_ell[(off[i] + j) * 32 + l] is filter (l + 32 i)'s j-th weight (0 past its end),
+// applied to power bin fstart[l + 32 i] + j.
+constexpr int ELL_MAX_ROWS = 768;     // sum_i lmax[i]; 86 at n_mels = 320
 struct MelPlanLayout {
-    size_t window, tw1024, w2048, fstart, flen, foff, fw, total;
+    size_t window, tw1024, w2048, fstart, grp, well, total;
 };
 static MelPlanLayout plan_layout(int n_mels) {
     MelPlanLayout L;
@@ -42,10 +48,10 @@ static MelPlanLayout plan_layout(int n_mels) {
     L.tw1024 = o; o += 32 * 32 * 8;
     L.w2048 = o;  o += 1024 * 8;
     size_t nm = align_up((size_t)n_mels, 16);
+    nm = align_up((size_t)n_mels, 32);
     L.fstart = o; o += nm * 4;
-    L.flen = o;   o += nm * 4;
-    L.foff = o;   o += nm * 4;
-    L.fw = o;     o += 4096 * 4;
+    L.grp = o;    o += 2 * 32 * 4;                    // int lmax[32], off[32]
+    L.well = o;   o += (size_t)ELL_MAX_ROWS * 32 * 4;
     L.total = o;
     return L;
 }
@@ -94,6 +100,14 @@ __device__ __forceinline__ void fft32_dif(float (&re)[32], float (&im)[32]) {
     }
 }
 
+// Diagnostic build only (-DMT_MEL_DIAG): per-phase wall-clock shares (10 ns ticks) of wave 0 of block 0..1023.
+#ifdef MT_MEL_DIAG
+__device__ unsigned long long mt_mel_diag[1024][12];
+#define MDIAG(i) do { if (tid == 0) { const long long n_ = __builtin_amdgcn_s_memrealtime(); dg[i] += n_ - tl; tl = n_; } } while (0)
+#else
+#define MDIAG(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ void lds_sync_wave() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -103,12 +117,15 @@ __device__ __forceinline__ void lds_sync_wave() {
 __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
     const float* __restrict__ wave, int n_samples, int T, int hop, int n_mels,
     const float2* __restrict__ window2, const float2* __restrict__ tw1024, const float2* __restrict__ w2048,
-    const int* __restrict__ fstart, const int* __restrict__ flen, const int* __restrict__ foff,
-    const float* __restrict__ fw, float* __restrict__ out, unsigned* __restrict__ chunk_max) {
+    const int* __restrict__ fstart, const int* __restrict__ grp, const float* __restrict__ well, int ell_rows,
+    float* __restrict__ out, unsigned* __restrict__ chunk_max) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xbuf = (float*)smem;                                   // [NWAVE][2][XREG]
     float2* w2048_s = (float2*)(smem + NWAVE * 2 * XREG * 4);     // [1024]
     float* tile = (float*)(smem + NWAVE * 2 * XREG * 4 + 1024 * 8);  // [n_mels][33]
+    const int ngrp = (n_mels + 31) >> 5;
+    int* fstart_s = (int*)(tile + n_mels * 33);                       // [ngrp * 32]
+    float* well_s = (float*)(fstart_s + ngrp * 32);                   // [ell_rows][32]
 
     const int tid = threadIdx.x;
     const int wv = tid >> 6, lane = tid & 63, half = lane >> 5, l = lane & 31;
@@ -117,10 +134,18 @@ __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
     float* X = xbuf + (wv * 2 + half) * XREG;
 
     for (int i = tid; i < 1024; i += NWAVE * 64) w2048_s[i] = w2048[i];
+    for (int i = tid; i < ngrp * 32; i += NWAVE * 64) fstart_s[i] = fstart[i];
+    for (int i = tid; i < ell_rows * 32; i += NWAVE * 64) well_s[i] = well[i];
+    for (int i = tid; i < NWAVE * 2 * XREG; i += NWAVE * 64) xbuf[i] = 0.0f;   // padded ELL rows read (x 0) past bin 1024
 
     __syncthreads();
 
     float vmax = 0.0f;
+#ifdef MT_MEL_DIAG
+    unsigned long long dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tl = __builtin_amdgcn_s_memrealtime();
+#endif
+    MDIAG(0);
 #pragma unroll 1
     for (int it = 0; it < FT / (NWAVE * 2); ++it) {
         const int fl = it * (NWAVE * 2) + wv * 2 + half;   // frame within tile
@@ -153,6 +178,10 @@ __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
             }
         }
         // ---- stage A: DFT-32 over r, twiddle, transpose
+#ifdef MT_MEL_DIAG
+        asm volatile("" :: "v"(re[31]), "v"(im[31]));
+#endif
+        MDIAG(1);
         __builtin_amdgcn_sched_barrier(0);
         fft32_dif(re, im);
         __builtin_amdgcn_sched_barrier(0);
@@ -163,6 +192,7 @@ __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
             re[i] = fmaf(yi, tw.y, yr * tw.x);
             im[i] = fmaf(-yr, tw.y, yi * tw.x);
         }
+        MDIAG(2);
 #pragma unroll
         for (int i = 0; i < 32; ++i) X[brev5(i) * 33 + l] = re[i];
         lds_sync_wave();
@@ -176,7 +206,9 @@ __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
         for (int n1 = 0; n1 < 32; ++n1) im[n1] = X[l * 33 + n1];
         lds_sync_wave();
         // ---- stage B: DFT-32 over n1 -> register i holds Z[l + 32*brev5(i)]
+        MDIAG(3);
         fft32_dif(re, im);
+        MDIAG(4);
         const float nyq = re[0] - im[0];                   // X[1024] = Re Z[0] - Im Z[0] (lane l == 0)
         // ---- real split: partner Z[(1024-k) & 1023] via a mirrored LDS exchange
         float dr[32];
@@ -211,16 +243,30 @@ __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
         for (int i = 0; i < 32; ++i) X[l + 32 * brev5(i)] = dr[i];
         if (l == 0) X[1024] = nyq * nyq;
         lds_sync_wave();
-        // ---- sparse mel projection + dB
-        for (int m = l; m < n_mels; m += 32) {
-            const int s = fstart[m], n = flen[m];
-            const float* w = fw + foff[m];
-            float acc = 0.0f;
-            for (int j = 0; j < n; ++j) acc = fmaf(w[j], X[s + j], acc);
-            vmax = fmaxf(vmax, acc);
-            tile[m * 33 + fl] = 10.0f * log10f(fmaxf(acc, AMIN));
+        MDIAG(5);
+        // ---- sparse mel projection + dB: lane l reduces filters l + 32 i; uniform trip counts (padded ELL)
+        int row = 0;
+        for (int i = 0; i < ngrp; ++i) {
+            const int m = l + 32 * i;
+            const int n = grp[i];                           // scalar load: same for every lane
+            const float* Xs = X + fstart_s[m];
+            const float* w = well_s + row * 32 + l;
+            float a0 = 0.0f, a1 = 0.0f;
+            int j = 0;
+            for (; j + 1 < n; j += 2) {
+                a0 = fmaf(w[j * 32], Xs[j], a0);
+                a1 = fmaf(w[(j + 1) * 32], Xs[j + 1], a1);
+            }
+            if (j < n) a0 = fmaf(w[j * 32], Xs[j], a0);
+            const float acc = a0 + a1;
+            row += n;
+            if (m < n_mels) {
+                vmax = fmaxf(vmax, acc);
+                tile[m * 33 + fl] = 10.0f * log10f(fmaxf(acc, AMIN));
+            }
         }
         lds_sync_wave();
+        MDIAG(6);
     }
     // ---- per-chunk max of mel POWER (non-negative floats order like their bit patterns)
 #pragma unroll
@@ -232,6 +278,10 @@ __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
         const int m = idx >> 5, tl = idx & 31, t = tile0 + tl;
         if (t < T) out[((size_t)b * n_mels + m) * T + t] = tile[m * 33 + tl];
     }
+    MDIAG(7);
+#ifdef MT_MEL_DIAG
+    if (tid == 0) { const int wg = blockIdx.y * gridDim.x + blockIdx.x; for (int i = 0; i < 12; ++i) mt_mel_diag[wg & 1023][i] = dg[i]; }
+#endif
 }
 
 __global__ void mel_clamp_kernel(float* __restrict__ mel, const unsigned* __restrict__ chunk_max, size_t per_chunk) {
@@ -280,6 +330,13 @@ static void build_filterbank(std::vector<float>& fb, int sr, int n_mels) {
 
 using namespace mt;
 
+#ifdef MT_MEL_DIAG
+extern "C" int mt_mel_diag_read(unsigned long long* host_out) {
+    MT_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mt_mel_diag), sizeof(unsigned long long) * 1024 * 12));
+    return MT_OK;
+}
+#endif
+
 extern "C" int mt_mel_num_frames(int n_samples, int hop) {
     if (n_samples < 0 || hop <= 0) return MT_EINVAL;
     return 1 + n_samples / hop;
@@ -297,8 +354,8 @@ extern "C" size_t mt_mel_plan_bytes(int n_mels) {
     return n_mels > 0 ? plan_layout(n_mels).total : 0;
 }
 
-extern "C" int mt_mel_plan_init(void* plan, size_t plan_bytes, int sr, int hop, int n_mels, mt_stream_t stream) {
-    MT_REQUIRE(plan && sr > 0 && hop > 0 && n_mels > 0 && n_mels <= 1024, MT_EINVAL, "mt_mel_plan_init: bad arguments");
+extern "C" int mt_mel_plan_init(void* plan, size_t plan_bytes, int sr, int hop, int n_mels, mt_mel_desc* desc, mt_stream_t stream) {
+    MT_REQUIRE(plan && desc && sr > 0 && hop > 0 && n_mels > 0 && n_mels <= 1024, MT_EINVAL, "mt_mel_plan_init: bad arguments");
     const MelPlanLayout L = plan_layout(n_mels);
     MT_REQUIRE(plan_bytes >= L.total, MT_EWORKSPACE, "mt_mel_plan_init: plan buffer %zu < %zu bytes", plan_bytes, L.total);
     std::vector<char> h(L.total, 0);
@@ -321,29 +378,45 @@ extern "C" int mt_mel_plan_init(void* plan, size_t plan_bytes, int sr, int hop, 
     std::vector<float> fb;
     build_filterbank(fb, sr, n_mels);
     const int nb = MT_N_FFT / 2 + 1;
-    int* fs = (int*)(h.data() + L.fstart); int* fl = (int*)(h.data() + L.flen); int* fo = (int*)(h.data() + L.foff);
-    float* fwp = (float*)(h.data() + L.fw);
-    int off = 0;
+    int* fs = (int*)(h.data() + L.fstart);
+    int* grp = (int*)(h.data() + L.grp);                 // grp[i] = lmax, grp[32 + i] = row offset
+    float* well = (float*)(h.data() + L.well);
+    const int ngrp = (n_mels + 31) / 32;
+    std::vector<int> lo_(ngrp * 32, 0), len_(ngrp * 32, 0);
     for (int m = 0; m < n_mels; ++m) {
         int lo = nb, hi = -1;
         for (int k = 0; k < nb; ++k) if (fb[(size_t)m * nb + k] != 0.0f) { if (k < lo) lo = k; hi = k; }
-        const int n = hi >= lo ? hi - lo + 1 : 0;
-        MT_REQUIRE(off + n <= 4096, MT_EUNSUPPORTED, "mt_mel_plan_init: filterbank has too many non-zeros");
-        fs[m] = n ? lo : 0; fl[m] = n; fo[m] = off;
-        for (int j = 0; j < n; ++j) fwp[off + j] = fb[(size_t)m * nb + lo + j];
-        off += n;
+        len_[m] = hi >= lo ? hi - lo + 1 : 0;
+        lo_[m] = len_[m] ? lo : 0;
+    }
+    int off = 0;
+    for (int i = 0; i < ngrp; ++i) {
+        int lmax = 0;
+        for (int l = 0; l < 32; ++l) lmax = std::max(lmax, len_[i * 32 + l]);
+        MT_REQUIRE(off + lmax <= ELL_MAX_ROWS, MT_EUNSUPPORTED, "mt_mel_plan_init: filterbank too wide for the ELL table");
+        grp[i] = lmax; grp[32 + i] = off;
+        for (int l = 0; l < 32; ++l) {
+            const int m = i * 32 + l;
+            fs[m] = lo_[m];
+            for (int j = 0; j < lmax; ++j)
+                well[(size_t)(off + j) * 32 + l] = (m < n_mels && j < len_[m]) ? fb[(size_t)m * nb + lo_[m] + j] : 0.0f;
+        }
+        off += lmax;
     }
     hdr[4] = off;
+    desc->sr = sr; desc->hop = hop; desc->n_mels = n_mels; desc->ell_rows = off;
     // pageable-host copy: the runtime stages it before returning, so `h` may die here
     MT_CHECK_HIP(hipMemcpyAsync(plan, h.data(), L.total, hipMemcpyHostToDevice, (hipStream_t)stream));
     MT_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return MT_OK;
 }
 
-extern "C" int mt_mel_db_f32(const void* plan, int hop, int n_mels, const float* wave, int B, int n_samples,
+extern "C" int mt_mel_db_f32(const void* plan, const mt_mel_desc* desc, const float* wave, int B, int n_samples,
                              float* mel_db, float* chunk_max_power, int apply_clamp, mt_stream_t stream) {
-    MT_REQUIRE(plan && wave && mel_db && chunk_max_power, MT_EINVAL, "mt_mel_db_f32: null pointer");
-    MT_REQUIRE(B >= 0 && n_samples >= 0 && hop > 0 && n_mels > 0 && n_mels <= 1024, MT_EINVAL, "mt_mel_db_f32: bad dims");
+    MT_REQUIRE(plan && desc && wave && mel_db && chunk_max_power, MT_EINVAL, "mt_mel_db_f32: null pointer");
+    const int hop = desc->hop, n_mels = desc->n_mels;
+    MT_REQUIRE(B >= 0 && n_samples >= 0 && hop > 0 && n_mels > 0 && n_mels <= 1024 && desc->ell_rows > 0 &&
+               desc->ell_rows <= ELL_MAX_ROWS, MT_EINVAL, "mt_mel_db_f32: bad dims / descriptor");
     MT_REQUIRE(hop % 2 == 0, MT_EUNSUPPORTED, "mt_mel_db_f32: hop must be even (got %d)", hop);
     if (B == 0) return MT_OK;
     const int T = 1 + n_samples / hop;
@@ -351,7 +424,9 @@ extern "C" int mt_mel_db_f32(const void* plan, int hop, int n_mels, const float*
     const char* p = (const char*)plan;
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(chunk_max_power, 0, (size_t)B * 4, st));
-    const size_t lds = (size_t)NWAVE * 2 * XREG * 4 + 1024 * 8 + (size_t)n_mels * 33 * 4;
+    const int ngrp = (n_mels + 31) / 32;
+    const size_t lds = (size_t)NWAVE * 2 * XREG * 4 + 1024 * 8 + (size_t)n_mels * 33 * 4 + (size_t)ngrp * 32 * 4 +
+                       (size_t)desc->ell_rows * 32 * 4;
     MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "mt_mel_db_f32: n_mels=%d needs %zu B of LDS", n_mels, lds);
     static bool attr_set = false;
     if (!attr_set) {
@@ -361,8 +436,8 @@ extern "C" int mt_mel_db_f32(const void* plan, int hop, int n_mels, const float*
     dim3 grid(cdiv(T, FT), B);
     hipLaunchKernelGGL(mel_kernel, grid, dim3(NWAVE * 64), lds, st, wave, n_samples, T, hop, n_mels,
                        (const float2*)(p + L.window), (const float2*)(p + L.tw1024), (const float2*)(p + L.w2048),
-                       (const int*)(p + L.fstart), (const int*)(p + L.flen), (const int*)(p + L.foff),
-                       (const float*)(p + L.fw), mel_db, (unsigned*)chunk_max_power);
+                       (const int*)(p + L.fstart), (const int*)(p + L.grp), (const float*)(p + L.well), desc->ell_rows,
+                       mel_db, (unsigned*)chunk_max_power);
     MT_CHECK_LAUNCH();
     if (apply_clamp) {
         const size_t per = (size_t)n_mels * T;

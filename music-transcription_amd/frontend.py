@@ -36,8 +36,9 @@ class MelFrontend:
             raise RuntimeError("MelFrontend runs on the GPU only (no CPU fallback in the product path)")
         nbytes = lib.mt_mel_plan_bytes(self.n_mels)
         self.plan = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.desc = _lib.MelDesc()
         with torch.cuda.device(self.device):
-            check(lib.mt_mel_plan_init(ptr(self.plan), nbytes, self.sr, self.hop, self.n_mels, _lib.stream_ptr()),
+            check(lib.mt_mel_plan_init(ptr(self.plan), nbytes, self.sr, self.hop, self.n_mels, self.desc, _lib.stream_ptr()),
                   "mt_mel_plan_init")
 
     def __call__(self, wave: torch.Tensor, clamp: bool = True, out=None, chunk_max=None):
@@ -55,7 +56,7 @@ class MelFrontend:
         if chunk_max is None:
             chunk_max = torch.empty(B, dtype=torch.float32, device=wave.device)
         with torch.cuda.device(wave.device):
-            check(lib.mt_mel_db_f32(ptr(self.plan), self.hop, self.n_mels, ptr(wave), B, N, ptr(out), ptr(chunk_max),
+            check(lib.mt_mel_db_f32(ptr(self.plan), self.desc, ptr(wave), B, N, ptr(out), ptr(chunk_max),
                                     1 if clamp else 0, _lib.stream_ptr()), "mt_mel_db_f32")
         return out, chunk_max
 
