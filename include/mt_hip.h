@@ -125,18 +125,19 @@ int    mt_lstm_unpack_f32(const float* hx, float* y, int B, int T, int H, mt_str
 #define MT_MAX_LSTM_LAYERS 8
 typedef struct {
     int n_mels;                              /* input mel bins                                    */
-    int hidden;                              /* LSTM hidden size H (multiple of 16, <= 1024)      */
+    int hidden;                              /* LSTM hidden size (1..1024); laid out padded to 16 */
     int layers;                              /* LSTM layers (<= MT_MAX_LSTM_LAYERS)               */
     int reserved;
     const float* conv1_w;                    /* [32][9]  BN-folded                                */
     const float* conv1_b;                    /* [32]                                              */
     const void*  conv2_w;                    /* bf16 [64][9][32] BN-folded                        */
     const float* conv2_b;                    /* [64]                                              */
-    const void*  w_ih[MT_MAX_LSTM_LAYERS];   /* bf16 [roundup(8H,128)][K_l]; layer 0 columns in   */
+    const void*  w_ih[MT_MAX_LSTM_LAYERS];   /* bf16 [roundup(8Hp,128)][K_l], Hp = roundup(H,16), */
+                                             /*   gate row p*Hp + j (zero for j >= H); layer 0 columns in */
                                              /*   fo*64+co order, K_0 = (n_mels/4)*64;            */
                                              /*   K_l = roundup(2H,64), zero-padded, for l > 0    */
-    const float* b_gates[MT_MAX_LSTM_LAYERS];/* f32 [8H] = b_ih + b_hh, [fwd; reverse]            */
-    const float* w_hh[MT_MAX_LSTM_LAYERS];   /* f32 [2][4H][H]                                    */
+    const float* b_gates[MT_MAX_LSTM_LAYERS];/* f32 [8Hp] = b_ih + b_hh, [fwd; reverse]           */
+    const float* w_hh[MT_MAX_LSTM_LAYERS];   /* f32 [2][4Hp][Hp]                                  */
     const void*  fc_w;                       /* bf16 [128][roundup(2H,64)], rows >= 88 zero       */
     const float* fc_b;                       /* f32 [88]                                          */
 } mt_cnnrnn_weights;
@@ -155,6 +156,65 @@ int    mt_cnnrnn_num_stages(int layers);
 int    mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power,
                             int B, int T, float* logits, void* workspace, size_t workspace_bytes,
                             void* const* events, int n_events, mt_stream_t stream);
+
+/* ------------------------------------------------------------------ CNNRNNModelLarge pieces
+ * Channels-last bf16 convolution with folded BatchNorm (ResidualBlock, freq_aware_conv;
+ * cnn_rnn_model.py:76-99,:186-202):  out = act(conv_{KHx3,pad(KH/2,1)}(A) [+ conv_1x1(S)] + bias),
+ * optional MaxPool2d((2,1)).  A [B][F][T][C1], S [B][F][T][C2] (residual skip input, may be NULL),
+ * W [Cout][KH*3*C1 + C2] bf16 (K order: tap = kh*3+kw, ci; then the skip channels).
+ * out_mode 0: [B][Fout][T][Cout] bf16;  1: GEMM-A rows X[(t*B+b)*ldx + fo*Cout + co].        */
+int    mt_conv_cl_bf16(const void* A, const void* S, const void* W, const float* bias, void* out,
+                       int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool,
+                       int out_mode, int ldx, mt_stream_t stream);
+/* Batched GEMMs: batch z -> (z1, z2) = (z / zdiv, z % zdiv), element offsets z1*s?1 + z2*s?2.  */
+int    mt_gemm_batched_f32(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw,
+                           long long sW1, long long sW2, const float* bias, float* C, int ldc,
+                           long long sC1, long long sC2, int M, int N, int K, int batch, int zdiv,
+                           mt_stream_t stream);
+int    mt_gemm_batched_bf16out(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw,
+                               long long sW1, long long sW2, const float* bias, void* C, int ldc,
+                               long long sC1, long long sC2, int M, int N, int K, int batch, int zdiv,
+                               int relu, mt_stream_t stream);
+/* hx -> feature rows with a column offset, dropping padded hidden units (k >= Hv); X (bf16) and/or Y (f32). */
+int    mt_lstm_relayout_ex(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off,
+                           int B, int T, int H, int Hv, mt_stream_t stream);
+/* MultiHeadAttention pieces (cnn_rnn_model.py:118-139): P = softmax(clamp(S*scale, +-clip)) -> bf16 with
+ * the key axis zero-padded to Tp; V^T per (chunk, head); y = LayerNorm(resid + proj) -> bf16.       */
+int    mt_attn_softmax_clamped(const float* S, int lds, void* P, int Tp, int T, long long rows,
+                               float scale, float clip, mt_stream_t stream);
+int    mt_attn_transpose_v(const void* qkv, int ld3, int voff, void* VT, int B, int T, int Tp,
+                           int heads, int dp, mt_stream_t stream);
+int    mt_layernorm_residual(const float* resid, int ldr, const float* proj, int ldp, const float* gamma,
+                             const float* beta, void* y, int ldy, long long rows, int n, float eps,
+                             mt_stream_t stream);
+
+/* CNNRNNModelLarge.forward, eval mode (cnn_rnn_model.py:262-348).  Packed by model.py: pack_large. */
+typedef struct {
+    int n_mels, hidden, layers, hidden_local;     /* real sizes (hidden_local = hidden / 2)            */
+    int use_attention, use_heads, heads, head_dim_pad;  /* head_dim padded to a multiple of 64         */
+    float attn_scale;                             /* (real head_dim)^-1/2                              */
+    int reserved;
+    const float* conv1_w; const float* conv1_b;   /* [32][9], [32]                                     */
+    const void*  rb1c1_w; const float* rb1c1_b;   /* bf16 [64][9*32]                                   */
+    const void*  rb1c2_w; const float* rb1c2_b;   /* bf16 [64][9*64 + 32]  (conv2 + 1x1 skip)          */
+    const void*  rb2c1_w; const float* rb2c1_b;   /* bf16 [128][9*64]                                  */
+    const void*  rb2c2_w; const float* rb2c2_b;   /* bf16 [128][9*128 + 64]                            */
+    const void*  fa_w;    const float* fa_b;      /* bf16 [256][21*128]                                */
+    const void*  main_w_ih[MT_MAX_LSTM_LAYERS]; const float* main_b[MT_MAX_LSTM_LAYERS]; const float* main_w_hh[MT_MAX_LSTM_LAYERS];
+    const void*  local_w_ih; const float* local_b; const float* local_w_hh;
+    const void*  qkv_w;  const float* qkv_b;      /* bf16 [roundup(3*heads*dp,128)][Cp], Cp = roundup(comb,64) */
+    const void*  proj_w; const float* proj_b;     /* bf16 [roundup(comb,128)][heads*dp]                */
+    const float* ln_g;   const float* ln_b;       /* [comb]                                            */
+    const void*  shared_w; const float* shared_b; /* bf16 [roundup(hidden,128)][Cp]                    */
+    const void*  heads_w;  const float* heads_b;  /* bf16 [384][roundup(hidden,64)]: frame, onset, offset */
+    const void*  fc_w;     const float* fc_b;     /* no-heads variant: bf16 [128][Cp]                  */
+} mt_cnnrnn_large_weights;
+size_t mt_cnnrnn_large_workspace_bytes(const mt_cnnrnn_large_weights* w, int B, int T);
+size_t mt_cnnrnn_large_status_offset(const mt_cnnrnn_large_weights* w, int B, int T, int idx);
+/* logits3: [3][B][88][T] (frame, onset, offset) when use_heads, else [B][88][T]. */
+int    mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power,
+                               int B, int T, float* logits3, void* workspace, size_t workspace_bytes,
+                               mt_stream_t stream);
 
 /* ------------------------------------------------------------------ loss, prediction, F1
  * Masked BCE-with-logits (transcription_model.py:110-162,:196-217):

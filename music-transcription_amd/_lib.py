@@ -51,6 +51,18 @@ class CnnRnnWeights(C.Structure):
                 ("fc_w", vp), ("fc_b", vp)]
 
 
+class CnnRnnLargeWeights(C.Structure):
+    """mt_cnnrnn_large_weights (include/mt_hip.h)."""
+    _fields_ = ([(n, i32) for n in ("n_mels", "hidden", "layers", "hidden_local", "use_attention", "use_heads", "heads", "head_dim_pad")]
+                + [("attn_scale", C.c_float), ("reserved", i32)]
+                + [(n, vp) for n in ("conv1_w", "conv1_b", "rb1c1_w", "rb1c1_b", "rb1c2_w", "rb1c2_b", "rb2c1_w", "rb2c1_b",
+                                     "rb2c2_w", "rb2c2_b", "fa_w", "fa_b")]
+                + [("main_w_ih", vp * MAX_LSTM_LAYERS), ("main_b", vp * MAX_LSTM_LAYERS), ("main_w_hh", vp * MAX_LSTM_LAYERS)]
+                + [(n, vp) for n in ("local_w_ih", "local_b", "local_w_hh", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln_g", "ln_b",
+                                     "shared_w", "shared_b", "heads_w", "heads_b", "fc_w", "fc_b")])
+
+
+ll = C.c_longlong
 _SIGS = {
     "mt_version": (i32, []),
     "mt_last_error": (C.c_char_p, []),
@@ -71,6 +83,16 @@ _SIGS = {
     "mt_lstm_bidir_fwd": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "mt_lstm_relayout_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "mt_lstm_unpack_f32": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mt_conv_cl_bf16": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),
+    "mt_gemm_batched_f32": (i32, [vp, i32, ll, ll, vp, i32, ll, ll, vp, vp, i32, ll, ll, i32, i32, i32, i32, i32, vp]),
+    "mt_gemm_batched_bf16out": (i32, [vp, i32, ll, ll, vp, i32, ll, ll, vp, vp, i32, ll, ll, i32, i32, i32, i32, i32, i32, vp]),
+    "mt_lstm_relayout_ex": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mt_attn_softmax_clamped": (i32, [vp, i32, vp, i32, i32, ll, C.c_float, C.c_float, vp]),
+    "mt_attn_transpose_v": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "mt_layernorm_residual": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, ll, i32, C.c_float, vp]),
+    "mt_cnnrnn_large_workspace_bytes": (sz, [C.POINTER(CnnRnnLargeWeights), i32, i32]),
+    "mt_cnnrnn_large_status_offset": (sz, [C.POINTER(CnnRnnLargeWeights), i32, i32, i32]),
+    "mt_cnnrnn_large_forward": (i32, [C.POINTER(CnnRnnLargeWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
     "mt_bce_workspace_bytes": (sz, []),
     "mt_bce_masked_fwd_bwd": (i32, [vp, vp, vp, C.c_longlong, C.c_float, i32, vp, vp, vp, sz, i32, i32, i32, vp]),
     "mt_onset_offset_targets": (i32, [vp, vp, vp, C.c_longlong, i32, vp]),

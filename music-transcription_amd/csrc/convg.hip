@@ -1,0 +1,243 @@
+// Generic channels-last bf16 convolution on MFMA for gfx950: the conv blocks of CNNRNNModelLarge
+// (models/cnn_rnn_model.py:76-99 ResidualBlock, :186-202 res_block1/2 + freq_aware_conv), eval mode,
+// BatchNorm folded into the weights at pack time.
+//
+//   out = act( conv_{KHx3, pad (KH/2,1)}(A) [+ conv_{1x1}(S)] + bias ), optional MaxPool2d((2,1))
+//
+// The optional 1x1 term is the residual block's skip path (Conv2d 1x1 + BN): since both branches end in
+// a BatchNorm and are summed before the ReLU, the block's second half is ONE implicit GEMM whose K runs
+// over the 3x3 taps of the main input and then over the channels of the skip input.
+//
+// Implicit GEMM: M = positions, N = output channels, K = taps x channels.
+//   workgroup tile: 16 frequency rows x 16 frames (256 positions) x BN_ channels, 8 waves (4 along M x 2 along N);
+//   MFMA M-tile (32 rows) = 2 frequency rows x 16 frames: row r -> (frame r & 15, f parity r >> 4), so the
+//     pair that MaxPool2d((2,1)) merges lives in one lane (registers 4q+p and 4(q+2)+p);
+//   the input tile (with halo) is staged once in LDS, channels-last, 16-B chunk index XOR-ed with a
+//     function of the COLUMN only (the row pitch is a multiple of the positions per 256-B bank row), so the
+//     16 lanes of a ds_read_b128 group -- 16 distinct frames -- never collide, whatever the tap;
+//   weights are streamed per (tap, KC channels) through a double-buffered LDS ring, one barrier per chunk.
+#include "mt_common.h"
+
+namespace mt {
+
+enum { CG_OUT_CL = 0, CG_OUT_X = 1 };   // channels-last activation / GEMM-A rows (t*B+b), column fo*Cout+co
+
+struct ConvGArgs {
+    const bf16_t* A;      // [B][F][T][C1]
+    const bf16_t* S;      // [B][F][T][C2] or null
+    const bf16_t* W;      // [Cout][KH*3*C1 + C2]
+    const float* bias;    // [Cout]
+    bf16_t* out;
+    int B, F, T, C1, C2, Cout, KH, relu, ldx;
+};
+
+constexpr int CG_TF = 16, CG_TT = 16;
+
+__device__ __forceinline__ int cg_swz(int col, int nc_log2) {
+    // positions per 256-B bank row = 16 / NC; swizzle = (col / PR) mod NC
+    return (col >> (4 - nc_log2)) & ((1 << nc_log2) - 1);
+}
+
+template <int KC, int BN_, bool POOL, int OUT>
+__global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5, t_l = r & 15, fbit = r >> 4;
+    const int wm = wv >> 1, wn = wv & 1;
+    constexpr int NT = BN_ / 64;                       // N tiles (32 wide) per wave
+    const int tiles_t = (a.T + CG_TT - 1) / CG_TT;
+    const int t0 = (blockIdx.x % tiles_t) * CG_TT, n0 = (blockIdx.x / tiles_t) * BN_;
+    const int f0 = blockIdx.y * CG_TF, b = blockIdx.z;
+    const int KH = a.KH, ph = KH >> 1, C1 = a.C1, C2 = a.C2;
+    const int nc1 = C1 >> 3, nc1_l2 = 31 - __builtin_clz(nc1);
+    const int pr1 = 16 >> nc1_l2;                      // positions per bank row
+    const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
+    const int rows1 = CG_TF + KH - 1;
+    const int in1_bytes = rows1 * pitch1 * C1 * 2;
+    const int nc2 = C2 >> 3, nc2_l2 = C2 ? 31 - __builtin_clz(nc2) : 0;
+    const int in2_bytes = C2 ? CG_TF * CG_TT * C2 * 2 : 0;
+    char* in1 = smem;
+    char* in2 = smem + in1_bytes;
+    char* wbuf = smem + in1_bytes + in2_bytes;         // 2 x [BN_][KC] bf16
+    constexpr int WB = BN_ * KC * 2;
+    const int Ktot = KH * 3 * C1 + C2;
+
+    // ---- stage the input tile(s), zero outside the image
+    for (int id = tid; id < rows1 * 18 * nc1; id += 512) {
+        const int ch = id % nc1, pos = id / nc1, col = pos % 18, row = pos / 18;
+        const int f = f0 - ph + row, t = t0 - 1 + col;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (f >= 0 && f < a.F && t >= 0 && t < a.T) v = *(const uint4*)(a.A + (((size_t)b * a.F + f) * a.T + t) * C1 + ch * 8);
+        *(uint4*)(in1 + ((row * pitch1 + col) * nc1 + (ch ^ cg_swz(col, nc1_l2))) * 16) = v;
+    }
+    if (C2) {
+        for (int id = tid; id < CG_TF * CG_TT * nc2; id += 512) {
+            const int ch = id % nc2, pos = id / nc2, col = pos % CG_TT, row = pos / CG_TT;
+            const int f = f0 + row, t = t0 + col;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (f < a.F && t < a.T) v = *(const uint4*)(a.S + (((size_t)b * a.F + f) * a.T + t) * C2 + ch * 8);
+            *(uint4*)(in2 + ((row * CG_TT + col) * nc2 + (ch ^ cg_swz(col, nc2_l2))) * 16) = v;
+        }
+    }
+
+    // ---- weight chunk staging: chunk q covers K columns [q*KC, (q+1)*KC) of rows n0 .. n0+BN_
+    constexpr int WCH = BN_ * KC / 8;                  // 16-B pieces per chunk
+    constexpr int WPT = (WCH + 511) / 512;             // per thread (1 or 2; half the threads idle when WCH = 256)
+    constexpr int CPR = KC / 8;                        // pieces per weight row (4 or 8)
+    uint4 wreg[WPT];
+    const int nchunks = Ktot / KC;
+#define CG_WLOAD(q)                                                                                   \
+    do {                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                          \
+            const int id_ = tid + 512 * i_, row_ = id_ / CPR, pc_ = id_ % CPR;                        \
+            if (id_ < WCH) wreg[i_] = *(const uint4*)(a.W + (size_t)(n0 + row_) * Ktot + (size_t)(q) * KC + pc_ * 8); \
+        }                                                                                             \
+    } while (0)
+    // weight rows are KC*2 bytes (64 or 128): swizzle the piece index so that 16 rows distinct mod 16 do not collide
+#define CG_WADDR(buf, row, pc) \
+    (wbuf + (buf) * WB + (row) * (KC * 2) + ((KC == 64 ? ((pc) ^ (((row) >> 1) & 7)) : ((pc) ^ (((row) >> 2) & 3))) << 4))
+#define CG_WSTORE(buf)                                                                                \
+    do {                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                          \
+            const int id_ = tid + 512 * i_, row_ = id_ / CPR, pc_ = id_ % CPR;                        \
+            if (id_ < WCH) *(uint4*)CG_WADDR(buf, row_, pc_) = wreg[i_];                              \
+        }                                                                                             \
+    } while (0)
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    CG_WLOAD(0);
+    CG_WSTORE(0);
+    __syncthreads();
+    const int cpt = C1 / KC;                            // chunks per main tap
+    const int main_chunks = KH * 3 * cpt;
+    for (int q = 0; q < nchunks; ++q) {
+        const int buf = q & 1;
+        if (q + 1 < nchunks) CG_WLOAD(q + 1);
+        // where does this chunk's A operand come from?
+        const bool is_main = q < main_chunks;
+        int kh = 0, kw = 0, cbase = 0;                  // cbase: first channel of the chunk
+        if (is_main) { const int tap = q / cpt; kh = tap / 3; kw = tap % 3; cbase = (q % cpt) * KC; }
+        else cbase = (q - main_chunks) * KC;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            bf16x8 fb[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int row = wn * (BN_ / 2) + j * 32 + r;
+                fb[j] = *(const bf16x8*)CG_WADDR(buf, row, ks * 2 + h);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int frow = 4 * wm + 2 * i + fbit;            // frequency row inside the tile
+                const int cch = (cbase >> 3) + ks * 2 + h;         // 16-B piece of the channel vector
+                bf16x8 fa;
+                if (is_main) {
+                    const int col = t_l + kw;
+                    fa = *(const bf16x8*)(in1 + (((frow + kh) * pitch1 + col) * nc1 + (cch ^ cg_swz(col, nc1_l2))) * 16);
+                } else {
+                    fa = *(const bf16x8*)(in2 + ((frow * CG_TT + t_l) * nc2 + (cch ^ cg_swz(t_l, nc2_l2))) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (q + 1 < nchunks) CG_WSTORE(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias, (pool), (ReLU), bf16 store
+    const int Fo = POOL ? a.F / 2 : a.F;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + wn * (BN_ / 2) + j * 32 + r;
+        const float bv = a.bias[co];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int t = t0 + p + 8 * qq + 4 * h;
+                    if (t >= a.T) continue;
+                    const float v0 = acc[i][j][4 * qq + p] + bv, v1 = acc[i][j][4 * (qq + 2) + p] + bv;
+                    if (POOL) {
+                        const int fo = (f0 >> 1) + 2 * wm + i;
+                        if (fo >= Fo) continue;
+                        float v = fmaxf(v0, v1);
+                        if (a.relu) v = fmaxf(v, 0.0f);
+                        if (OUT == CG_OUT_CL) a.out[(((size_t)b * Fo + fo) * a.T + t) * a.Cout + co] = f32_to_bf16(v);
+                        else a.out[((size_t)t * a.B + b) * a.ldx + (size_t)fo * a.Cout + co] = f32_to_bf16(v);
+                    } else {
+                        const int f = f0 + 4 * wm + 2 * i;
+                        float u0 = v0, u1 = v1;
+                        if (a.relu) { u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                        if (OUT == CG_OUT_CL) {
+                            if (f < Fo) a.out[(((size_t)b * Fo + f) * a.T + t) * a.Cout + co] = f32_to_bf16(u0);
+                            if (f + 1 < Fo) a.out[(((size_t)b * Fo + f + 1) * a.T + t) * a.Cout + co] = f32_to_bf16(u1);
+                        } else {
+                            if (f < Fo) a.out[((size_t)t * a.B + b) * a.ldx + (size_t)f * a.Cout + co] = f32_to_bf16(u0);
+                            if (f + 1 < Fo) a.out[((size_t)t * a.B + b) * a.ldx + (size_t)(f + 1) * a.Cout + co] = f32_to_bf16(u1);
+                        }
+                    }
+                }
+        }
+    }
+#undef CG_WLOAD
+#undef CG_WSTORE
+#undef CG_WADDR
+}
+
+template <int KC, int BN_, bool POOL, int OUT>
+static int cg_launch(const ConvGArgs& a, hipStream_t st) {
+    const int nc1 = a.C1 / 8, pr1 = 16 / nc1 > 0 ? 16 / nc1 : 1;
+    const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
+    const size_t lds = (size_t)(CG_TF + a.KH - 1) * pitch1 * a.C1 * 2 + (a.C2 ? (size_t)CG_TF * CG_TT * a.C2 * 2 : 0) + 2 * BN_ * KC * 2;
+    MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "conv: tile needs %zu B of LDS", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)convg_kernel<KC, BN_, POOL, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int tiles_t = cdiv(a.T, CG_TT);
+    dim3 grid(tiles_t * (a.Cout / BN_), cdiv(a.F, CG_TF), a.B);
+    hipLaunchKernelGGL((convg_kernel<KC, BN_, POOL, OUT>), grid, dim3(512), lds, st, a);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+}  // namespace mt
+
+using namespace mt;
+
+// out_mode 0: channels-last activation [B][Fout][T][Cout] bf16; 1: GEMM-A rows X[(t*B+b)*ldx + fo*Cout + co].
+extern "C" int mt_conv_cl_bf16(const void* A, const void* S, const void* W, const float* bias, void* out,
+                               int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,
+                               mt_stream_t stream) {
+    MT_REQUIRE(A && W && bias && out, MT_EINVAL, "mt_conv_cl_bf16: null pointer");
+    MT_REQUIRE(B > 0 && F > 0 && T > 0 && (KH == 3 || KH == 7) && (C1 == 32 || C1 == 64 || C1 == 128) &&
+               (C2 == 0 || C2 == 32 || C2 == 64 || C2 == 128) && (C2 == 0 || S) && (Cout % 64 == 0), MT_EUNSUPPORTED,
+               "mt_conv_cl_bf16: unsupported shape C1=%d C2=%d Cout=%d KH=%d", C1, C2, Cout, KH);
+    ConvGArgs a{(const bf16_t*)A, (const bf16_t*)S, (const bf16_t*)W, bias, (bf16_t*)out, B, F, T, C1, C2, Cout, KH, relu, ldx};
+    hipStream_t st = (hipStream_t)stream;
+    const bool kc64 = (C1 % 64 == 0) && (C2 % 64 == 0);
+    const bool bn128 = (Cout % 128 == 0);
+#define CG_DISPATCH(KC_, BN__)                                                                     \
+    do {                                                                                           \
+        if (pool && out_mode == 1) return cg_launch<KC_, BN__, true, CG_OUT_X>(a, st);            \
+        if (pool) return cg_launch<KC_, BN__, true, CG_OUT_CL>(a, st);                            \
+        if (out_mode == 1) return cg_launch<KC_, BN__, false, CG_OUT_X>(a, st);                   \
+        return cg_launch<KC_, BN__, false, CG_OUT_CL>(a, st);                                     \
+    } while (0)
+    if (kc64 && bn128) CG_DISPATCH(64, 128);
+    if (kc64) CG_DISPATCH(64, 64);
+    if (bn128) CG_DISPATCH(32, 128);
+    CG_DISPATCH(32, 64);
+#undef CG_DISPATCH
+}

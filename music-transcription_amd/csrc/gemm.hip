@@ -26,13 +26,17 @@
 namespace mt {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-enum { EPI_ROWMAJOR = 0, EPI_LSTM_GX = 1, EPI_LOGITS = 2 };
+enum { EPI_ROWMAJOR = 0, EPI_LSTM_GX = 1, EPI_LOGITS = 2, EPI_ROWMAJOR_BF16 = 3 };
 
 struct GemmEpi {
-    float* out;
+    float* out;            // f32 output (bf16_t* for EPI_ROWMAJOR_BF16)
     const float* bias;
-    int ldc;      // EPI_ROWMAJOR
-    int B, T, H;  // EPI_LSTM_GX / EPI_LOGITS
+    int ldc;               // EPI_ROWMAJOR*
+    int B, T, H;           // EPI_LSTM_GX / EPI_LOGITS
+    int relu;              // EPI_ROWMAJOR_BF16
+    // batch (blockIdx.z = z): offsets z1*s?1 + z2*s?2 in elements with z1 = z / zdiv, z2 = z % zdiv
+    long long sA, sW, sC, sA2, sW2, sC2;
+    int zdiv;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -44,6 +48,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
     __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * BK * 2];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    {
+        const int z1 = blockIdx.z / ep.zdiv, z2 = blockIdx.z - z1 * ep.zdiv;
+        A += (size_t)(z1 * ep.sA + z2 * ep.sA2);
+        W += (size_t)(z1 * ep.sW + z2 * ep.sW2);
+        const long long oc = z1 * ep.sC + z2 * ep.sC2;
+        ep.out += (EPI == EPI_ROWMAJOR_BF16 ? oc / 2 : oc);                          // out is typed float*
+    }
     const int r = lane & 31, h = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;              // wave's 64x64 sub-tile
 
@@ -133,15 +144,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
                     const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (m < M && n < N) ep.out[(size_t)m * ep.ldc + n] = acc[i][j][e] + bv;
                 }
-            } else if (EPI == EPI_LOGITS) {
+            } else if (EPI == EPI_ROWMAJOR_BF16) {
                 const int n = nb + r;
                 const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
+                bf16_t* o = (bf16_t*)ep.out;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    float v = acc[i][j][e] + bv;
+                    if (ep.relu) v = fmaxf(v, 0.0f);
+                    if (m < M && n < N) o[(size_t)m * ep.ldc + n] = f32_to_bf16(v);
+                }
+            } else if (EPI == EPI_LOGITS) {
+                // column n = head*88 + pitch (one head when N = 88): out[head][b][pitch][t]
+                const int n = nb + r;
+                const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
+                const int head = n / MT_N_PITCH, pit = n - head * MT_N_PITCH;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (m < M && n < N) {
                         const int t = m / ep.B, b = m - t * ep.B;
-                        ep.out[((size_t)b * N + n) * ep.T + t] = acc[i][j][e] + bv;
+                        ep.out[(((size_t)head * ep.B + b) * MT_N_PITCH + pit) * ep.T + t] = acc[i][j][e] + bv;
                     }
                 }
             } else {  // EPI_LSTM_GX (swapped): lane column = m, register rows = n
@@ -163,14 +187,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
         }
 }
 
-static int launch(int epi, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st) {
+static int launch(int epi, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st, int batch = 1) {
     MT_REQUIRE(A && W && ep.out, MT_EINVAL, "gemm: null pointer");
     MT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MT_EINVAL,
                "gemm: bad dims M=%d N=%d K=%d lda=%d ldw=%d (K must be a multiple of %d)", M, N, K, lda, ldw, BK);
-    dim3 grid(cdiv(N, BN), cdiv(M, BM));
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
     if (epi == EPI_ROWMAJOR) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     else if (epi == EPI_LSTM_GX) hipLaunchKernelGGL(gemm_kernel<EPI_LSTM_GX>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
+    else if (epi == EPI_ROWMAJOR_BF16) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR_BF16>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     else hipLaunchKernelGGL(gemm_kernel<EPI_LOGITS>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     MT_CHECK_LAUNCH();
     return MT_OK;
@@ -183,7 +208,7 @@ using namespace mt;
 extern "C" int mt_gemm_bf16_f32acc(const void* A, int lda, const void* W, int ldw, const float* bias,
                                    float* C, int ldc, int M, int N, int K, mt_stream_t stream) {
     MT_REQUIRE(ldc >= N, MT_EINVAL, "mt_gemm_bf16_f32acc: ldc < N");
-    GemmEpi ep{C, bias, ldc, 0, 0, 0};
+    GemmEpi ep{C, bias, ldc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
     return launch(EPI_ROWMAJOR, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream);
 }
 
@@ -191,13 +216,31 @@ extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw
                                int B, int T, int H, int K, mt_stream_t stream) {
     MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx: bias is required (b_ih + b_hh)");
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx: bad dims B=%d T=%d H=%d", B, T, H);
-    GemmEpi ep{gx, bias, 0, B, T, H};
+    GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1};
     return launch(EPI_LSTM_GX, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream);
 }
 
 extern "C" int mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
                               int B, int T, int N, int K, mt_stream_t stream) {
-    MT_REQUIRE(B > 0 && T > 0, MT_EINVAL, "mt_gemm_logits: bad dims");
-    GemmEpi ep{logits, bias, 0, B, T, 0};
+    MT_REQUIRE(B > 0 && T > 0 && N % MT_N_PITCH == 0, MT_EINVAL, "mt_gemm_logits: bad dims (N must be a multiple of 88)");
+    GemmEpi ep{logits, bias, 0, B, T, 0, 0, 0, 0, 0, 0, 0, 0, 1};
     return launch(EPI_LOGITS, X, ldx, W, ldw, T * B, N, K, ep, (hipStream_t)stream);
+}
+
+// Batched variants: batch index z -> (z / zdiv, z % zdiv), element offsets z1*stride1 + z2*stride2 on A, W and C
+// (zdiv = 1: a plain stride).  f32, or bf16 (+bias, optional ReLU), row-major output.
+extern "C" int mt_gemm_batched_f32(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw, long long sW1, long long sW2,
+                                   const float* bias, float* C, int ldc, long long sC1, long long sC2, int M, int N, int K,
+                                   int batch, int zdiv, mt_stream_t stream) {
+    MT_REQUIRE(ldc >= N && batch > 0 && zdiv > 0, MT_EINVAL, "mt_gemm_batched_f32: bad arguments");
+    GemmEpi ep{C, bias, ldc, 0, 0, 0, 0, sA1, sW1, sC1, sA2, sW2, sC2, zdiv};
+    return launch(EPI_ROWMAJOR, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream, batch);
+}
+
+extern "C" int mt_gemm_batched_bf16out(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw, long long sW1, long long sW2,
+                                       const float* bias, void* C, int ldc, long long sC1, long long sC2, int M, int N, int K,
+                                       int batch, int zdiv, int relu, mt_stream_t stream) {
+    MT_REQUIRE(ldc >= N && batch > 0 && zdiv > 0 && sC1 % 2 == 0 && sC2 % 2 == 0, MT_EINVAL, "mt_gemm_batched_bf16out: bad arguments");
+    GemmEpi ep{(float*)C, bias, ldc, 0, 0, 0, relu, sA1, sW1, sC1, sA2, sW2, sC2, zdiv};
+    return launch(EPI_ROWMAJOR_BF16, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream, batch);
 }

@@ -261,16 +261,34 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
 
 // Layer output for (g, t, d): nks blocks of 2 KB: [hi | lo][lane = (k half)*32 + batch][8 bf16], k = 16 ks + 8 half + j.
 // hx -> X[(t*B + b)][d*H + k] bf16 (next layer's GEMM A matrix) = the hi pieces (bf16(h), round-to-nearest).
-__global__ void lstm_relayout_kernel(const bf16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, int B, int T, int H) {
-    const int nkb = H >> 3;
-    const size_t total = (size_t)T * B * 2 * nkb;
+// H = layout hidden size (multiple of 16), Hv <= H = real hidden size (units >= Hv are zero padding and are
+// dropped), col_off = first column of this LSTM's features in a concatenated row.  Optionally also writes
+// the fp32 value hi + lo to Y (residual / LayerNorm input of the Large model).
+__global__ void lstm_relayout_kernel(const bf16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, float* __restrict__ Y, int ldy,
+                                     int col_off, int B, int T, int H, int Hv) {
+    const int nkb = H >> 3, nkv = (Hv + 7) >> 3;
+    const size_t total = (size_t)T * B * 2 * nkv;
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        const int kb = id % nkb;
-        const int d = (id / nkb) & 1;
-        const size_t m = id / (2 * nkb);
+        const int kb = id % nkv;
+        const int d = (id / nkv) & 1;
+        const size_t m = id / (2 * nkv);
         const int t = m / B, b = m - (size_t)t * B, g = b >> 5, bl = b & 31;
         const bf16_t* src = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 512 + (size_t)(kb >> 1) * 1024 + ((kb & 1) * 32 + bl) * 8;
-        *(uint4*)(X + m * ldx + d * H + kb * 8) = *(const uint4*)src;
+        const int c0 = col_off + d * Hv + kb * 8;
+        const uint4 hi = *(const uint4*)src;
+        if (X) {
+            if ((c0 & 7) == 0 && kb * 8 + 8 <= Hv) *(uint4*)(X + m * ldx + c0) = hi;
+            else {
+                const bf16_t* e = (const bf16_t*)&hi;
+                for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) X[m * ldx + c0 + j] = e[j];
+            }
+        }
+        if (Y) {
+            const uint4 lo = *(const uint4*)(src + 512);
+            const bf16_t* eh = (const bf16_t*)&hi;
+            const bf16_t* el = (const bf16_t*)&lo;
+            for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) Y[m * ldy + c0 + j] = bf16_to_f32(eh[j]) + bf16_to_f32(el[j]);
+        }
     }
 }
 
@@ -335,13 +353,20 @@ extern "C" int mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, 
     return MT_OK;
 }
 
-extern "C" int mt_lstm_relayout_bf16(const float* hx, void* X, int ldx, int B, int T, int H, mt_stream_t stream) {
-    MT_REQUIRE(hx && X && ldx >= 2 * H && ldx % 8 == 0, MT_EINVAL, "mt_lstm_relayout_bf16: bad arguments");
-    const size_t total = (size_t)T * B * 2 * (H >> 3);
+extern "C" int mt_lstm_relayout_ex(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off, int B, int T, int H, int Hv,
+                                   mt_stream_t stream) {
+    MT_REQUIRE(hx && (X || Y) && H % 16 == 0 && Hv > 0 && Hv <= H && col_off >= 0, MT_EINVAL, "mt_lstm_relayout_ex: bad arguments");
+    MT_REQUIRE((!X || (ldx >= col_off + 2 * Hv && ldx % 8 == 0)) && (!Y || ldy >= col_off + 2 * Hv), MT_EINVAL, "mt_lstm_relayout_ex: bad leading dimension");
+    const size_t total = (size_t)T * B * 2 * ((Hv + 7) >> 3);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(lstm_relayout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hx, (bf16_t*)X, ldx, B, T, H);
+    hipLaunchKernelGGL(lstm_relayout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hx, (bf16_t*)X, ldx, Y, ldy,
+                       col_off, B, T, H, Hv);
     MT_CHECK_LAUNCH();
     return MT_OK;
+}
+
+extern "C" int mt_lstm_relayout_bf16(const float* hx, void* X, int ldx, int B, int T, int H, mt_stream_t stream) {
+    return mt_lstm_relayout_ex(hx, X, ldx, nullptr, 0, 0, B, T, H, H, stream);
 }
 
 #ifdef MT_LSTM_DIAG

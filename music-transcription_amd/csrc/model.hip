@@ -10,7 +10,7 @@ int mt_conv2_bn_relu_pool(const void*, const void*, const float*, void*, int, in
 int mt_gemm_lstm_gx(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
 int mt_gemm_logits(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd(const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
-int mt_lstm_relayout_bf16(const float*, void*, int, int, int, int, mt_stream_t);
+int mt_lstm_relayout_ex(const float*, void*, int, float*, int, int, int, int, int, int, mt_stream_t);
 size_t mt_lstm_gx_bytes(int, int, int);
 size_t mt_lstm_hx_bytes(int, int, int);
 size_t mt_lstm_sync_bytes(int, int);
@@ -18,7 +18,7 @@ size_t mt_lstm_sync_bytes(int, int);
 
 namespace mt {
 struct CnnRnnPlan {
-    int F1, Fo2, K0, K1, M, Mpad;
+    int F1, Fo2, K0, K1, M, Mpad, Hp;
     size_t act1, x0, x1, gx, hx, sync, sync_stride, total;
 };
 static CnnRnnPlan plan(const mt_cnnrnn_weights* w, int B, int T) {
@@ -26,14 +26,15 @@ static CnnRnnPlan plan(const mt_cnnrnn_weights* w, int B, int T) {
     p.F1 = w->n_mels / 2; p.Fo2 = p.F1 / 2;
     p.K0 = p.Fo2 * 64;
     p.K1 = (int)align_up((size_t)2 * w->hidden, 64);
+    p.Hp = (int)align_up((size_t)w->hidden, 16);        // recurrence layout size (zero-padded hidden units)
     p.M = T * B; p.Mpad = (int)align_up((size_t)p.M, 128);
     size_t o = 0;
     p.act1 = o; o += align_up((size_t)B * p.F1 * T * 32 * 2, 256);
     p.x0 = o;   o += align_up((size_t)p.Mpad * p.K0 * 2, 256);
     p.x1 = o;   o += align_up((size_t)p.Mpad * p.K1 * 2, 256);
-    p.gx = o;   o += align_up(mt_lstm_gx_bytes(B, T, w->hidden), 256);
-    p.hx = o;   o += align_up(mt_lstm_hx_bytes(B, T, w->hidden), 256);
-    p.sync_stride = align_up(mt_lstm_sync_bytes(B, w->hidden), 256);
+    p.gx = o;   o += align_up(mt_lstm_gx_bytes(B, T, p.Hp), 256);
+    p.hx = o;   o += align_up(mt_lstm_hx_bytes(B, T, p.Hp), 256);
+    p.sync_stride = align_up(mt_lstm_sync_bytes(B, p.Hp), 256);
     p.sync = o; o += p.sync_stride * w->layers;
     p.total = o;
     return p;
@@ -46,8 +47,7 @@ static int check_weights(const mt_cnnrnn_weights* w) {
     MT_REQUIRE(w, MT_EINVAL, "cnnrnn: null weights");
     MT_REQUIRE(w->n_mels >= 4 && w->layers >= 1 && w->layers <= MT_MAX_LSTM_LAYERS, MT_EINVAL,
                "cnnrnn: bad config n_mels=%d layers=%d", w->n_mels, w->layers);
-    MT_REQUIRE(w->hidden >= 16 && w->hidden % 16 == 0 && w->hidden <= 1024, MT_EUNSUPPORTED,
-               "cnnrnn: hidden size %d unsupported (multiple of 16, <= 1024)", w->hidden);
+    MT_REQUIRE(w->hidden >= 1 && w->hidden <= 1024, MT_EUNSUPPORTED, "cnnrnn: hidden size %d unsupported (1..1024)", w->hidden);
     MT_REQUIRE(w->conv1_w && w->conv1_b && w->conv2_w && w->conv2_b && w->fc_w && w->fc_b, MT_EINVAL, "cnnrnn: null weight pointer");
     for (int l = 0; l < w->layers; ++l)
         MT_REQUIRE(w->w_ih[l] && w->b_gates[l] && w->w_hh[l], MT_EINVAL, "cnnrnn: null LSTM weight pointer (layer %d)", l);
@@ -87,7 +87,7 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
     const CnnRnnPlan p = plan(w, B, T);
     MT_REQUIRE(workspace_bytes >= p.total, MT_EWORKSPACE, "mt_cnnrnn_forward: workspace %zu < %zu bytes", workspace_bytes, p.total);
     char* ws = (char*)workspace;
-    const int H = w->hidden;
+    const int H = p.Hp, Hv = w->hidden;
     hipStream_t st = (hipStream_t)stream;
     int ei = 0;
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;                      // event 0: start
@@ -95,7 +95,7 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     if ((rc = mt_conv2_bn_relu_pool(ws + p.act1, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, p.F1, T, stream)) != MT_OK) return rc;
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
-    if (p.K1 != 2 * H) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, (hipStream_t)stream));
+    if (p.K1 != 2 * Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, (hipStream_t)stream));
     for (int l = 0; l < w->layers; ++l) {
         const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
         const int K = l == 0 ? p.K0 : p.K1;
@@ -104,7 +104,7 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
         if ((rc = mt_lstm_bidir_fwd((const float*)(ws + p.gx), w->w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * l,
                                     p.sync_stride, B, T, H, stream)) != MT_OK) return rc;
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
-        if ((rc = mt_lstm_relayout_bf16((const float*)(ws + p.hx), ws + p.x1, p.K1, B, T, H, stream)) != MT_OK) return rc;
+        if ((rc = mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.x1, p.K1, nullptr, 0, 0, B, T, H, Hv, stream)) != MT_OK) return rc;
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     }
     if ((rc = mt_gemm_logits(ws + p.x1, p.K1, w->fc_w, p.K1, w->fc_b, logits, B, T, MT_N_PITCH, p.K1, stream)) != MT_OK) return rc;

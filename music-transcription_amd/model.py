@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._lib import lib, check, ptr, CnnRnnWeights
+from ._lib import lib, check, ptr, CnnRnnWeights, CnnRnnLargeWeights
 
 BN_EPS = 1e-5
 
@@ -30,14 +30,54 @@ def _round_up(v: int, a: int) -> int:
 
 def _fold_bn(conv_w, conv_b, bn):
     """Conv2d followed by eval-mode BatchNorm2d == Conv2d with w*s, (b-mu)*s+beta, s = gamma/sqrt(var+eps)."""
-    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
-    w = conv_w.detach().float() * s[:, None, None, None]
-    b = (conv_b.detach().float() - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
+    s = bn.weight.detach().float().cpu() / torch.sqrt(bn.running_var.detach().float().cpu() + bn.eps)
+    w = conv_w.detach().float().cpu() * s[:, None, None, None]
+    b = (conv_b.detach().float().cpu() - bn.running_mean.detach().float().cpu()) * s + bn.bias.detach().float().cpu()
     return w, b
 
 
 def _bf16(t):
     return t.to(torch.bfloat16).contiguous()
+
+
+def _pad2(t, rows, cols):
+    out = torch.zeros(rows, cols, dtype=t.dtype)
+    out[:t.shape[0], :t.shape[1]] = t
+    return out
+
+
+def _pack_bilstm(rnn: nn.LSTM, layers: int, H: int, k0_cols, dev):
+    """Pack a bidirectional nn.LSTM for mt_gemm_lstm_gx + mt_lstm_bidir_fwd.  The hidden size is laid out
+    padded to Hp = roundup(H, 16): a padded unit has zero weights and bias, so its gates are 0 and its c, h
+    stay 0.  Gate row p*Hp + j; directions stacked [fwd; reverse]; layer 0's columns are re-ordered by
+    `k0_cols` (index tensor: kernel column -> reference column); deeper layers take the compact
+    [fwd H | reverse H] rows padded to roundup(2H, 64) columns.  Returns (w_ih[], b_gates[], w_hh[])."""
+    Hp = _round_up(H, 16)
+    K1 = _round_up(2 * H, 64)
+    w_ih, b_g, w_hh = [], [], []
+    for l in range(layers):
+        wi, bb, wh = [], [], []
+        for suf in ("", "_reverse"):
+            w = getattr(rnn, f"weight_ih_l{l}{suf}").detach().float().cpu()
+            w = w[:, k0_cols] if l == 0 else w
+            K = w.shape[1]
+            wpad = torch.zeros(4, Hp, K)
+            wpad[:, :H] = w.reshape(4, H, K)
+            wi.append(wpad.reshape(4 * Hp, K))
+            b = (getattr(rnn, f"bias_ih_l{l}{suf}") + getattr(rnn, f"bias_hh_l{l}{suf}")).detach().float().cpu()
+            bpad = torch.zeros(4, Hp)
+            bpad[:, :H] = b.reshape(4, H)
+            bb.append(bpad.reshape(-1))
+            h = getattr(rnn, f"weight_hh_l{l}{suf}").detach().float().cpu()
+            hpad = torch.zeros(4, Hp, Hp)
+            hpad[:, :H, :H] = h.reshape(4, H, H)
+            wh.append(hpad.reshape(4 * Hp, Hp))
+        wcat = torch.cat(wi, 0)
+        Kp = wcat.shape[1] if l == 0 else K1
+        w_ih.append(_bf16(_pad2(wcat, _round_up(8 * Hp, 128), Kp)).to(dev))
+        b_g.append(torch.cat(bb).contiguous().to(dev))
+        w_hh.append(torch.stack(wh).contiguous().to(dev))
+    return w_ih, b_g, w_hh
 
 
 class _HipForward:
@@ -78,8 +118,8 @@ class CNNRNNModel(nn.Module, _HipForward):
     # ---- weight packing (once per load_state_dict): layouts documented in include/mt_hip.h
     def _pack(self, device) -> Dict[str, object]:
         H, L, Fo2 = self.hidden_size, self.num_layers, self.n_mels // 4
-        if H % 16 or H > 1024:
-            raise NotImplementedError(f"hidden_size={H}: the recurrence kernel needs a multiple of 16, <= 1024")
+        if H > 1024:
+            raise NotImplementedError(f"hidden_size={H}: the recurrence kernel keeps W_hh slices in registers, H <= 1024")
         if L > _lib.MAX_LSTM_LAYERS:
             raise NotImplementedError(f"num_layers={L} > {_lib.MAX_LSTM_LAYERS}")
         dev = dict(device=device)
@@ -89,26 +129,13 @@ class CNNRNNModel(nn.Module, _HipForward):
              "conv2_w": _bf16(w2.permute(0, 2, 3, 1).reshape(64, 9, 32)).to(**dev),   # [co][tap][ci]
              "conv2_b": b2.contiguous().to(**dev)}
         K1 = _round_up(2 * H, 64)
-        npad = _round_up(8 * H, 128)
+        # reference feature index c*Fo2+f (cnn_rnn_model.py:60-62) -> kernel column f*64+c
+        cols = (torch.arange(64)[None, :] * Fo2 + torch.arange(Fo2)[:, None]).reshape(-1)
+        wi, bg, wh = _pack_bilstm(self.rnn, L, H, cols, device)
         for l in range(L):
-            wi = torch.cat([getattr(self.rnn, f"weight_ih_l{l}").detach().float(),
-                            getattr(self.rnn, f"weight_ih_l{l}_reverse").detach().float()], 0)     # (8H, K)
-            if l == 0:   # reference feature index c*Fo2+f (cnn_rnn_model.py:60-62) -> kernel's f*64+c
-                wi = wi.reshape(8 * H, 64, Fo2).permute(0, 2, 1).reshape(8 * H, Fo2 * 64)
-                K = Fo2 * 64
-            else:
-                K = K1
-            wp = torch.zeros(npad, K)
-            wp[:8 * H, :wi.shape[1]] = wi
-            t[f"w_ih{l}"] = _bf16(wp).to(**dev)
-            t[f"b_g{l}"] = torch.cat([
-                getattr(self.rnn, f"bias_ih_l{l}").detach().float() + getattr(self.rnn, f"bias_hh_l{l}").detach().float(),
-                getattr(self.rnn, f"bias_ih_l{l}_reverse").detach().float() + getattr(self.rnn, f"bias_hh_l{l}_reverse").detach().float(),
-            ]).contiguous().to(**dev)
-            t[f"w_hh{l}"] = torch.stack([getattr(self.rnn, f"weight_hh_l{l}").detach().float(),
-                                         getattr(self.rnn, f"weight_hh_l{l}_reverse").detach().float()]).contiguous().to(**dev)
+            t[f"w_ih{l}"], t[f"b_g{l}"], t[f"w_hh{l}"] = wi[l], bg[l], wh[l]
         fw = torch.zeros(128, K1)
-        fw[:88, :2 * H] = self.fc.weight.detach().float()
+        fw[:88, :2 * H] = self.fc.weight.detach().float().cpu()
         t["fc_w"] = _bf16(fw).to(**dev)
         t["fc_b"] = self.fc.bias.detach().float().contiguous().to(**dev)
         w = CnnRnnWeights()
@@ -170,9 +197,9 @@ class CNNRNNModel(nn.Module, _HipForward):
 
 
 class CNNRNNModelLarge(nn.Module, _HipForward):
-    """Parameter container with the reference's names (models/cnn_rnn_model.py:142-256).
-    Its HIP forward (residual blocks, 7x3 conv, dual LSTM, clamped attention, heads) is the
-    next SURVEY-8 row and is not built yet: forward raises instead of falling back."""
+    """Residual CNN + dual bi-LSTM + clamped 8-head attention + frame/onset/offset heads
+    (reference models/cnn_rnn_model.py:142-348).  Input (B, 1, n_mels, T) -> logits (B, 88, T), or a dict
+    of three with return_all_heads=True."""
 
     class _Res(nn.Module):
         def __init__(self, cin, cout):
@@ -218,9 +245,125 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
         else:
             self.fc = nn.Linear(comb, 88)
 
-    def forward(self, x, return_all_heads=False):
+    # ---- weight packing: layouts in include/mt_hip.h (mt_cnnrnn_large_weights)
+    def _pack(self, device):
+        H, L, Hl = self.hidden_size, self.num_layers, self.hidden_size // 2
+        if H > 1024 or L > _lib.MAX_LSTM_LAYERS or Hl < 1:
+            raise NotImplementedError(f"hidden_size={H}, num_layers={L}: outside what the kernels implement")
+        F3 = self.n_mels // 8
+        comb = 2 * H + 2 * Hl
+        Cp = _round_up(comb, 64)
+        t = {}
+
+        def put(name, tensor):
+            t[name] = tensor.contiguous().to(device)
+            return ptr(t[name])
+
+        def conv_cl(wf):        # [Cout][Cin][KH][KW] -> [Cout][(kh*KW + kw)*Cin + ci]
+            return wf.permute(0, 2, 3, 1).reshape(wf.shape[0], -1)
+
+        w = CnnRnnLargeWeights()
+        w.n_mels, w.hidden, w.layers, w.hidden_local = self.n_mels, H, L, Hl
+        w.use_attention, w.use_heads = int(self.use_attention), int(self.use_onset_offset_heads)
+        w1, b1 = _fold_bn(self.conv1[0].weight, self.conv1[0].bias, self.conv1[1])
+        w.conv1_w, w.conv1_b = put("conv1_w", w1.reshape(32, 9)), put("conv1_b", b1)
+        for name, rb in (("rb1", self.res_block1), ("rb2", self.res_block2)):
+            wa, ba = _fold_bn(rb.conv1.weight, rb.conv1.bias, rb.bn1)
+            wb, bb = _fold_bn(rb.conv2.weight, rb.conv2.bias, rb.bn2)
+            if len(rb.skip):
+                wsk, bsk = _fold_bn(rb.skip[0].weight, rb.skip[0].bias, rb.skip[1])
+                wsk = wsk.reshape(wsk.shape[0], -1)
+            else:           # identity skip == 1x1 conv with the identity matrix (exact in bf16)
+                wsk, bsk = torch.eye(wb.shape[0]), torch.zeros(wb.shape[0])
+            setattr(w, name + "c1_w", put(name + "c1_w", _bf16(conv_cl(wa))))
+            setattr(w, name + "c1_b", put(name + "c1_b", ba))
+            setattr(w, name + "c2_w", put(name + "c2_w", _bf16(torch.cat([conv_cl(wb), wsk], 1))))
+            setattr(w, name + "c2_b", put(name + "c2_b", bb + bsk))
+        wf, bf_ = _fold_bn(self.freq_aware_conv[0].weight, self.freq_aware_conv[0].bias, self.freq_aware_conv[1])
+        w.fa_w, w.fa_b = put("fa_w", _bf16(conv_cl(wf))), put("fa_b", bf_)
+        # reference feature index c*F3+f (cnn_rnn_model.py:292-294) -> kernel column f*256+c
+        cols = (torch.arange(256)[None, :] * F3 + torch.arange(F3)[:, None]).reshape(-1)
+        wi, bg, wh = _pack_bilstm(self.rnn_main, L, H, cols, device)
+        for l in range(L):
+            t[f"m_wi{l}"], t[f"m_b{l}"], t[f"m_wh{l}"] = wi[l], bg[l], wh[l]
+            w.main_w_ih[l], w.main_b[l], w.main_w_hh[l] = ptr(wi[l]), ptr(bg[l]), ptr(wh[l])
+        wi, bg, wh = _pack_bilstm(self.rnn_local, 1, Hl, cols, device)
+        t["l_wi"], t["l_b"], t["l_wh"] = wi[0], bg[0], wh[0]
+        w.local_w_ih, w.local_b, w.local_w_hh = ptr(wi[0]), ptr(bg[0]), ptr(wh[0])
+        if self.use_attention:
+            heads, d = self.attention.num_heads, self.attention.head_dim
+            dp = _round_up(d, 64)
+            Ca = heads * dp
+            w.heads, w.head_dim_pad, w.attn_scale = heads, dp, float(d) ** -0.5
+            qw = self.attention.qkv.weight.detach().float().cpu().reshape(3, heads, d, comb)
+            qb = self.attention.qkv.bias.detach().float().cpu().reshape(3, heads, d)
+            qwp = torch.zeros(3, heads, dp, Cp); qwp[:, :, :d, :comb] = qw
+            qbp = torch.zeros(3, heads, dp); qbp[:, :, :d] = qb
+            w.qkv_w = put("qkv_w", _bf16(_pad2(qwp.reshape(3 * Ca, Cp), _round_up(3 * Ca, 128), Cp)))
+            w.qkv_b = put("qkv_b", qbp.reshape(-1))
+            pw = self.attention.proj.weight.detach().float().cpu().reshape(comb, heads, d)
+            pwp = torch.zeros(comb, heads, dp); pwp[:, :, :d] = pw
+            w.proj_w = put("proj_w", _bf16(_pad2(pwp.reshape(comb, Ca), _round_up(comb, 128), Ca)))
+            w.proj_b = put("proj_b", self.attention.proj.bias.detach().float().cpu())
+            w.ln_g = put("ln_g", self.attention_norm.weight.detach().float().cpu())
+            w.ln_b = put("ln_b", self.attention_norm.bias.detach().float().cpu())
+        if self.use_onset_offset_heads:
+            Hs = _round_up(H, 64)
+            w.shared_w = put("shared_w", _bf16(_pad2(self.shared_fc.weight.detach().float().cpu(), _round_up(H, 128), Cp)))
+            w.shared_b = put("shared_b", self.shared_fc.bias.detach().float().cpu())
+            hw = torch.cat([m.weight.detach().float().cpu() for m in (self.frame_head, self.onset_head, self.offset_head)], 0)
+            hb = torch.cat([m.bias.detach().float().cpu() for m in (self.frame_head, self.onset_head, self.offset_head)], 0)
+            w.heads_w, w.heads_b = put("heads_w", _bf16(_pad2(hw, 384, Hs))), put("heads_b", hb)
+        else:
+            w.fc_w = put("fc_w", _bf16(_pad2(self.fc.weight.detach().float().cpu(), 128, Cp)))
+            w.fc_b = put("fc_b", self.fc.bias.detach().float().cpu())
+        return {"tensors": t, "struct": w}
+
+    def forward(self, x, return_all_heads=False, chunk_max_power: Optional[torch.Tensor] = None, check_status: bool = False):
         self._require_cuda(x)
-        raise NotImplementedError("CNNRNNModelLarge: HIP forward not built yet (SURVEY 8 rows a4-a6)")
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            raise NotImplementedError("the HIP path implements the eval-mode forward; the training step "
+                                      "(backward kernels) is not built yet -- call model.eval() / torch.no_grad()")
+        if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.n_mels:
+            raise ValueError(f"expected (B, 1, {self.n_mels}, T), got {tuple(x.shape)}")
+        B, _, _, T = x.shape
+        heads_out = self.use_onset_offset_heads
+        if T == 0:
+            z = torch.zeros(B, self.output_dim, 1, device=x.device)
+            return {"frame": z, "onset": z.clone(), "offset": z.clone()} if (heads_out and return_all_heads) else z
+        pk = self._ensure_packed(x.device)
+        w = pk["struct"]
+        x = x.contiguous().float()
+        out = torch.empty(3 if heads_out else 1, B, self.output_dim, T, dtype=torch.float32, device=x.device)
+        key = (B, T, torch.cuda.current_stream(x.device).cuda_stream)
+        if key not in self._ws:
+            nbytes = lib.mt_cnnrnn_large_workspace_bytes(w, B, T)
+            if nbytes == 0:
+                raise _lib.MtError("mt_cnnrnn_large_workspace_bytes: " + _lib.last_error())
+            for k in [k for k in self._ws if k[:2] != (B, T)] + list(self._ws)[: max(0, len(self._ws) - 3)]:
+                self._ws.pop(k, None)
+            self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        ws = self._ws[key]
+        with torch.cuda.device(x.device):
+            check(lib.mt_cnnrnn_large_forward(w, ptr(x), ptr(chunk_max_power), B, T, ptr(out), ptr(ws), ws.numel(),
+                                              _lib.stream_ptr()), "mt_cnnrnn_large_forward")
+        if check_status:
+            self.raise_on_handoff_timeout(B, T)
+        if heads_out and return_all_heads:
+            return {"frame": out[0], "onset": out[1], "offset": out[2]}
+        return out[0]
+
+    def raise_on_handoff_timeout(self, B, T):
+        w = self._packed["struct"]
+        torch.cuda.synchronize()
+        for key, ws in self._ws.items():
+            if key[:2] != (B, T):
+                continue
+            for i in range(self.num_layers + 1):
+                off = lib.mt_cnnrnn_large_status_offset(w, B, T, i)
+                st = int(ws[off:off + 4].view(torch.int32).item())
+                if st != 0:
+                    raise _lib.MtError(f"LSTM {'local' if i == 0 else 'main layer %d' % (i - 1)}: hand-off timed out (status {st:#x})")
 
 
 class TranscriptionModel(nn.Module):

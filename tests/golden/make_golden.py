@@ -33,7 +33,7 @@ torch.manual_seed(0)
 torch.set_num_threads(8)
 
 
-def ref_model(model_type, n_mels, hidden, layers, seed, **kw):
+def ref_model(model_type, n_mels, hidden, layers, seed, calib_T=64, **kw):
     from models.transcription_model import TranscriptionModel
     m = TranscriptionModel(model_type=model_type, n_mels=n_mels, hidden_size=hidden,
                            num_layers=layers, dropout=0.2, device="cpu", **kw)
@@ -41,6 +41,20 @@ def ref_model(model_type, n_mels, hidden, layers, seed, **kw):
                                    use_attention=kw.get("use_attention", True),
                                    use_heads=kw.get("use_onset_offset_heads", True))
     m.load_state_dict(sd, strict=True)
+    # calibrate the BatchNorm running statistics on seeded inputs (reference in train mode, cumulative
+    # average), as a trained checkpoint's would be: activations then stay O(1) through the network
+    if calib_T:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.reset_running_stats()
+                mod.momentum = None
+        m.train()
+        with torch.no_grad():
+            for k in range(3):
+                m(mel_input(2, n_mels, calib_T, seed=100 + k))
+        for k, v in m.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                sd[k] = v.detach().clone()
     m.eval()
     return m, sd
 
@@ -92,6 +106,7 @@ def main():
             x = mel_input(B, nm, T, seed=5)
             small[f"{tag}_cfg"] = np.array([nm, hs, nl, B, T, 11, 5])
             small[f"{tag}_wsum"] = np.array(checksum(sd))
+            small[f"{tag}_bn"] = model_ref.get_bn_flat(sd)
             small[f"{tag}_logits"] = m(x).numpy()
             if mt == "cnn_rnn_large":
                 d = m(x, return_all_heads=True)
@@ -110,12 +125,15 @@ def main():
         # variants without attention / heads
         m, sd = ref_model("large", 32, 16, 2, seed=12, use_attention=False, use_onset_offset_heads=True)
         x = mel_input(2, 32, 30, seed=6)
+        small["large_noattn_bn"] = model_ref.get_bn_flat(sd)
         small["large_noattn_logits"] = m(x).numpy()
         m, sd = ref_model("large", 32, 16, 2, seed=13, use_attention=True, use_onset_offset_heads=False)
+        small["large_noheads_bn"] = model_ref.get_bn_flat(sd)
         small["large_noheads_logits"] = m(x).numpy()
 
         # (vii) padded batch: collate semantics leak padding into valid frames
         m, sd = ref_model("cnn_rnn", 32, 16, 2, seed=11)
+        small["pad_bn"] = model_ref.get_bn_flat(sd)
         xa = mel_input(1, 32, 50, seed=7)
         xb = mel_input(1, 32, 30, seed=8)
         xp = torch.cat([xa, torch.nn.functional.pad(xb, (0, 20))], dim=0)
@@ -133,6 +151,7 @@ def main():
             y = m(x).numpy()
             canon[f"{tag}_cfg"] = np.array([320, 512, 3, B, T, 21, 9])
             canon[f"{tag}_wsum"] = np.array(checksum(sd))
+            canon[f"{tag}_bn"] = model_ref.get_bn_flat(sd)
             canon[f"{tag}_sample"] = y[:, ::5, ::7].copy()
             canon[f"{tag}_stats"] = np.array([y.mean(), y.std(), np.abs(y).max(), y.min(), y.max()], dtype=np.float64)
             if mt == "cnn_rnn_large" and B == 1:
@@ -143,7 +162,7 @@ def main():
 
     # (iv) losses -------------------------------------------------------------------
     loss = {}
-    m, _ = ref_model("cnn_rnn_large", 32, 16, 2, seed=11)
+    m, _ = ref_model("cnn_rnn_large", 32, 16, 2, seed=11, calib_T=0)
     g = torch.Generator().manual_seed(3)
     logits = torch.randn(3, 88, 40, generator=g) * 2.0
     targets = roll_input(3, 40, seed=4, p=0.1)

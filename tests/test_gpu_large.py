@@ -1,0 +1,139 @@
+"""GPU parity tests for CNNRNNModelLarge: op-level (conv, attention pieces) and whole-model against the
+CPU oracle and the reference-generated goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model_ref as R
+
+
+@pytest.fixture(scope="module")
+def mta():
+    import music_transcription_amd as m
+    return m
+
+
+def _mel_in(B, nm, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(B, 1, nm, T, generator=g) * 60.0 - 70.0 + 10.0 * torch.randn(B, 1, nm, 1, generator=g))
+
+
+def _bf(x):
+    return x.bfloat16().float()
+
+
+@pytest.mark.parametrize("C1,C2,Cout,KH,pool,F,T", [(32, 0, 64, 3, 0, 20, 37), (64, 32, 64, 3, 1, 20, 37), (64, 0, 128, 3, 0, 10, 50),
+                                                    (128, 64, 128, 3, 0, 9, 33), (128, 0, 256, 7, 1, 12, 40), (128, 0, 256, 7, 1, 7, 16)])
+def test_conv_cl_matches_torch(mta, C1, C2, Cout, KH, pool, F, T):
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(C1 + Cout + KH)
+    B = 2
+    x = _bf(torch.randn(B, C1, F, T, generator=g))
+    s = _bf(torch.randn(B, C2, F, T, generator=g)) if C2 else None
+    w = _bf(torch.randn(Cout, C1, KH, 3, generator=g) / np.sqrt(C1 * KH * 3))
+    ws = _bf(torch.randn(Cout, C2, 1, 1, generator=g) / np.sqrt(max(C2, 1))) if C2 else None
+    bias = torch.randn(Cout, generator=g)
+    ref = TF.conv2d(x, w, bias, padding=(KH // 2, 1))
+    if C2:
+        ref = ref + TF.conv2d(s, ws)
+    ref = torch.relu(ref)
+    if pool:
+        ref = R.pool_f2(ref)
+    Fo = ref.shape[2]
+    xa = x.permute(0, 2, 3, 1).contiguous().bfloat16().cuda()
+    sa = s.permute(0, 2, 3, 1).contiguous().bfloat16().cuda() if C2 else None
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, -1)
+    if C2:
+        wk = torch.cat([wk, ws.reshape(Cout, C2)], 1)
+    wk = wk.contiguous().bfloat16().cuda()
+    out = torch.zeros(B, Fo, T, Cout, dtype=torch.bfloat16, device="cuda")
+    bias_d = bias.cuda()
+    check(lib.mt_conv_cl_bf16(ptr(xa), ptr(sa), ptr(wk), ptr(bias_d), ptr(out), B, F, T, C1, C2, Cout, KH, 1, pool, 0, 0, stream_ptr()))
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-2 * max(1.0, ref.abs().max().item()), err          # bf16 output rounding
+    # GEMM-row output mode: X[(t*B+b)][fo*Cout+co]
+    ld = Fo * Cout
+    X = torch.zeros(T * B, ld, dtype=torch.bfloat16, device="cuda")
+    check(lib.mt_conv_cl_bf16(ptr(xa), ptr(sa), ptr(wk), ptr(bias_d), ptr(X), B, F, T, C1, C2, Cout, KH, 1, pool, 1, ld, stream_ptr()))
+    assert torch.equal(X.view(T, B, Fo, Cout).permute(1, 2, 0, 3).contiguous(), out)
+
+
+def test_attention_pieces(mta):
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(0)
+    rows, T, Tp = 37, 50, 64
+    S = torch.randn(rows, Tp, generator=g) * 30.0
+    P = torch.full((rows, Tp), 7.0, dtype=torch.bfloat16, device="cuda")
+    S_d = S.cuda()
+    check(lib.mt_attn_softmax_clamped(ptr(S_d), Tp, ptr(P), Tp, T, rows, 0.25, 10.0, stream_ptr()))
+    ref = torch.softmax(torch.clamp(S[:, :T] * 0.25, -10, 10), -1)
+    assert (P[:, :T].float().cpu() - ref).abs().max().item() < 4e-3 and float(P[:, T:].abs().max()) == 0.0
+    # layernorm(residual + proj)
+    n, ld = 96, 128
+    a, b = torch.randn(rows, n, generator=g), torch.randn(rows, n, generator=g)
+    gam, bet = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    y = torch.zeros(rows, ld, dtype=torch.bfloat16, device="cuda")
+    a_d, b_d, g_d, be_d = a.cuda(), b.cuda(), gam.cuda(), bet.cuda()      # keep the device buffers alive across the async launch
+    check(lib.mt_layernorm_residual(ptr(a_d), n, ptr(b_d), n, ptr(g_d), ptr(be_d), ptr(y), ld, rows, n, 1e-6, stream_ptr()))
+    torch.cuda.synchronize()
+    ref = TF.layer_norm(a + b, (n,), gam, bet, 1e-6)
+    assert (y[:, :n].float().cpu() - ref).abs().max().item() < 3e-2 and float(y[:, n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tag", ["large_a", "large_b"])
+def test_large_small_configs_vs_reference_golden(mta, golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, "small_models.npz"))
+    nm, hs, nl, B, T, wseed, xseed = [int(v) for v in z[f"{tag}_cfg"]]
+    sd = R.set_bn_flat(R.make_state_dict("cnn_rnn_large", nm, hs, nl, wseed), z[f"{tag}_bn"])
+    model = mta.TranscriptionModel("cnn_rnn_large", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = _mel_in(B, nm, T, xseed)
+    with torch.no_grad():
+        got = model(x.cuda(), return_all_heads=True)
+        model.model.raise_on_handoff_timeout(B, T)
+        emu = R.cnnrnn_large_forward(sd, x, return_all_heads=True, o=R.Opts(gemm_bf16=True))
+        frame_only = model(x.cuda())
+    assert torch.equal(frame_only, got["frame"])
+    for k in ("frame", "onset", "offset"):
+        gk = got[k].cpu()
+        assert gk.shape == (B, 88, T)
+        assert (gk - emu[k]).abs().max().item() < 1e-2, k        # same bf16 rounding points; accumulation order differs
+        assert (gk - torch.from_numpy(z[f"{tag}_{k}"])).abs().max().item() < 3e-2, k   # vs the fp32 reference (bf16 operands)
+
+
+def test_large_variants_vs_reference_golden(mta, golden_dir):
+    z = np.load(os.path.join(golden_dir, "small_models.npz"))
+    x = _mel_in(2, 32, 30, 6)
+    for seed, att, heads, key in ((12, False, True, "large_noattn_logits"), (13, True, False, "large_noheads_logits")):
+        sd = R.set_bn_flat(R.make_state_dict("large", 32, 16, 2, seed, use_attention=att, use_heads=heads), z[key.replace("_logits", "_bn")])
+        model = mta.TranscriptionModel("large", n_mels=32, hidden_size=16, num_layers=2, device="cuda",
+                                       use_attention=att, use_onset_offset_heads=heads).eval()
+        model.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            got = model(x.cuda()).cpu()
+        ref = torch.from_numpy(z[key])
+        # tiny config (48 features under the LayerNorm): relative bound, the no-heads fc sees |logit| up to ~2
+        assert (got - ref).abs().max().item() < 5e-2 * max(1.0, ref.abs().max().item()), key
+
+
+def test_large_canonical_vs_reference_golden(mta, golden_dir):
+    c = np.load(os.path.join(golden_dir, "canonical_models.npz"))
+    tag = "large_937"
+    nm, hs, nl, B, T, wseed, xseed = [int(v) for v in c[f"{tag}_cfg"]]
+    sd = R.set_bn_flat(R.make_state_dict("cnn_rnn_large", nm, hs, nl, wseed), c[f"{tag}_bn"])
+    model = mta.TranscriptionModel("cnn_rnn_large", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    x = _mel_in(B, nm, T, xseed)
+    with torch.no_grad():
+        d = model(x.cuda(), return_all_heads=True)
+        model.model.raise_on_handoff_timeout(B, T)
+    for k, key in (("frame", f"{tag}_sample"), ("onset", f"{tag}_onset_sample"), ("offset", f"{tag}_offset_sample")):
+        err = np.abs(d[k].cpu().numpy()[:, ::5, ::7] - c[key]).max()
+        assert err < 3e-2, (k, err)

@@ -141,7 +141,7 @@ def test_lstm_layer_matches_oracle(mta, B, T, H, K):
 def test_cnnrnn_small_vs_reference_golden(mta, golden_dir, tag):
     z = np.load(os.path.join(golden_dir, "small_models.npz"))
     nm, hs, nl, B, T, wseed, xseed = [int(v) for v in z[f"{tag}_cfg"]]
-    sd = R.make_state_dict("cnn_rnn", nm, hs, nl, wseed)
+    sd = R.set_bn_flat(R.make_state_dict("cnn_rnn", nm, hs, nl, wseed), z[f"{tag}_bn"])
     model = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda")
     model.load_state_dict(sd, strict=True)
     model.eval()
@@ -162,7 +162,7 @@ def test_cnnrnn_canonical_vs_reference_golden(mta, golden_dir):
     c = np.load(os.path.join(golden_dir, "canonical_models.npz"))
     for tag in ("small_937", "small_938"):
         nm, hs, nl, B, T, wseed, xseed = [int(v) for v in c[f"{tag}_cfg"]]
-        sd = R.make_state_dict("cnn_rnn", nm, hs, nl, wseed)
+        sd = R.set_bn_flat(R.make_state_dict("cnn_rnn", nm, hs, nl, wseed), c[f"{tag}_bn"])
         model = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda")
         model.load_state_dict(sd, strict=True)
         model.eval()

@@ -12,9 +12,13 @@ from oracle import model_ref as R
 TOL = 2e-5  # fp32 noise floor between two fp32 evaluation orders (~1e-6 observed)
 
 
-def _sd(mt, cfg, **kw):
+def _sd(mt, cfg, bn=None, **kw):
+    """Seeded weights + the fixture's calibrated BatchNorm running statistics."""
     nm, hs, nl, B, T, wseed, xseed = [int(v) for v in cfg]
-    return R.make_state_dict(mt, nm, hs, nl, wseed, **kw), (nm, hs, nl, B, T, xseed)
+    sd = R.make_state_dict(mt, nm, hs, nl, wseed, **kw)
+    if bn is not None:
+        R.set_bn_flat(sd, bn)
+    return sd, (nm, hs, nl, B, T, xseed)
 
 
 def _mel(B, nm, T, seed):
@@ -34,7 +38,7 @@ def small(golden_dir):
 @pytest.mark.parametrize("tag,mt", [("small_a", "cnn_rnn"), ("small_b", "cnn_rnn"),
                                     ("large_a", "cnn_rnn_large"), ("large_b", "cnn_rnn_large")])
 def test_small_configs_full_logits(small, tag, mt):
-    sd, (nm, hs, nl, B, T, xs) = _sd(mt, small[f"{tag}_cfg"])
+    sd, (nm, hs, nl, B, T, xs) = _sd(mt, small[f"{tag}_cfg"], small[f"{tag}_bn"])
     assert abs(_wsum(sd) - float(small[f"{tag}_wsum"])) < 1e-6 * float(small[f"{tag}_wsum"]), "weight RNG drift"
     x = _mel(B, nm, T, xs)
     y = R.forward(sd, x, mt).numpy()
@@ -52,7 +56,7 @@ def test_small_configs_full_logits(small, tag, mt):
 
 
 def test_fast_lstm_matches_loop(small):
-    sd, (nm, hs, nl, B, T, xs) = _sd("cnn_rnn", small["small_b_cfg"])
+    sd, (nm, hs, nl, B, T, xs) = _sd("cnn_rnn", small["small_b_cfg"], small["small_b_bn"])
     x = _mel(B, nm, T, xs)
     a = R.cnnrnn_forward(sd, x).numpy()
     b = R.cnnrnn_forward(sd, x, R.Opts(fast_lstm=True)).numpy()
@@ -61,14 +65,14 @@ def test_fast_lstm_matches_loop(small):
 
 def test_large_variants(small):
     x = _mel(2, 32, 30, 6)
-    sd = R.make_state_dict("large", 32, 16, 2, 12, use_attention=False, use_heads=True)
+    sd = R.set_bn_flat(R.make_state_dict("large", 32, 16, 2, 12, use_attention=False, use_heads=True), small["large_noattn_bn"])
     assert np.abs(R.forward(sd, x, "large").numpy() - small["large_noattn_logits"]).max() < TOL
-    sd = R.make_state_dict("large", 32, 16, 2, 13, use_attention=True, use_heads=False)
+    sd = R.set_bn_flat(R.make_state_dict("large", 32, 16, 2, 13, use_attention=True, use_heads=False), small["large_noheads_bn"])
     assert np.abs(R.forward(sd, x, "large").numpy() - small["large_noheads_logits"]).max() < TOL
 
 
 def test_padding_leaks_into_valid_frames(small):
-    sd = R.make_state_dict("cnn_rnn", 32, 16, 2, 11)
+    sd = R.set_bn_flat(R.make_state_dict("cnn_rnn", 32, 16, 2, 11), small["pad_bn"])
     xa, xb = _mel(1, 32, 50, 7), _mel(1, 32, 30, 8)
     xp = torch.cat([xa, torch.nn.functional.pad(xb, (0, 20))], 0)
     yb = R.cnnrnn_forward(sd, xp).numpy()
@@ -83,7 +87,7 @@ def test_padding_leaks_into_valid_frames(small):
                                     ("large_937", "cnn_rnn_large")])
 def test_canonical_config_samples(golden_dir, tag, mt):
     c = np.load(os.path.join(golden_dir, "canonical_models.npz"))
-    sd, (nm, hs, nl, B, T, xs) = _sd(mt, c[f"{tag}_cfg"])
+    sd, (nm, hs, nl, B, T, xs) = _sd(mt, c[f"{tag}_cfg"], c[f"{tag}_bn"])
     assert abs(_wsum(sd) - float(c[f"{tag}_wsum"])) < 1e-6 * float(c[f"{tag}_wsum"])
     x = _mel(B, nm, T, xs)
     with torch.no_grad():
