@@ -174,3 +174,38 @@ def test_two_rank_gloo_sharding(tmp_path):
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
         assert "ok" in o
+
+
+def test_chunking_notes_and_midi_writer(mta, tmp_path):
+    from music_transcription_amd import transcribe as tr
+    y = np.arange(480000 + 1234, dtype=np.float32)
+    chunks, dur = tr.split_into_chunks(y)
+    assert chunks.shape == (2, 480000) and dur == pytest.approx((480000 + 1234) / 16000)
+    assert chunks[1, 1233] == y[-1] and chunks[1, 1234:].max() == 0.0          # main.py:93-95 zero pad
+    assert tr.split_into_chunks(np.zeros(480000, np.float32))[0].shape == (1, 480000)
+    roll = np.zeros((88, 100), np.float32)
+    roll[0, 0:5] = 1; roll[39, 10:11] = 1; roll[87, 95:100] = 1; roll[39, 20:30] = 1
+    notes = tr.pianoroll_to_notes(roll, 31.25)
+    assert notes == [(21, 0.0, 5 / 31.25), (60, 10 / 31.25, 11 / 31.25), (60, 20 / 31.25, 30 / 31.25), (108, 95 / 31.25, 100 / 31.25)]
+    p = tmp_path / "o.mid"
+    tr.write_midi(notes, str(p))
+    raw = p.read_bytes()
+    assert raw[:4] == b"MThd" and raw[8:14] == bytes([0, 1, 0, 2, 0, 220]) and raw.count(b"MTrk") == 2
+    assert raw.count(bytes([0x90, 60, 100])) == 2 and raw.endswith(b"\xFF\x2F\x00")
+    # wav loader: stereo int16 at 32 kHz -> mono float32 at 16 kHz
+    from scipy.io import wavfile
+    t = np.arange(32000) / 32000.0
+    st = np.stack([np.sin(2 * np.pi * 440 * t), np.sin(2 * np.pi * 440 * t)], 1)
+    wavfile.write(str(tmp_path / "a.wav"), 32000, (st * 20000).astype(np.int16))
+    y = tr.load_audio(str(tmp_path / "a.wav"))
+    assert y.dtype == np.float32 and abs(len(y) - 16000) <= 1 and 0.55 < np.abs(y).max() < 0.65
+
+
+def test_cli_errors_like_reference(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), str(tmp_path / "nope.wav"), str(tmp_path / "m.pth")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "Error: Audio file not found" in r.stdout
+    (tmp_path / "a.wav").write_bytes(b"RIFF")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), str(tmp_path / "a.wav"), str(tmp_path / "m.pth")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "Error: Model file not found" in r.stdout
