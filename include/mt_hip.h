@@ -114,6 +114,14 @@ size_t mt_lstm_hx_bytes(int B, int T, int H);
 size_t mt_lstm_sync_bytes(int B, int H);
 int    mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                          int B, int T, int H, mt_stream_t stream);
+/* mode 0: as above (agent-scope hand-off, correct under any workgroup placement).  mode 1: XCD-local
+ * hand-off: each (direction, batch group) runs on workgroups that read their hardware XCC id and share one
+ * XCD's L2 (about 2x shorter steps).  It needs the dispatcher to deal the launch's workgroups evenly over the
+ * 8 XCDs (liveness only; bounded spins report otherwise in the status word): check once with
+ * mt_xcd_census (host array of 8 counts; scratch32 = 32 device bytes; synchronises the stream).          */
+int    mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
+                            int B, int T, int H, int mode, mt_stream_t stream);
+int    mt_xcd_census(int* counts_host, void* scratch32, int nwg, mt_stream_t stream);
 /* hx -> X[(t*B+b)*ldx + dir*H + j] bf16 (next GEMM's A) / y[b][t][dir*H + j] f32 (torch layout). */
 int    mt_lstm_relayout_bf16(const float* hx, void* X, int ldx, int B, int T, int H, mt_stream_t stream);
 int    mt_lstm_unpack_f32(const float* hx, float* y, int B, int T, int H, mt_stream_t stream);
@@ -127,7 +135,7 @@ typedef struct {
     int n_mels;                              /* input mel bins                                    */
     int hidden;                              /* LSTM hidden size (1..1024); laid out padded to 16 */
     int layers;                              /* LSTM layers (<= MT_MAX_LSTM_LAYERS)               */
-    int reserved;
+    int lstm_mode;                           /* 0 agent-scope hand-off, 1 XCD-local (mt_lstm_bidir_fwd_ex) */
     const float* conv1_w;                    /* [32][9]  BN-folded                                */
     const float* conv1_b;                    /* [32]                                              */
     const void*  conv2_w;                    /* bf16 [64][9][32] BN-folded                        */
@@ -193,7 +201,7 @@ typedef struct {
     int n_mels, hidden, layers, hidden_local;     /* real sizes (hidden_local = hidden / 2)            */
     int use_attention, use_heads, heads, head_dim_pad;  /* head_dim padded to a multiple of 64         */
     float attn_scale;                             /* (real head_dim)^-1/2                              */
-    int reserved;
+    int lstm_mode;                                /* 0 agent-scope hand-off, 1 XCD-local               */
     const float* conv1_w; const float* conv1_b;   /* [32][9], [32]                                     */
     const void*  rb1c1_w; const float* rb1c1_b;   /* bf16 [64][9*32]                                   */
     const void*  rb1c2_w; const float* rb1c2_b;   /* bf16 [64][9*64 + 32]  (conv2 + 1x1 skip)          */

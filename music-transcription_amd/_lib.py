@@ -33,6 +33,10 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       f"or `make -C {os.path.join(_HERE, 'csrc')}` (needs hipcc)")
 
+# torch ships its own libamdhip64; load it first so that libmt_hip.so binds to the SAME HIP runtime instance
+# (two runtimes in one process do not share devices, streams or allocations).
+import torch as _torch  # noqa: E402,F401
+
 lib = C.CDLL(LIB_PATH)
 
 vp, sz, i32, f32p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
@@ -45,7 +49,7 @@ class MelDesc(C.Structure):
 
 class CnnRnnWeights(C.Structure):
     """mt_cnnrnn_weights (include/mt_hip.h)."""
-    _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("reserved", i32),
+    _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("lstm_mode", i32),
                 ("conv1_w", vp), ("conv1_b", vp), ("conv2_w", vp), ("conv2_b", vp),
                 ("w_ih", vp * MAX_LSTM_LAYERS), ("b_gates", vp * MAX_LSTM_LAYERS), ("w_hh", vp * MAX_LSTM_LAYERS),
                 ("fc_w", vp), ("fc_b", vp)]
@@ -54,7 +58,7 @@ class CnnRnnWeights(C.Structure):
 class CnnRnnLargeWeights(C.Structure):
     """mt_cnnrnn_large_weights (include/mt_hip.h)."""
     _fields_ = ([(n, i32) for n in ("n_mels", "hidden", "layers", "hidden_local", "use_attention", "use_heads", "heads", "head_dim_pad")]
-                + [("attn_scale", C.c_float), ("reserved", i32)]
+                + [("attn_scale", C.c_float), ("lstm_mode", i32)]
                 + [(n, vp) for n in ("conv1_w", "conv1_b", "rb1c1_w", "rb1c1_b", "rb1c2_w", "rb1c2_b", "rb2c1_w", "rb2c1_b",
                                      "rb2c2_w", "rb2c2_b", "fa_w", "fa_b")]
                 + [("main_w_ih", vp * MAX_LSTM_LAYERS), ("main_b", vp * MAX_LSTM_LAYERS), ("main_w_hh", vp * MAX_LSTM_LAYERS)]
@@ -81,6 +85,8 @@ _SIGS = {
     "mt_lstm_hx_bytes": (sz, [i32, i32, i32]),
     "mt_lstm_sync_bytes": (sz, [i32, i32]),
     "mt_lstm_bidir_fwd": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "mt_lstm_bidir_fwd_ex": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
+    "mt_xcd_census": (i32, [vp, vp, i32, vp]),
     "mt_lstm_relayout_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "mt_lstm_unpack_f32": (i32, [vp, vp, i32, i32, i32, vp]),
     "mt_conv_cl_bf16": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),

@@ -47,13 +47,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
     constexpr bool SWAP = (EPI == EPI_LSTM_GX);
     __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * BK * 2];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2s): give every XCD a contiguous
+    // run of tile ids, and order tile ids so that the ~64 tiles an XCD has in flight form an 8 x 8 patch
+    // (groups of 8 tile rows, column-major inside a group): each A and W panel is then shared by 8 resident
+    // workgroups through that XCD's L2.  Speed only -- any order is correct.
+    int m0, n0;
+    {
+        const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, total = tiles_m * tiles_n;
+        const int bid = blockIdx.x, xcd = bid & 7, q = total >> 3, rmd = total & 7;
+        const int pid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * tiles_n, grp = pid / per_group, first_m = grp * GM;
+        const int gm = min(GM, tiles_m - first_m), in_grp = pid - grp * per_group;
+        m0 = (first_m + in_grp % gm) * BM;
+        n0 = (in_grp / gm) * BN;
+    }
+    float* outp;       // kernel arguments stay read-only (a modified by-value struct would be copied to scratch)
     {
         const int z1 = blockIdx.z / ep.zdiv, z2 = blockIdx.z - z1 * ep.zdiv;
         A += (size_t)(z1 * ep.sA + z2 * ep.sA2);
         W += (size_t)(z1 * ep.sW + z2 * ep.sW2);
         const long long oc = z1 * ep.sC + z2 * ep.sC2;
-        ep.out += (EPI == EPI_ROWMAJOR_BF16 ? oc / 2 : oc);                          // out is typed float*
+        outp = ep.out + (EPI == EPI_ROWMAJOR_BF16 ? oc / 2 : oc);                    // out is typed float*
     }
     const int r = lane & 31, h = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;              // wave's 64x64 sub-tile
@@ -62,33 +77,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
     const int srow = tid >> 3, sch = tid & 7;
     const bf16_t* ag = A + (size_t)(m0 + srow) * lda + sch * 8;
     const bf16_t* wg = W + (size_t)(n0 + srow) * ldw + sch * 8;
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-#define MT_GLOAD(kt)                                                        \
+    // Two register sets: the K-tile two steps ahead is in flight from global memory while the tile one step
+    // ahead (loaded during the previous iteration) is written to the other LDS buffer after this step's MFMAs.
+    uint4 pa0_0, pa0_1, pa0_2, pa0_3, pw0_0, pw0_1, pw0_2, pw0_3, pa1_0, pa1_1, pa1_2, pa1_3, pw1_0, pw1_1, pw1_2, pw1_3;   // scalars: arrays here end up in scratch
+#define MT_GLOAD1(kt, S, I)                                                 \
+    pa##S##_##I = *(const uint4*)(ag + (size_t)(kt) * BK + (size_t)(32 * (I)) * lda); \
+    pw##S##_##I = *(const uint4*)(wg + (size_t)(kt) * BK + (size_t)(32 * (I)) * ldw);
+#define MT_GLOAD(kt, S) do { MT_GLOAD1(kt, S, 0) MT_GLOAD1(kt, S, 1) MT_GLOAD1(kt, S, 2) MT_GLOAD1(kt, S, 3) } while (0)
+#define MT_SWRITE1(buf, S, I)                                               \
+    *(uint4*)(smem + (buf) * (BM + BN) * BK * 2 + (srow + 32 * (I)) * 128 + (swz(srow + 32 * (I), sch) << 4)) = pa##S##_##I; \
+    *(uint4*)(smem + (buf) * (BM + BN) * BK * 2 + BM * BK * 2 + (srow + 32 * (I)) * 128 + (swz(srow + 32 * (I), sch) << 4)) = pw##S##_##I;
+#define MT_SWRITE(buf, S) do { MT_SWRITE1(buf, S, 0) MT_SWRITE1(buf, S, 1) MT_SWRITE1(buf, S, 2) MT_SWRITE1(buf, S, 3) } while (0)
+#define MT_KSTEP(as, ws, ks)                                                \
+    {                                                                       \
+        const int rowa0 = wm * 64 + r, rowa1 = rowa0 + 32, roww0 = wn * 64 + r, roww1 = roww0 + 32; \
+        const bf16x8 fa0 = *(const bf16x8*)((as) + rowa0 * 128 + (swz(rowa0, (ks) * 2 + h) << 4)); \
+        const bf16x8 fa1 = *(const bf16x8*)((as) + rowa1 * 128 + (swz(rowa1, (ks) * 2 + h) << 4)); \
+        const bf16x8 fb0 = *(const bf16x8*)((ws) + roww0 * 128 + (swz(roww0, (ks) * 2 + h) << 4)); \
+        const bf16x8 fb1 = *(const bf16x8*)((ws) + roww1 * 128 + (swz(roww1, (ks) * 2 + h) << 4)); \
+        if (SWAP) {                                                         \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0, fa0, acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1, fa0, acc[0][1], 0, 0, 0); \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0, fa1, acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1, fa1, acc[1][1], 0, 0, 0); \
+        } else {                                                            \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0); \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0); \
+        }                                                                   \
+    }
+#define MT_COMPUTE(buf)                                                     \
     do {                                                                    \
-        const bf16_t* ap_ = ag + (size_t)(kt) * BK;                         \
-        const bf16_t* wp_ = wg + (size_t)(kt) * BK;                         \
-        ra0 = *(const uint4*)(ap_);                                         \
-        ra1 = *(const uint4*)(ap_ + (size_t)32 * lda);                      \
-        ra2 = *(const uint4*)(ap_ + (size_t)64 * lda);                      \
-        ra3 = *(const uint4*)(ap_ + (size_t)96 * lda);                      \
-        rw0 = *(const uint4*)(wp_);                                         \
-        rw1 = *(const uint4*)(wp_ + (size_t)32 * ldw);                      \
-        rw2 = *(const uint4*)(wp_ + (size_t)64 * ldw);                      \
-        rw3 = *(const uint4*)(wp_ + (size_t)96 * ldw);                      \
-    } while (0)
-    // rows srow + 32 i share (row >> 1) & 7 only in part; compute each row's swizzle
-#define MT_SWRITE(buf)                                                      \
-    do {                                                                    \
-        char* as_ = smem + (buf) * (BM + BN) * BK * 2;                      \
-        char* ws_ = as_ + BM * BK * 2;                                      \
-        *(uint4*)(as_ + (srow) * 128 + (swz(srow, sch) << 4)) = ra0;        \
-        *(uint4*)(as_ + (srow + 32) * 128 + (swz(srow + 32, sch) << 4)) = ra1; \
-        *(uint4*)(as_ + (srow + 64) * 128 + (swz(srow + 64, sch) << 4)) = ra2; \
-        *(uint4*)(as_ + (srow + 96) * 128 + (swz(srow + 96, sch) << 4)) = ra3; \
-        *(uint4*)(ws_ + (srow) * 128 + (swz(srow, sch) << 4)) = rw0;        \
-        *(uint4*)(ws_ + (srow + 32) * 128 + (swz(srow + 32, sch) << 4)) = rw1; \
-        *(uint4*)(ws_ + (srow + 64) * 128 + (swz(srow + 64, sch) << 4)) = rw2; \
-        *(uint4*)(ws_ + (srow + 96) * 128 + (swz(srow + 96, sch) << 4)) = rw3; \
+        const char* as = smem + (buf) * (BM + BN) * BK * 2;                 \
+        const char* ws = as + BM * BK * 2;                                  \
+        MT_KSTEP(as, ws, 0) MT_KSTEP(as, ws, 1) MT_KSTEP(as, ws, 2) MT_KSTEP(as, ws, 3) \
     } while (0)
 
     f32x16 acc[2][2];
@@ -100,34 +123,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int nk = K / BK;
-    MT_GLOAD(0);
-    MT_SWRITE(0);
+    MT_GLOAD(0, 0);
+    MT_SWRITE(0, 0);
+    if (nk > 1) MT_GLOAD(1, 1);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) MT_GLOAD(kt + 1);
-        const char* as = smem + buf * (BM + BN) * BK * 2;
-        const char* ws = as + BM * BK * 2;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int rowa = wm * 64 + i * 32 + r, roww = wn * 64 + i * 32 + r;
-                fa[i] = *(const bf16x8*)(as + rowa * 128 + (swz(rowa, ks * 2 + h) << 4));
-                fb[i] = *(const bf16x8*)(ws + roww * 128 + (swz(roww, ks * 2 + h) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                    else      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (kt + 1 < nk) MT_SWRITE(buf ^ 1);
+    // iteration kt: tile kt is in LDS buf kt&1, tile kt+1 is in register set (kt+1)&1, tile kt+2 gets requested
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 2 < nk) MT_GLOAD(kt + 2, 0);
+        MT_COMPUTE(0);
+        if (kt + 1 < nk) MT_SWRITE(1, 1);
         __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 3 < nk) MT_GLOAD(kt + 3, 1);
+            MT_COMPUTE(1);
+            if (kt + 2 < nk) MT_SWRITE(0, 0);
+            __syncthreads();
+        }
     }
+#undef MT_GLOAD
+#undef MT_GLOAD1
+#undef MT_SWRITE
+#undef MT_SWRITE1
+#undef MT_COMPUTE
+#undef MT_KSTEP
 
     // ---- epilogue.  acc[i][j]: M sub-tile i, N sub-tile j.  Unswapped: lane column = n, register rows = m.
     //      Swapped: lane column = m, register rows = n.
@@ -142,12 +160,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (m < M && n < N) ep.out[(size_t)m * ep.ldc + n] = acc[i][j][e] + bv;
+                    if (m < M && n < N) outp[(size_t)m * ep.ldc + n] = acc[i][j][e] + bv;
                 }
             } else if (EPI == EPI_ROWMAJOR_BF16) {
                 const int n = nb + r;
                 const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
-                bf16_t* o = (bf16_t*)ep.out;
+                bf16_t* o = (bf16_t*)outp;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -165,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
                     const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (m < M && n < N) {
                         const int t = m / ep.B, b = m - t * ep.B;
-                        ep.out[(((size_t)head * ep.B + b) * MT_N_PITCH + pit) * ep.T + t] = acc[i][j][e] + bv;
+                        outp[(((size_t)head * ep.B + b) * MT_N_PITCH + pit) * ep.T + t] = acc[i][j][e] + bv;
                     }
                 }
             } else {  // EPI_LSTM_GX (swapped): lane column = m, register rows = n
@@ -173,13 +191,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
                 if (m < M) {
                     const int t = m / ep.B, b = m - t * ep.B, g = b >> 5, bl = b & 31;
                     const int H = ep.H, nkb = H >> 3;
+                    const size_t tg = ((size_t)(g * ep.T + t) * 2) * nkb * 1024 + bl;       // gx block base of (g, t)
+                    // the 32 rows of this tile share (direction, gate) when they do not straddle a multiple of H
+                    const int d0 = nb / (4 * H), rem0 = nb - d0 * 4 * H, p0 = rem0 / H, jj0 = rem0 - p0 * H;
+                    if (jj0 + 32 <= H && nb + 32 <= N) {
+                        float* o = outp + tg + (size_t)d0 * nkb * 1024 + p0 * 256;
+                        const float* bp = ep.bias + nb;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (n < N) {
-                            const int d = n / (4 * H), rem = n - d * 4 * H, p = rem / H, jj = rem - p * H;
-                            const size_t off = ((((size_t)(g * ep.T + t) * 2 + d) * nkb + (jj >> 3)) * 4 + p) * 256 + (jj & 7) * 32 + bl;
-                            ep.out[off] = acc[i][j][e] + ep.bias[n];
+                        for (int e = 0; e < 16; ++e) {
+                            const int row = (e & 3) + 8 * (e >> 2) + 4 * h, jj = jj0 + row;
+                            o[(size_t)(jj >> 3) * 1024 + (jj & 7) * 32] = acc[i][j][e] + bp[row];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                            if (n < N) {
+                                const int d = n / (4 * H), rem = n - d * 4 * H, p = rem / H, jj = rem - p * H;
+                                outp[tg + ((size_t)(d * nkb + (jj >> 3)) * 4 + p) * 256 + (jj & 7) * 32] = acc[i][j][e] + ep.bias[n];
+                            }
                         }
                     }
                 }
@@ -191,7 +221,7 @@ static int launch(int epi, const void* A, int lda, const void* W, int ldw, int M
     MT_REQUIRE(A && W && ep.out, MT_EINVAL, "gemm: null pointer");
     MT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MT_EINVAL,
                "gemm: bad dims M=%d N=%d K=%d lda=%d ldw=%d (K must be a multiple of %d)", M, N, K, lda, ldw, BK);
-    dim3 grid(cdiv(N, BN), cdiv(M, BM), batch);
+    dim3 grid(cdiv(N, BN) * cdiv(M, BM), 1, batch);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
     if (epi == EPI_ROWMAJOR) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     else if (epi == EPI_LSTM_GX) hipLaunchKernelGGL(gemm_kernel<EPI_LSTM_GX>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);

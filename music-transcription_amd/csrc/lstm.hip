@@ -37,6 +37,7 @@
 // Every spin is bounded: on timeout the workgroup raises the abort word, which every other
 // workgroup's spin also watches, and all workgroups drain.
 #include "mt_common.h"
+#include <atomic>
 
 namespace mt {
 
@@ -50,6 +51,9 @@ struct LstmArgs {
     unsigned* status;     // [0] = abort/timeout word, zeroed before every launch
     int B, T, H;
     int g0;               // first batch group of this launch
+    // XCD-local mode (see lstm_rec_kernel): lanes = (direction, batch group) pairs of this launch,
+    unsigned* tickets;    // [8] per-XCD arrival counters, zeroed before every launch
+    int nlanes, xcd_off;  // lane l runs on the XCD with hardware id (l + xcd_off) & 7
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -72,14 +76,43 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
     lo = f32_to_bf16(x - bf16_to_f32(hi));
 }
 
-template <int NKSW>   // 16-wide k-steps per wave: ceil(H/16/4)
+// XCD = true: XCD-local hand-off.  The S = H/8 workgroups of one (direction, batch group) "lane" are made up of
+// workgroups that physically sit on ONE XCD: every workgroup reads its hardware XCC id, lanes are bound to XCC
+// ids, and a workgroup takes its slice index from an arrival ticket of its own XCD -- nothing is inferred from
+// blockIdx.  Inside an XCD the L2 is the coherence point of all its CUs, so the payload and the flag are PLAIN
+// stores (they stay in that L2) and the sc1 loads (L1 bypass) hit them at L2 latency instead of crossing the
+// fabric: ~2x shorter steps.  Which XCD a workgroup lands on is the dispatcher's choice: if an XCD receives fewer
+// than S workgroups of the launch its lane cannot complete; that is a liveness matter only (bounded spins raise
+// the status word), never a stale read.  The host sizes the grid 8 x S (the dispatcher deals workgroups
+// round-robin over the 8 XCDs) and falls back to the agent-scope variant (XCD = false) if a census launch at
+// start-up shows a different distribution.
+template <int NKSW, bool XCD>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
 __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][16][64];
     __shared__ __attribute__((aligned(16))) bf16_t hs[2][32][8];       // [hi|lo][batch][unit]
+#ifdef MT_LSTM_LDS_PAD
+    __shared__ char lds_pad[MT_LSTM_LDS_PAD];                          // experiment: inflate the LDS footprint
+    if (threadIdx.x == 0) lds_pad[blockIdx.x & 1023] = 1;
+#endif
     __shared__ int abort_s;
+    __shared__ int ident_s[2];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int kb = blockIdx.x, d = blockIdx.y, g = blockIdx.z + a.g0;
     const int H = a.H, T = a.T, nkb = H >> 3, nks = H >> 4;
+    int kb, d, g;
+    if (XCD) {
+        if (tid == 0) {
+            const int xcc = __builtin_amdgcn_s_getreg(20 /*HW_REG_XCC_ID*/ | (0 << 6) | ((4 - 1) << 11));
+            const int ln = (xcc - a.xcd_off) & 7;
+            ident_s[0] = ln;
+            ident_s[1] = ln < a.nlanes ? (int)__hip_atomic_fetch_add(a.tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+        }
+        __syncthreads();
+        const int ln = ident_s[0], ticket = ident_s[1];
+        if (ln >= a.nlanes || ticket >= nkb) return;       // this XCD hosts no lane, or the lane is already fully staffed
+        kb = ticket; d = ln & 1; g = a.g0 + (ln >> 1);
+    } else {
+        kb = blockIdx.x; d = blockIdx.y; g = blockIdx.z + a.g0;
+    }
     const int b = lane & 31, hh = lane >> 5;
     const int Bg = min(32, a.B - g * 32);            // valid batch rows of this group
 
@@ -243,11 +276,13 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
             typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
             const u32x4 piece = *(const u32x4*)(&hs[hh][b][0]);    // lanes 0-31: hi, lanes 32-63: lo
             const int hoff = ((t * 2 + d) * nkb) * 1024 + (kb >> 1) * 2048 + hh * 1024 + ((kb & 1) * 32 + b) * 16;
-            __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1*/);
-#ifndef MT_LSTM_NO_DRAIN
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pieces have reached memory before the flag says so
-#endif
-            if (lane == 0) __hip_atomic_store(flags + kb, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (XCD) __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
+            else __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1: write-through*/);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pieces are in L2 / memory before the flag says so
+            if (lane == 0) {
+                if (XCD) *(volatile unsigned*)(flags + kb) = (unsigned)(s + 1);   // plain store: stays in this XCD's L2
+                else __hip_atomic_store(flags + kb, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         DIAG_STAMP(6);
     }
@@ -308,8 +343,9 @@ __global__ void lstm_unpack_kernel(const bf16_t* __restrict__ hx, float* __restr
 }
 
 template <int NKSW>
-static int launch_rec(const LstmArgs& a, int ngroups, hipStream_t st) {
-    hipLaunchKernelGGL(lstm_rec_kernel<NKSW>, dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
+static int launch_rec(const LstmArgs& a, int ngroups, bool xcd, hipStream_t st) {
+    if (xcd) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, true>), dim3(8 * (a.H >> 3)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -324,8 +360,26 @@ extern "C" size_t mt_lstm_sync_bytes(int B, int H) { return align_up(64 + (size_
 // One bidirectional LSTM layer's recurrence.  gx from mt_gemm_lstm_gx, w_hh = [fwd; reverse] (2 x 4H x H f32),
 // hx receives every step's hidden state (layer output, MFMA-operand layout).  sync_ws: mt_lstm_sync_bytes().
 // After the stream has drained, word 0 of sync_ws is 0 on success, 1 + step on a hand-off timeout.
-extern "C" int mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
-                                 int B, int T, int H, mt_stream_t stream) {
+// Workgroups of a `nwg`-workgroup launch per hardware XCC id (host array of 8 ints).  Synchronises the stream.
+__global__ void xcd_census_kernel(unsigned* counts) {
+    if (threadIdx.x == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));
+        atomicAdd(counts + (xcc & 7), 1u);
+    }
+}
+extern "C" int mt_xcd_census(int* counts_host, void* scratch32, int nwg, mt_stream_t stream) {
+    MT_REQUIRE(counts_host && scratch32 && nwg > 0, MT_EINVAL, "mt_xcd_census: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    MT_CHECK_HIP(hipMemsetAsync(scratch32, 0, 32, st));
+    hipLaunchKernelGGL(xcd_census_kernel, dim3(nwg), dim3(256), 0, st, (unsigned*)scratch32);
+    MT_CHECK_LAUNCH();
+    MT_CHECK_HIP(hipMemcpyAsync(counts_host, scratch32, 32, hipMemcpyDeviceToHost, st));
+    MT_CHECK_HIP(hipStreamSynchronize(st));
+    return MT_OK;
+}
+
+static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
+                         int B, int T, int H, int xcd_local, mt_stream_t stream) {
     MT_REQUIRE(gx && w_hh && hx && sync_ws, MT_EINVAL, "mt_lstm_bidir_fwd: null pointer");
     MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 1024, MT_EUNSUPPORTED,
                "mt_lstm_bidir_fwd: hidden size %d unsupported (multiple of 16, <= 1024)", H);
@@ -335,22 +389,40 @@ extern "C" int mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, 
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
     MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
-    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 64), (unsigned*)sync_ws, B, T, H, 0};
-    // every workgroup of a launch must be resident (they wait on each other): at most 256 workgroups
-    // (one per CU) per launch; further batch groups run as further launches on the same stream.
-    const int per_launch = (256 / (2 * nkb)) > 0 ? (256 / (2 * nkb)) : 1;
+    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 64), (unsigned*)sync_ws, B, T, H, 0, (unsigned*)((char*)sync_ws + 32), 0, 0};
+    // every workgroup of a launch must be resident (they wait on each other).  Agent-scope variant: at most 256
+    // workgroups (one per CU) per launch; XCD-local variant: at most 8 lanes = 4 batch groups per launch, each lane's
+    // H/8 workgroups share one XCD (H/8 <= 128 -> at most 4 per CU).  Further groups run as further launches.
+    static std::atomic<unsigned> rotate{0};
+    const int per_launch = xcd_local ? 4 : ((256 / (2 * nkb)) > 0 ? (256 / (2 * nkb)) : 1);
     const int nksw = cdiv(nkb / 2, 4);
     for (int g0 = 0; g0 < ng; g0 += per_launch) {
         a.g0 = g0;
         const int n = (ng - g0) < per_launch ? (ng - g0) : per_launch;
-        if (nksw <= 1) launch_rec<1>(a, n, st);
-        else if (nksw <= 2) launch_rec<2>(a, n, st);
-        else if (nksw <= 4) launch_rec<4>(a, n, st);
-        else if (nksw <= 8) launch_rec<8>(a, n, st);
-        else launch_rec<16>(a, n, st);
+        a.nlanes = 2 * n;
+        a.xcd_off = xcd_local ? (int)(rotate.fetch_add(2 * n) & 7) : 0;
+        if (xcd_local && g0 > 0) MT_CHECK_HIP(hipMemsetAsync((char*)sync_ws + 32, 0, 32, st));   // fresh tickets per launch
+        const bool x = xcd_local != 0;
+        if (nksw <= 1) launch_rec<1>(a, n, x, st);
+        else if (nksw <= 2) launch_rec<2>(a, n, x, st);
+        else if (nksw <= 4) launch_rec<4>(a, n, x, st);
+        else if (nksw <= 8) launch_rec<8>(a, n, x, st);
+        else launch_rec<16>(a, n, x, st);
         MT_CHECK_LAUNCH();
     }
     return MT_OK;
+}
+
+extern "C" int mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
+                                 int B, int T, int H, mt_stream_t stream) {
+    return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, 0, stream);
+}
+
+// mode 0: agent-scope hand-off (placement-independent); mode 1: XCD-local hand-off (see lstm_rec_kernel).
+extern "C" int mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
+                                    int B, int T, int H, int mode, mt_stream_t stream) {
+    MT_REQUIRE(mode == 0 || mode == 1, MT_EINVAL, "mt_lstm_bidir_fwd_ex: mode must be 0 or 1");
+    return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, mode, stream);
 }
 
 extern "C" int mt_lstm_relayout_ex(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off, int B, int T, int H, int Hv,

@@ -115,173 +115,199 @@ __device__ __forceinline__ void lds_sync_wave() {
 }
 
 __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
-    const float* __restrict__ wave, int n_samples, int T, int hop, int n_mels,
+    const float* __restrict__ wave, int n_samples, int T, int hop, int n_mels, int B, int tiles_per_chunk,
     const float2* __restrict__ window2, const float2* __restrict__ tw1024, const float2* __restrict__ w2048,
     const int* __restrict__ fstart, const int* __restrict__ grp, const float* __restrict__ well, int ell_rows,
     float* __restrict__ out, unsigned* __restrict__ chunk_max) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xbuf = (float*)smem;                                   // [NWAVE][2][XREG]
     float2* w2048_s = (float2*)(smem + NWAVE * 2 * XREG * 4);     // [1024]
-    float* tile = (float*)(smem + NWAVE * 2 * XREG * 4 + 1024 * 8);  // [n_mels][33]
+    float2* win_s = w2048_s + 1024;                               // [1024] Hann window pairs (w[2n], w[2n+1])
+    float* tile = (float*)(win_s + 1024);                         // [n_mels][33]
     const int ngrp = (n_mels + 31) >> 5;
-    int* fstart_s = (int*)(tile + n_mels * 33);                       // [ngrp * 32]
-    float* well_s = (float*)(fstart_s + ngrp * 32);                   // [ell_rows][32]
+    int* fstart_s = (int*)(tile + n_mels * 33);                   // [ngrp * 32]
+    int* grp_s = fstart_s + ngrp * 32;                            // [32] trip count of each filter group
+    float* well_s = (float*)(grp_s + 32);                         // [ell_rows][32]
 
     const int tid = threadIdx.x;
     const int wv = tid >> 6, lane = tid & 63, half = lane >> 5, l = lane & 31;
-    const int b = blockIdx.y, tile0 = blockIdx.x * FT;
-    const float* x = wave + (size_t)b * n_samples;
     float* X = xbuf + (wv * 2 + half) * XREG;
 
-    for (int i = tid; i < 1024; i += NWAVE * 64) w2048_s[i] = w2048[i];
+    for (int i = tid; i < 1024; i += NWAVE * 64) { w2048_s[i] = w2048[i]; win_s[i] = window2[i]; }
     for (int i = tid; i < ngrp * 32; i += NWAVE * 64) fstart_s[i] = fstart[i];
+    if (tid < 32) grp_s[tid] = grp[tid];
     for (int i = tid; i < ell_rows * 32; i += NWAVE * 64) well_s[i] = well[i];
     for (int i = tid; i < NWAVE * 2 * XREG; i += NWAVE * 64) xbuf[i] = 0.0f;   // padded ELL rows read (x 0) past bin 1024
-
     __syncthreads();
 
-    float vmax = 0.0f;
+    // Raw samples come through a buffer descriptor over the whole waveform array: an offset outside
+    // [0, B*n_samples) reads as 0 (hardware range check), and offsets that would cross into a neighbouring
+    // chunk are pushed out of range explicitly -- so edge frames need no second code path.
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wave, 0, (int)min((size_t)B * n_samples * 4, (size_t)0x7fffffff), 0x00020000);
+    const int n_tiles = B * tiles_per_chunk;
+    constexpr int ITERS = FT / (NWAVE * 2);
+    typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2;
+
+    // frame (tile ti, iteration it) of this half-wave -> raw float2 x 32 (prefetched one frame ahead)
+    u32x2 raw[32];
+#define MEL_ISSUE_LOADS(TI, IT)                                                                         \
+    do {                                                                                                \
+        const int ti_ = (TI), bb_ = ti_ / tiles_per_chunk;                                              \
+        const int f_ = (ti_ - bb_ * tiles_per_chunk) * FT + (IT) * (NWAVE * 2) + wv * 2 + half;         \
+        const int s0_ = f_ * hop - (MT_N_FFT / 2) + 2 * l;   /* first sample of this lane, may be < 0 or >= n_samples */ \
+        const bool ok_ = (ti_ < n_tiles) && (f_ < T);                                                   \
+        const long long base_ = ((long long)bb_ * n_samples + s0_) * 4;                                 \
+        _Pragma("unroll") for (int r = 0; r < 32; ++r) {                                                \
+            const int sidx = s0_ + 64 * r;                                                              \
+            /* the pair (sidx, sidx+1) must lie inside the chunk; an odd n_samples' last sample is handled when windowing */ \
+            const bool in = ok_ && (sidx >= 0) && (sidx + 1 < n_samples + (n_samples & 1));             \
+            raw[r] = __builtin_amdgcn_raw_buffer_load_b64(wsrc, in ? (int)(base_ + 256 * r) : -16, 0, 0); \
+        }                                                                                               \
+    } while (0)
+
 #ifdef MT_MEL_DIAG
     unsigned long long dg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tl = __builtin_amdgcn_s_memrealtime();
 #endif
-    MDIAG(0);
+    int ti = blockIdx.x;
+    MEL_ISSUE_LOADS(ti, 0);
+    for (; ti < n_tiles; ti += gridDim.x) {
+        const int b = ti / tiles_per_chunk, tile0 = (ti - b * tiles_per_chunk) * FT;
+        float vmax = 0.0f;
 #pragma unroll 1
-    for (int it = 0; it < FT / (NWAVE * 2); ++it) {
-        const int fl = it * (NWAVE * 2) + wv * 2 + half;   // frame within tile
-        const int f = tile0 + fl;
-        float re[32], im[32];
-        // ---- load + window: z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1], n = l + 32 r
-        const int s0 = f * hop - (MT_N_FFT / 2) + 2 * l;
-        // wave-uniform: both frames of this wave lie fully inside the chunk and rows are 8-B aligned
-        const int fw0 = tile0 + it * (NWAVE * 2) + wv * 2;
-        const bool interior = ((n_samples & 1) == 0) && (fw0 * hop - (MT_N_FFT / 2) >= 0) &&
-                              ((fw0 + 1) * hop + (MT_N_FFT / 2) <= n_samples) && (fw0 + 1 < T);
-        if (interior) {
-            const float2* xp = (const float2*)(x + s0);
+        for (int it = 0; it < ITERS; ++it) {
+            const int fl = it * (NWAVE * 2) + wv * 2 + half;   // frame within tile
+            const int f = tile0 + fl;
+            float re[32], im[32];
+            MDIAG(0);
+            // ---- window: z[n] = w[2n] x[2n] + i w[2n+1] x[2n+1], n = l + 32 r
+            const bool odd_tail = (n_samples & 1) != 0;
 #pragma unroll
             for (int r = 0; r < 32; ++r) {
-                const float2 w = window2[l + 32 * r];
-                const float2 v = xp[32 * r];
-                re[r] = v.x * w.x;
-                im[r] = v.y * w.y;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int s = s0 + 64 * r;
-                const float2 w = window2[l + 32 * r];
-                const float x0 = (f < T && s >= 0 && s < n_samples) ? x[s] : 0.0f;
-                const float x1 = (f < T && s + 1 >= 0 && s + 1 < n_samples) ? x[s + 1] : 0.0f;
+                const float2 w = win_s[l + 32 * r];
+                float x0 = __uint_as_float(raw[r][0]), x1 = __uint_as_float(raw[r][1]);
+                if (odd_tail && (f * hop - (MT_N_FFT / 2) + 2 * l + 64 * r + 1 >= n_samples)) x1 = 0.0f;
                 re[r] = x0 * w.x;
                 im[r] = x1 * w.y;
             }
-        }
-        // ---- stage A: DFT-32 over r, twiddle, transpose
-#ifdef MT_MEL_DIAG
-        asm volatile("" :: "v"(re[31]), "v"(im[31]));
-#endif
-        MDIAG(1);
-        __builtin_amdgcn_sched_barrier(0);
-        fft32_dif(re, im);
-        __builtin_amdgcn_sched_barrier(0);
+            // ---- stage A: DFT-32 over r, twiddle, transpose
+            __builtin_amdgcn_sched_barrier(0);
+            MDIAG(1);
+            fft32_dif(re, im);
+            __builtin_amdgcn_sched_barrier(0);
+            MDIAG(2);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const float2 tw = tw1024[i * 32 + l];          // W_1024^(l * brev5(i)), L1-resident table
-            const float yr = re[i], yi = im[i];
-            re[i] = fmaf(yi, tw.y, yr * tw.x);
-            im[i] = fmaf(-yr, tw.y, yi * tw.x);
-        }
-        MDIAG(2);
-#pragma unroll
-        for (int i = 0; i < 32; ++i) X[brev5(i) * 33 + l] = re[i];
-        lds_sync_wave();
-#pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) re[n1] = X[l * 33 + n1];
-        lds_sync_wave();
-#pragma unroll
-        for (int i = 0; i < 32; ++i) X[brev5(i) * 33 + l] = im[i];
-        lds_sync_wave();
-#pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) im[n1] = X[l * 33 + n1];
-        lds_sync_wave();
-        // ---- stage B: DFT-32 over n1 -> register i holds Z[l + 32*brev5(i)]
-        MDIAG(3);
-        fft32_dif(re, im);
-        MDIAG(4);
-        const float nyq = re[0] - im[0];                   // X[1024] = Re Z[0] - Im Z[0] (lane l == 0)
-        // ---- real split: partner Z[(1024-k) & 1023] via a mirrored LDS exchange
-        float dr[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) X[l + 32 * brev5(i)] = re[i];
-        if (l == 0) X[1024] = re[0];                       // Z[1024] := Z[0], so the mirror index needs no wrap
-        lds_sync_wave();
-        const float* Xm = X + (32 - l);                    // Xm[32*(31-k1)] = Z[1024 - (l + 32 k1)]
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const float pr = Xm[32 * (31 - brev5(i))];
-            dr[i] = 0.5f * (re[i] - pr);                   // -Oi
-            re[i] = 0.5f * (re[i] + pr);                   // Er
-        }
-        lds_sync_wave();
-#pragma unroll
-        for (int i = 0; i < 32; ++i) X[l + 32 * brev5(i)] = im[i];
-        if (l == 0) X[1024] = im[0];
-        lds_sync_wave();
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int k = l + 32 * brev5(i);
-            const float pi = Xm[32 * (31 - brev5(i))];
-            const float2 w = w2048_s[k];                   // (cos, sin)(2 pi k / 2048)
-            const float ei = 0.5f * (im[i] - pi), orr = 0.5f * (im[i] + pi), oi = -dr[i];
-            const float xr = re[i] + fmaf(w.x, orr, w.y * oi);
-            const float xi = ei + fmaf(w.x, oi, -w.y * orr);
-            dr[i] = fmaf(xr, xr, xi * xi);                 // power; dr[i] is dead from here
-        }
-        lds_sync_wave();
-#pragma unroll
-        for (int i = 0; i < 32; ++i) X[l + 32 * brev5(i)] = dr[i];
-        if (l == 0) X[1024] = nyq * nyq;
-        lds_sync_wave();
-        MDIAG(5);
-        // ---- sparse mel projection + dB: lane l reduces filters l + 32 i; uniform trip counts (padded ELL)
-        int row = 0;
-        for (int i = 0; i < ngrp; ++i) {
-            const int m = l + 32 * i;
-            const int n = grp[i];                           // scalar load: same for every lane
-            const float* Xs = X + fstart_s[m];
-            const float* w = well_s + row * 32 + l;
-            float a0 = 0.0f, a1 = 0.0f;
-            int j = 0;
-            for (; j + 1 < n; j += 2) {
-                a0 = fmaf(w[j * 32], Xs[j], a0);
-                a1 = fmaf(w[(j + 1) * 32], Xs[j + 1], a1);
+            for (int i = 0; i < 32; ++i) {
+                const float2 tw = tw1024[i * 32 + l];          // W_1024^(l * brev5(i)), L1-resident table
+                const float yr = re[i], yi = im[i];
+                re[i] = fmaf(yi, tw.y, yr * tw.x);
+                im[i] = fmaf(-yr, tw.y, yi * tw.x);
             }
-            if (j < n) a0 = fmaf(w[j * 32], Xs[j], a0);
-            const float acc = a0 + a1;
-            row += n;
-            if (m < n_mels) {
-                vmax = fmaxf(vmax, acc);
-                tile[m * 33 + fl] = 10.0f * log10f(fmaxf(acc, AMIN));
-            }
-        }
-        lds_sync_wave();
-        MDIAG(6);
-    }
-    // ---- per-chunk max of mel POWER (non-negative floats order like their bit patterns)
+            __builtin_amdgcn_sched_barrier(0);
+            MDIAG(3);
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    __syncthreads();
-    if (lane == 0) atomicMax(chunk_max + b, __float_as_uint(vmax));
-    // ---- write the [n_mels][FT] tile as row segments
-    for (int idx = tid; idx < n_mels * FT; idx += NWAVE * 64) {
-        const int m = idx >> 5, tl = idx & 31, t = tile0 + tl;
-        if (t < T) out[((size_t)b * n_mels + m) * T + t] = tile[m * 33 + tl];
+            for (int i = 0; i < 32; ++i) X[brev5(i) * 33 + l] = re[i];
+            lds_sync_wave();
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) re[n1] = X[l * 33 + n1];
+            lds_sync_wave();
+#pragma unroll
+            for (int i = 0; i < 32; ++i) X[brev5(i) * 33 + l] = im[i];
+            lds_sync_wave();
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) im[n1] = X[l * 33 + n1];
+            lds_sync_wave();
+            // ---- stage B: DFT-32 over n1 -> register i holds Z[l + 32*brev5(i)]
+            MDIAG(4);
+            fft32_dif(re, im);
+            __builtin_amdgcn_sched_barrier(0);
+            MDIAG(5);
+            const float nyq = re[0] - im[0];                   // X[1024] = Re Z[0] - Im Z[0] (lane l == 0)
+            // ---- real split: partner Z[(1024-k) & 1023] via a mirrored LDS exchange
+            float dr[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) X[l + 32 * brev5(i)] = re[i];
+            if (l == 0) X[1024] = re[0];                       // Z[1024] := Z[0], so the mirror index needs no wrap
+            lds_sync_wave();
+            const float* Xm = X + (32 - l);                    // Xm[32*(31-k1)] = Z[1024 - (l + 32 k1)]
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float pr = Xm[32 * (31 - brev5(i))];
+                dr[i] = 0.5f * (re[i] - pr);                   // -Oi
+                re[i] = 0.5f * (re[i] + pr);                   // Er
+            }
+            lds_sync_wave();
+#pragma unroll
+            for (int i = 0; i < 32; ++i) X[l + 32 * brev5(i)] = im[i];
+            if (l == 0) X[1024] = im[0];
+            lds_sync_wave();
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int k = l + 32 * brev5(i);
+                const float pi = Xm[32 * (31 - brev5(i))];
+                const float2 w = w2048_s[k];                   // (cos, sin)(2 pi k / 2048)
+                const float ei = 0.5f * (im[i] - pi), orr = 0.5f * (im[i] + pi), oi = -dr[i];
+                const float xr = re[i] + fmaf(w.x, orr, w.y * oi);
+                const float xi = ei + fmaf(w.x, oi, -w.y * orr);
+                dr[i] = fmaf(xr, xr, xi * xi);                 // power; dr[i] is dead from here
+            }
+            lds_sync_wave();
+#pragma unroll
+            for (int i = 0; i < 32; ++i) X[l + 32 * brev5(i)] = dr[i];
+            if (l == 0) X[1024] = nyq * nyq;
+            lds_sync_wave();
+            MDIAG(6);
+            // ---- prefetch the next frame's samples (next iteration, or the first frame of this block's next tile):
+            //      re/im/dr are dead from here, so the 64 registers of raw data cost no extra pressure, and the
+            //      loads fly during the mel reduction, the dB conversion and (last iteration) the tile store
+            if (it + 1 < ITERS) MEL_ISSUE_LOADS(ti, it + 1);
+            else MEL_ISSUE_LOADS(ti + gridDim.x, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- sparse mel projection + dB: lane l reduces filters l + 32 i; uniform trip counts (ELL padded to x4)
+            int row = 0;
+            for (int i = 0; i < ngrp; ++i) {
+                const int m = l + 32 * i;
+                const int n = grp_s[i];                         // same for every lane; multiple of 4
+                const float* Xs = X + fstart_s[m];
+                const float* w = well_s + row * 32 + l;
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                for (int j = 0; j < n; j += 4) {
+                    const float w0 = w[j * 32], w1 = w[(j + 1) * 32], w2 = w[(j + 2) * 32], w3 = w[(j + 3) * 32];
+                    const float x0 = Xs[j], x1 = Xs[j + 1], x2 = Xs[j + 2], x3 = Xs[j + 3];
+                    a0 = fmaf(w0, x0, a0); a1 = fmaf(w1, x1, a1); a2 = fmaf(w2, x2, a2); a3 = fmaf(w3, x3, a3);
+                }
+                const float acc = (a0 + a1) + (a2 + a3);
+                row += n;
+                if (m < n_mels && f < T) {
+                    vmax = fmaxf(vmax, acc);
+                    // 10 log10(x) = (10 log10 2) log2(x); v_log_f32 is good to 1 ulp of log2 -> < 1e-5 dB
+                    tile[m * 33 + fl] = 3.01029995663981195f * __log2f(fmaxf(acc, AMIN));
+                }
+            }
+            lds_sync_wave();
+            MDIAG(7);
+        }
+        // ---- per-chunk max of mel POWER (non-negative floats order like their bit patterns)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        // LDS-only barriers around the tile store: __syncthreads() would also drain vmcnt, i.e. wait for the
+        // prefetched samples of the next tile and for this tile's global stores
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (lane == 0) atomicMax(chunk_max + b, __float_as_uint(vmax));
+        // ---- write the [n_mels][FT] tile as row segments
+        for (int idx = tid; idx < n_mels * FT; idx += NWAVE * 64) {
+            const int m = idx >> 5, tl = idx & 31, t = tile0 + tl;
+            if (t < T) out[((size_t)b * n_mels + m) * T + t] = tile[m * 33 + tl];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // tile is reused by the next tile of this block
+        MDIAG(8);
     }
-    MDIAG(7);
 #ifdef MT_MEL_DIAG
-    if (tid == 0) { const int wg = blockIdx.y * gridDim.x + blockIdx.x; for (int i = 0; i < 12; ++i) mt_mel_diag[wg & 1023][i] = dg[i]; }
+    if (tid == 0) { for (int i = 0; i < 12; ++i) mt_mel_diag[blockIdx.x & 1023][i] = dg[i]; }
 #endif
+#undef MEL_ISSUE_LOADS
 }
 
 __global__ void mel_clamp_kernel(float* __restrict__ mel, const unsigned* __restrict__ chunk_max, size_t per_chunk) {
@@ -393,6 +419,7 @@ extern "C" int mt_mel_plan_init(void* plan, size_t plan_bytes, int sr, int hop, 
     for (int i = 0; i < ngrp; ++i) {
         int lmax = 0;
         for (int l = 0; l < 32; ++l) lmax = std::max(lmax, len_[i * 32 + l]);
+        lmax = (lmax + 3) / 4 * 4;                       // the kernel's reduction loop is unrolled by 4
         MT_REQUIRE(off + lmax <= ELL_MAX_ROWS, MT_EUNSUPPORTED, "mt_mel_plan_init: filterbank too wide for the ELL table");
         grp[i] = lmax; grp[32 + i] = off;
         for (int l = 0; l < 32; ++l) {
@@ -425,7 +452,7 @@ extern "C" int mt_mel_db_f32(const void* plan, const mt_mel_desc* desc, const fl
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(chunk_max_power, 0, (size_t)B * 4, st));
     const int ngrp = (n_mels + 31) / 32;
-    const size_t lds = (size_t)NWAVE * 2 * XREG * 4 + 1024 * 8 + (size_t)n_mels * 33 * 4 + (size_t)ngrp * 32 * 4 +
+    const size_t lds = (size_t)NWAVE * 2 * XREG * 4 + 2 * 1024 * 8 + (size_t)n_mels * 33 * 4 + (size_t)ngrp * 32 * 4 + 32 * 4 +
                        (size_t)desc->ell_rows * 32 * 4;
     MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "mt_mel_db_f32: n_mels=%d needs %zu B of LDS", n_mels, lds);
     static bool attr_set = false;
@@ -433,8 +460,10 @@ extern "C" int mt_mel_db_f32(const void* plan, const mt_mel_desc* desc, const fl
         MT_CHECK_HIP(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid(cdiv(T, FT), B);
-    hipLaunchKernelGGL(mel_kernel, grid, dim3(NWAVE * 64), lds, st, wave, n_samples, T, hop, n_mels,
+    MT_REQUIRE((size_t)B * n_samples * 4 < (size_t)0x7fffffff, MT_EUNSUPPORTED, "mt_mel_db_f32: B*n_samples too large for one launch (split the batch)");
+    const int tiles_per_chunk = cdiv(T, FT), n_tiles = B * tiles_per_chunk;
+    dim3 grid(n_tiles < 256 ? n_tiles : 256);          // persistent: one workgroup per CU walks the tiles
+    hipLaunchKernelGGL(mel_kernel, grid, dim3(NWAVE * 64), lds, st, wave, n_samples, T, hop, n_mels, B, tiles_per_chunk,
                        (const float2*)(p + L.window), (const float2*)(p + L.tw1024), (const float2*)(p + L.w2048),
                        (const int*)(p + L.fstart), (const int*)(p + L.grp), (const float*)(p + L.well), desc->ell_rows,
                        mel_db, (unsigned*)chunk_max_power);

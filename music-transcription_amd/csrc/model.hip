@@ -9,7 +9,7 @@ int mt_conv1_bn_relu_pool(const float*, const float*, const float*, const float*
 int mt_conv2_bn_relu_pool(const void*, const void*, const float*, void*, int, int, int, int, mt_stream_t);
 int mt_gemm_lstm_gx(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
 int mt_gemm_logits(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
-int mt_lstm_bidir_fwd(const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
+int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
 int mt_lstm_relayout_ex(const float*, void*, int, float*, int, int, int, int, int, int, mt_stream_t);
 size_t mt_lstm_gx_bytes(int, int, int);
 size_t mt_lstm_hx_bytes(int, int, int);
@@ -101,8 +101,8 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
         const int K = l == 0 ? p.K0 : p.K1;
         if ((rc = mt_gemm_lstm_gx(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, stream)) != MT_OK) return rc;
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
-        if ((rc = mt_lstm_bidir_fwd((const float*)(ws + p.gx), w->w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * l,
-                                    p.sync_stride, B, T, H, stream)) != MT_OK) return rc;
+        if ((rc = mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * l,
+                                    p.sync_stride, B, T, H, w->lstm_mode, stream)) != MT_OK) return rc;
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
         if ((rc = mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.x1, p.K1, nullptr, 0, 0, B, T, H, Hv, stream)) != MT_OK) return rc;
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;

@@ -15,7 +15,7 @@ int mt_gemm_batched_f32(const void*, int, long long, long long, const void*, int
                         long long, long long, int, int, int, int, int, mt_stream_t);
 int mt_gemm_batched_bf16out(const void*, int, long long, long long, const void*, int, long long, long long, const float*, void*, int,
                             long long, long long, int, int, int, int, int, int, mt_stream_t);
-int mt_lstm_bidir_fwd(const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
+int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
 int mt_lstm_relayout_ex(const float*, void*, int, float*, int, int, int, int, int, int, mt_stream_t);
 int mt_attn_softmax_clamped(const float*, int, void*, int, int, long long, float, float, mt_stream_t);
 int mt_attn_transpose_v(const void*, int, int, void*, int, int, int, int, int, mt_stream_t);
@@ -116,15 +116,15 @@ extern "C" int mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const f
     if (p.K1 != 2 * Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, st));
     // local LSTM (1 layer) -> columns [2H, 2H + 2Hl)
     RUN(mt_gemm_lstm_gx(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx), B, T, p.Hlp, p.K0, stream));
-    RUN(mt_lstm_bidir_fwd((const float*)(ws + p.gx), w->local_w_hh, (float*)(ws + p.hx), ws + p.sync, p.sync_stride, B, T, p.Hlp, stream));
+    RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->local_w_hh, (float*)(ws + p.hx), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode, stream));
     RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, stream));
     // main LSTM
     for (int l = 0; l < w->layers; ++l) {
         const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
         const int K = l == 0 ? p.K0 : p.K1;
         RUN(mt_gemm_lstm_gx(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, stream));
-        RUN(mt_lstm_bidir_fwd((const float*)(ws + p.gx), w->main_w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * (l + 1),
-                              p.sync_stride, B, T, p.Hp, stream));
+        RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * (l + 1),
+                              p.sync_stride, B, T, p.Hp, w->lstm_mode, stream));
         if (l + 1 < w->layers) RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, stream));
         else RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, stream));
     }

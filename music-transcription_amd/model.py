@@ -24,6 +24,34 @@ from ._lib import lib, check, ptr, CnnRnnWeights, CnnRnnLargeWeights
 BN_EPS = 1e-5
 
 
+_LSTM_MODE: Dict[int, int] = {}
+
+
+def lstm_mode(device) -> int:
+    """Hand-off protocol of the recurrence kernel on this device: 0 = agent-scope (default; correct under any
+    workgroup placement), 1 = XCD-local (csrc/lstm.hip; experimental: measured SLOWER at H = 512, B = 32 because a
+    lane's whole all-gather then goes through one XCD's L2 -- 5.0 vs 4.4 us/step).  MT_LSTM_MODE=1 opts in, and
+    only takes effect if a census launch shows the dispatcher dealing workgroups evenly over the 8 XCDs."""
+    import os
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _LSTM_MODE:
+        env = os.environ.get("MT_LSTM_MODE", "0")
+        if env != "1":
+            _LSTM_MODE[idx] = 0
+        else:
+            import ctypes
+            counts = (ctypes.c_int * 8)()
+            scratch = torch.empty(32, dtype=torch.uint8, device=dev)
+            ok = True
+            with torch.cuda.device(dev):
+                for nwg in (512, 256, 128):
+                    check(lib.mt_xcd_census(counts, ptr(scratch), nwg, _lib.stream_ptr()), "mt_xcd_census")
+                    ok = ok and all(c == nwg // 8 for c in counts)
+            _LSTM_MODE[idx] = 1 if ok else 0
+    return _LSTM_MODE[idx]
+
+
 def _round_up(v: int, a: int) -> int:
     return (v + a - 1) // a * a
 
@@ -175,6 +203,7 @@ class CNNRNNModel(nn.Module, _HipForward):
             import ctypes
             n_ev = len(events)
             ev_arr = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in events])
+        w.lstm_mode = lstm_mode(x.device)
         with torch.cuda.device(x.device):
             check(lib.mt_cnnrnn_forward_ex(w, ptr(x), ptr(chunk_max_power), B, T, ptr(logits), ptr(ws), ws.numel(),
                                            ev_arr, n_ev, _lib.stream_ptr()), "mt_cnnrnn_forward")
@@ -344,6 +373,7 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
                 self._ws.pop(k, None)
             self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         ws = self._ws[key]
+        w.lstm_mode = lstm_mode(x.device)
         with torch.cuda.device(x.device):
             check(lib.mt_cnnrnn_large_forward(w, ptr(x), ptr(chunk_max_power), B, T, ptr(out), ptr(ws), ws.numel(),
                                               _lib.stream_ptr()), "mt_cnnrnn_large_forward")

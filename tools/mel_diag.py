@@ -23,8 +23,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 out = np.zeros((1024, 12), dtype=np.uint64)
 lib.mt_mel_diag_read(out.ctypes.data)
-x = out[:960].astype(np.float64) * 10.0      # ns per block
-names = ["prologue (tables->LDS)", "load+window (x2 iters)", "fft A + twiddle", "transpose", "fft B", "real split + power", "mel + dB", "tile store"]
+x = out[:256].astype(np.float64) * 10.0 / 7.5   # ns per (tile iteration): 3.75 tiles x 2 iterations per block
+names = ["wait at loop top", "window (load wait)", "fft A", "twiddle", "transpose", "fft B", "split+power", "mel+dB", "tile store (per tile/2)"]
 for i, n in enumerate(names):
     print(f"{n:26s} mean {x[:, i].mean():9.0f} ns  min {x[:, i].min():9.0f}  max {x[:, i].max():9.0f}")
-print("sum", x[:, :8].sum(1).mean())
+print("sum", x[:, :9].sum(1).mean())
