@@ -243,6 +243,16 @@ int    mt_predict_threshold(const float* logits, float* roll, long long n, float
 int    mt_f1_counts(const float* pred, const float* target, const long long* lengths,
                     unsigned long long* counts, int B, int P, int T, mt_stream_t stream);
 
+/* ------------------------------------------------------------------ optimizer step (training)
+ * clip_grad_norm_(max_norm) + torch.optim.Adam with coupled L2 weight decay over flat f32 buffers
+ * (train_transcriber.py:134-144, train_cnn.py:290); a NaN/Inf gradient norm skips the step (:137-142).
+ * step = 1-based step count.  stats (2 floats, may be NULL) = {norm before clipping, 1 if stepped else 0}.
+ * With data parallelism, all-reduce (mean) `grads` over RCCL before calling this.                         */
+size_t mt_adam_workspace_bytes(void);
+int    mt_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                         int step, float* stats, void* workspace, size_t workspace_bytes, mt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,69 @@
+"""Fused clip + Adam step and the data-parallel gradient reduction of the training loop:
+reference semantics = clip_grad_norm_(1.0) then torch.optim.Adam(lr, eps=1e-8, weight_decay=1e-5) with a
+NaN-norm skip (train/train_transcriber.py:130-150, scripts/train_cnn.py:290).
+
+All parameters live in ONE flat fp32 buffer (parameters become views of it), so the step is two kernel
+launches and the data-parallel reduction is ONE RCCL all-reduce of the flat gradient."""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import lib, check, ptr
+
+
+def flatten_parameters(params: Iterable[torch.nn.Parameter]):
+    """Re-home parameters as views of one flat fp32 tensor; returns (flat_params, flat_grads) with p.grad views."""
+    params = [p for p in params if p.requires_grad]
+    n = sum(p.numel() for p in params)
+    dev = params[0].device
+    flat = torch.empty(n, dtype=torch.float32, device=dev)
+    grads = torch.zeros(n, dtype=torch.float32, device=dev)
+    o = 0
+    for p in params:
+        k = p.numel()
+        flat[o:o + k].copy_(p.detach().reshape(-1))
+        p.data = flat[o:o + k].view_as(p)
+        p.grad = grads[o:o + k].view_as(p)
+        o += k
+    return flat, grads
+
+
+def allreduce_mean_(flat_grads: torch.Tensor) -> torch.Tensor:
+    """Gradient mean over ranks: one all-reduce of the flat buffer (RCCL on GPUs, gloo on CPU tensors)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+        flat_grads.div_(dist.get_world_size())
+    return flat_grads
+
+
+class FusedAdamClip:
+    """clip_grad_norm_ + Adam (coupled L2) in libmt_hip.so over flat buffers.  step() returns a (2,) device tensor
+    {grad norm before clipping, 1.0 if the step was taken / 0.0 if skipped for a non-finite norm}: no host sync."""
+
+    def __init__(self, flat_params: torch.Tensor, flat_grads: torch.Tensor, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-5, max_norm=1.0):
+        if not flat_params.is_cuda:
+            raise RuntimeError("FusedAdamClip runs on the GPU only")
+        self.p, self.g = flat_params, flat_grads
+        self.m, self.v = torch.zeros_like(flat_params), torch.zeros_like(flat_params)
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.t = 0
+        self.ws = torch.empty(lib.mt_adam_workspace_bytes(), dtype=torch.uint8, device=flat_params.device)
+        self.stats = torch.zeros(2, dtype=torch.float32, device=flat_params.device)
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def step(self, sync_grads: bool = True):
+        if sync_grads:
+            allreduce_mean_(self.g)
+        self.t += 1
+        with torch.cuda.device(self.p.device):
+            check(lib.mt_adam_clip_step(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), self.p.numel(), self.lr, self.betas[0],
+                                        self.betas[1], self.eps, self.wd, self.max_norm, self.t, ptr(self.stats), ptr(self.ws),
+                                        self.ws.numel(), _lib.stream_ptr()), "mt_adam_clip_step")
+        return self.stats

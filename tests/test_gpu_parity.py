@@ -260,3 +260,32 @@ def test_main_cli_end_to_end(mta, tmp_path):
     ref = np.concatenate(ref, axis=1)
     assert roll.shape == ref.shape == (88, 2 * 938)
     assert (roll != ref).mean() < 5e-3 and roll.sum() > 0                   # only |logit| ~ 0 cells may flip
+
+
+# ------------------------------------------------------------------ optimizer step (training row a11)
+def test_fused_adam_clip_matches_torch(mta):
+    from music_transcription_amd.optim import FusedAdamClip, flatten_parameters
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 32, 3, 3), (64,), (2048, 300), (88, 1024), (7,)]
+    ref_params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    my_params = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_params]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-4, eps=1e-8, weight_decay=1e-5)       # scripts/train_cnn.py:290
+    flat, grads = flatten_parameters(my_params)
+    opt = FusedAdamClip(flat, grads, lr=1e-4, eps=1e-8, weight_decay=1e-5, max_norm=1.0)
+    for step in range(4):
+        scale = [5.0, 0.01, 1.0, 30.0][step]                                            # clipped and unclipped steps
+        for rp, mp in zip(ref_params, my_params):
+            gr = torch.randn(rp.shape, generator=g) * scale
+            rp.grad = gr.clone()
+            mp.grad.copy_(gr)
+        norm = torch.nn.utils.clip_grad_norm_(ref_params, 1.0)                          # train_transcriber.py:134
+        ref_opt.step()
+        st = opt.step(sync_grads=False).cpu()
+        assert abs(float(st[0]) - float(norm)) < 1e-4 * float(norm) and float(st[1]) == 1.0
+        for rp, mp in zip(ref_params, my_params):
+            assert (mp.detach().cpu() - rp.detach()).abs().max().item() < 5e-7          # 1 ulp at |p| ~ 4
+    # NaN guard: a non-finite norm leaves parameters untouched (train_transcriber.py:137-142)
+    before = flat.clone()
+    my_params[0].grad[0, 0, 0, 0] = float("nan")
+    st = opt.step(sync_grads=False).cpu()
+    assert float(st[1]) == 0.0 and torch.equal(flat, before)

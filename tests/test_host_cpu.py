@@ -209,3 +209,31 @@ def test_cli_errors_like_reference(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), str(tmp_path / "a.wav"), str(tmp_path / "m.pth")],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "Error: Model file not found" in r.stdout
+
+
+DP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+import importlib.util as u
+root = sys.argv[1]
+sys.path.insert(0, root)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+import music_transcription_amd as mta
+from music_transcription_amd.optim import allreduce_mean_
+rank = dist.get_rank()
+g = torch.arange(10, dtype=torch.float32) * (rank + 1)          # rank 0: x, rank 1: 2x  -> mean 1.5x
+allreduce_mean_(g)
+assert torch.allclose(g, torch.arange(10, dtype=torch.float32) * 1.5), g
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_two_rank_gloo_gradient_mean(tmp_path, mta):
+    script = tmp_path / "dp.py"
+    script.write_text(DP_WORKER)
+    port = str(29000 + os.getpid() % 500)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
