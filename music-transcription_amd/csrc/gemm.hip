@@ -73,21 +73,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
     const int r = lane & 31, h = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;              // wave's 64x64 sub-tile
 
-    // staging: thread owns chunk (row = tid>>3 + 32*i, chunk = tid&7) of A and of W
-    const int srow = tid >> 3, sch = tid & 7;
-    const bf16_t* ag = A + (size_t)(m0 + srow) * lda + sch * 8;
-    const bf16_t* wg = W + (size_t)(n0 + srow) * ldw + sch * 8;
-    // Two register sets: the K-tile two steps ahead is in flight from global memory while the tile one step
-    // ahead (loaded during the previous iteration) is written to the other LDS buffer after this step's MFMAs.
-    uint4 pa0_0, pa0_1, pa0_2, pa0_3, pw0_0, pw0_1, pw0_2, pw0_3, pa1_0, pa1_1, pa1_2, pa1_3, pw1_0, pw1_1, pw1_2, pw1_3;   // scalars: arrays here end up in scratch
-#define MT_GLOAD1(kt, S, I)                                                 \
-    pa##S##_##I = *(const uint4*)(ag + (size_t)(kt) * BK + (size_t)(32 * (I)) * lda); \
-    pw##S##_##I = *(const uint4*)(wg + (size_t)(kt) * BK + (size_t)(32 * (I)) * ldw);
-#define MT_GLOAD(kt, S) do { MT_GLOAD1(kt, S, 0) MT_GLOAD1(kt, S, 1) MT_GLOAD1(kt, S, 2) MT_GLOAD1(kt, S, 3) } while (0)
-#define MT_SWRITE1(buf, S, I)                                               \
-    *(uint4*)(smem + (buf) * (BM + BN) * BK * 2 + (srow + 32 * (I)) * 128 + (swz(srow + 32 * (I), sch) << 4)) = pa##S##_##I; \
-    *(uint4*)(smem + (buf) * (BM + BN) * BK * 2 + BM * BK * 2 + (srow + 32 * (I)) * 128 + (swz(srow + 32 * (I), sch) << 4)) = pw##S##_##I;
-#define MT_SWRITE(buf, S) do { MT_SWRITE1(buf, S, 0) MT_SWRITE1(buf, S, 1) MT_SWRITE1(buf, S, 2) MT_SWRITE1(buf, S, 3) } while (0)
+    // Global -> LDS by LDS-DMA (global_load_lds, 16 B per lane): no staging VGPRs, no ds_write traffic (ds_write_b128
+    // runs at ~80 B/clk and would cost as many LDS cycles as the MFMAs of the step).  One wave instruction fills 8
+    // consecutive 128-B LDS rows linearly (lane -> row lane>>3, 16-B slot lane&7), so the bank swizzle is applied to
+    // the per-lane SOURCE address: LDS slot c of row r receives data chunk c ^ ((r >> 1) & 7), and fragment reads
+    // look chunk k up at slot k ^ ((r >> 1) & 7).  Wave wv stages rows [32 wv, 32 wv + 32) of both tiles.
+    typedef __attribute__((address_space(1))) const void gvoid_t;
+    typedef __attribute__((address_space(3))) void lvoid_t;
+    const int drow = lane >> 3, dslot = lane & 7;
+#define MT_DMA1(kt, buf, J)                                                                                   \
+    {                                                                                                         \
+        const int row_ = wv * 32 + (J) * 8 + drow;                                                            \
+        const int chunk_ = dslot ^ ((row_ >> 1) & 7);                                                         \
+        const bf16_t* ga_ = A + (size_t)(m0 + row_) * lda + (size_t)(kt) * BK + chunk_ * 8;                   \
+        const bf16_t* gw_ = W + (size_t)(n0 + row_) * ldw + (size_t)(kt) * BK + chunk_ * 8;                   \
+        char* la_ = smem + (buf) * (BM + BN) * BK * 2 + (wv * 32 + (J) * 8) * 128;                            \
+        __builtin_amdgcn_global_load_lds((gvoid_t*)ga_, (lvoid_t*)la_, 16, 0, 0);                             \
+        __builtin_amdgcn_global_load_lds((gvoid_t*)gw_, (lvoid_t*)(la_ + BM * BK * 2), 16, 0, 0);             \
+    }
+#define MT_DMA(kt, buf) do { MT_DMA1(kt, buf, 0) MT_DMA1(kt, buf, 1) MT_DMA1(kt, buf, 2) MT_DMA1(kt, buf, 3) } while (0)
 #define MT_KSTEP(as, ws, ks)                                                \
     {                                                                       \
         const int rowa0 = wm * 64 + r, rowa1 = rowa0 + 32, roww0 = wn * 64 + r, roww1 = roww0 + 32; \
@@ -123,27 +127,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int nk = K / BK;
-    MT_GLOAD(0, 0);
-    MT_SWRITE(0, 0);
-    if (nk > 1) MT_GLOAD(1, 1);
-    __syncthreads();
-    // iteration kt: tile kt is in LDS buf kt&1, tile kt+1 is in register set (kt+1)&1, tile kt+2 gets requested
+    MT_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 2 < nk) MT_GLOAD(kt + 2, 0);
+        // buffer 1 was last read in iteration kt-1 (every wave is past that barrier): refill it while computing on 0
+        if (kt + 1 < nk) MT_DMA(kt + 1, 1);
         MT_COMPUTE(0);
-        if (kt + 1 < nk) MT_SWRITE(1, 1);
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // my DMA pieces have landed, my fragment reads are done
+        __builtin_amdgcn_s_barrier();
         if (kt + 1 < nk) {
-            if (kt + 3 < nk) MT_GLOAD(kt + 3, 1);
+            if (kt + 2 < nk) MT_DMA(kt + 2, 0);
             MT_COMPUTE(1);
-            if (kt + 2 < nk) MT_SWRITE(0, 0);
-            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
     }
-#undef MT_GLOAD
-#undef MT_GLOAD1
-#undef MT_SWRITE
-#undef MT_SWRITE1
+#undef MT_DMA
+#undef MT_DMA1
 #undef MT_COMPUTE
 #undef MT_KSTEP
 
