@@ -71,75 +71,103 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
 // and the folded weights [64 co][288 + 8 pad] bf16 (592-B row stride: conflict-free B-fragment reads).
 constexpr int C2_TF = 16, C2_TT = 16;                 // pooled rows, frames per tile
 constexpr int C2_ROWS = 2 * C2_TF + 2, C2_PITCH = 20; // input tile rows, positions per row
-constexpr int C2_IN_BYTES = C2_ROWS * C2_PITCH * 64;
-constexpr int C2_WSTRIDE = 296;                       // bf16 elements per co row in LDS
-constexpr int C2_W_BYTES = 64 * C2_WSTRIDE * 2;
 
-__global__ __launch_bounds__(256) void conv2_kernel(const bf16_t* __restrict__ act1, const bf16_t* __restrict__ w2 /*[64][9][32]*/,
-                                                    const float* __restrict__ bias /*[64]*/, bf16_t* __restrict__ X0,
-                                                    int B, int F1, int T, int Fo2, int ldx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* in_s = smem;
-    char* w_s = smem + C2_IN_BYTES;
+// Persistent: a workgroup walks tiles (b, 16 pooled rows, 16 frames); its waves keep the folded weights of their
+// 32 output channels in registers as MFMA B-fragments for the whole kernel (18 K-steps x 4 VGPRs), so the only
+// per-tile traffic is the 43 KB input tile, brought in by LDS-DMA through a buffer descriptor over the chunk's
+// activation (out-of-image positions read as zero through the hardware range check: no zero-fill code), and the
+// next tile's DMA is issued before this tile's epilogue stores.
+constexpr int C2_DMA_INSTRS = (C2_ROWS * C2_PITCH * 4 + 63) / 64;          // 64 x 16-B pieces per wave instruction
+constexpr int C2_LDS_BYTES = C2_DMA_INSTRS * 1024;
+
+__global__ __launch_bounds__(256, 2) void conv2_kernel(const bf16_t* __restrict__ act1, const bf16_t* __restrict__ w2 /*[64][9][32]*/,
+                                                       const float* __restrict__ bias /*[64]*/, bf16_t* __restrict__ X0,
+                                                       int B, int F1, int T, int Fo2, int ldx, int tiles_f, int tiles_t) {
+    extern __shared__ __attribute__((aligned(16))) char in_s[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int t0 = blockIdx.x * C2_TT, fo0 = blockIdx.y * C2_TF, b = blockIdx.z;
-    const int f_base = 2 * fo0 - 1;                   // input row of tile row 0
-    // ---- stage weights: 64 rows x 36 chunks of 16 B
-    for (int id = tid; id < 64 * 36; id += 256) {
-        const int co = id / 36, ch = id % 36;
-        *(uint4*)(w_s + co * (C2_WSTRIDE * 2) + ch * 16) = *(const uint4*)(w2 + (size_t)co * 288 + ch * 8);
-    }
-    // ---- stage input tile: 34 rows x 18 cols x 4 chunks, zero outside the image
-    for (int id = tid; id < C2_ROWS * 18 * 4; id += 256) {
-        const int ch = id & 3, pos = id >> 2, col = pos % 18, row = pos / 18;
-        const int f = f_base + row, t = t0 - 1 + col;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (f >= 0 && f < F1 && t >= 0 && t < T) v = *(const uint4*)(act1 + (((size_t)b * F1 + f) * T + t) * 32 + ch * 8);
-        *(uint4*)(in_s + (row * C2_PITCH + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = v;
-    }
-    __syncthreads();
-
     const int ntile = wv & 1, mgrp = wv >> 1;         // wave: 32 channels x 8 pooled rows
     const int r = lane & 31, h = lane >> 5;
     const int t_l = r & 15, fbit = r >> 4;
-    f32x16 acc[8];
+    const int co = ntile * 32 + r;
+    const float bv = bias[co];
+    bf16x8 wf[18];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
+    for (int ks = 0; ks < 18; ++ks) wf[ks] = *(const bf16x8*)(w2 + (size_t)co * 288 + ks * 16 + h * 8);
 
+    const int n_tiles = B * tiles_f * tiles_t;
+    typedef __attribute__((address_space(3))) void lvoid_t;
+#define C2_ISSUE_DMA(TILE)                                                                                     \
+    do {                                                                                                       \
+        const int tile_ = (TILE);                                                                              \
+        if (tile_ < n_tiles) {                                                                                 \
+            const int b_ = tile_ / (tiles_f * tiles_t), rem_ = tile_ - b_ * tiles_f * tiles_t;                 \
+            const int fy_ = rem_ / tiles_t, tx_ = rem_ - fy_ * tiles_t;                                        \
+            const int fb_ = 2 * fy_ * C2_TF - 1, tb_ = tx_ * C2_TT - 1;                                        \
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                              \
+                (void*)(act1 + (size_t)b_ * F1 * T * 32), 0, F1 * T * 64, 0x00020000);                         \
+            for (int q_ = wv; q_ < C2_DMA_INSTRS; q_ += 4) {                                                   \
+                const int p_ = q_ * 64 + lane, pos_ = p_ >> 2, slot_ = p_ & 3;                                 \
+                const int row_ = pos_ / C2_PITCH, col_ = pos_ - row_ * C2_PITCH;                               \
+                const int f_ = fb_ + row_, t_ = tb_ + col_;                                                    \
+                const bool ok_ = row_ < C2_ROWS && col_ < 18 && f_ >= 0 && f_ < F1 && t_ >= 0 && t_ < T;       \
+                const int off_ = ok_ ? ((f_ * T + t_) * 64 + ((slot_ ^ ((col_ >> 2) & 3)) << 4)) : 0x7fffffff; \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_, (lvoid_t*)(in_s + q_ * 1024), 16, off_, 0, 0, 0); \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+
+    C2_ISSUE_DMA(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / (tiles_f * tiles_t), rem = tile - b * tiles_f * tiles_t;
+        const int fy = rem / tiles_t, tx = rem - fy * tiles_t;
+        const int t0 = tx * C2_TT, fo0 = fy * C2_TF;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my DMA pieces (and earlier stores) are done
+        __builtin_amdgcn_s_barrier();                          // ... and so are everyone else's: the tile is in LDS
+        // two passes of 4 pooled rows each keep the accumulators at 64 VGPRs next to the 72 weight VGPRs
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            f32x16 acc[4];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int kh = tap / 3, kw = tap % 3;
-        const int col = t_l + kw;
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8 bfrag = *(const bf16x8*)(w_s + (ntile * 32 + r) * (C2_WSTRIDE * 2) + (tap * 32 + s2 * 16 + h * 8) * 2);
-            const int chunk = (s2 * 2 + h) ^ ((col >> 2) & 3);
+                for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int row = 2 * (mgrp * 8 + mi) + fbit + kh;
-                const bf16x8 afrag = *(const bf16x8*)(in_s + (row * C2_PITCH + col) * 64 + (chunk << 4));
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[mi], 0, 0, 0);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kh = tap / 3, kw = tap % 3;
+                const int col = t_l + kw;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int chunk = (s2 * 2 + h) ^ ((col >> 2) & 3);
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int row = 2 * (mgrp * 8 + half * 4 + mi) + fbit + kh;
+                        const bf16x8 afrag = *(const bf16x8*)(in_s + (row * C2_PITCH + col) * 64 + (chunk << 4));
+                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, wf[tap * 2 + s2], acc[mi], 0, 0, 0);
+                    }
+                }
+            }
+            if (half == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                  // every wave has read the tile: LDS may be refilled
+                C2_ISSUE_DMA(tile + gridDim.x);
+            }
+            // ---- epilogue: + folded bias, MaxPool over the f pair, ReLU, bf16, X0[(t*B+b)][fo*64+co]
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int fo = fo0 + mgrp * 8 + half * 4 + mi;
+                if (fo >= Fo2) continue;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int tl = p + 8 * q + 4 * h, t = t0 + tl;
+                        const float v = fmaxf(fmaxf(acc[mi][4 * q + p], acc[mi][4 * (q + 2) + p]) + bv, 0.0f);
+                        if (t < T) X0[((size_t)t * B + b) * ldx + fo * 64 + co] = f32_to_bf16(v);
+                    }
             }
         }
     }
-    // ---- epilogue: + folded bias, MaxPool over the f pair, ReLU, bf16, X0[(t*B+b)][fo*64+co]
-    const int co = ntile * 32 + r;
-    const float bv = bias[co];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int fo = fo0 + mgrp * 8 + mi;
-        if (fo >= Fo2) continue;
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int tl = p + 8 * q + 4 * h, t = t0 + tl;
-                const float v = fmaxf(fmaxf(acc[mi][4 * q + p], acc[mi][4 * (q + 2) + p]) + bv, 0.0f);
-                if (t < T) X0[((size_t)t * B + b) * ldx + fo * 64 + co] = f32_to_bf16(v);
-            }
-    }
+#undef C2_ISSUE_DMA
 }
 
 }  // namespace mt
@@ -163,14 +191,16 @@ extern "C" int mt_conv2_bn_relu_pool(const void* act1, const void* w2, const flo
     MT_REQUIRE(act1 && w2 && bias && X0, MT_EINVAL, "mt_conv2_bn_relu_pool: null pointer");
     MT_REQUIRE(B > 0 && F1 >= 2 && T > 0 && ldx >= (F1 / 2) * 64, MT_EINVAL, "mt_conv2_bn_relu_pool: bad dims");
     const int Fo2 = F1 / 2;
+    MT_REQUIRE((size_t)F1 * T * 64 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_conv2_bn_relu_pool: chunk activation too large for one buffer descriptor");
     static bool attr_set = false;
     if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C2_IN_BYTES + C2_W_BYTES));
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
         attr_set = true;
     }
-    dim3 grid(cdiv(T, C2_TT), cdiv(Fo2, C2_TF), B);
-    hipLaunchKernelGGL(conv2_kernel, grid, dim3(256), C2_IN_BYTES + C2_W_BYTES, (hipStream_t)stream, (const bf16_t*)act1,
-                       (const bf16_t*)w2, bias, (bf16_t*)X0, B, F1, T, Fo2, ldx);
+    const int tiles_t = cdiv(T, C2_TT), tiles_f = cdiv(Fo2, C2_TF), n_tiles = B * tiles_f * tiles_t;
+    dim3 grid(n_tiles < 512 ? n_tiles : 512);          // persistent: two workgroups per CU walk the tiles
+    hipLaunchKernelGGL(conv2_kernel, grid, dim3(256), C2_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)act1,
+                       (const bf16_t*)w2, bias, (bf16_t*)X0, B, F1, T, Fo2, ldx, tiles_f, tiles_t);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
