@@ -92,32 +92,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
         __builtin_amdgcn_global_load_lds((gvoid_t*)gw_, (lvoid_t*)(la_ + BM * BK * 2), 16, 0, 0);             \
     }
 #define MT_DMA(kt, buf) do { MT_DMA1(kt, buf, 0) MT_DMA1(kt, buf, 1) MT_DMA1(kt, buf, 2) MT_DMA1(kt, buf, 3) } while (0)
-#define MT_KSTEP(as, ws, ks)                                                \
-    {                                                                       \
-        const int rowa0 = wm * 64 + r, rowa1 = rowa0 + 32, roww0 = wn * 64 + r, roww1 = roww0 + 32; \
-        const bf16x8 fa0 = *(const bf16x8*)((as) + rowa0 * 128 + (swz(rowa0, (ks) * 2 + h) << 4)); \
-        const bf16x8 fa1 = *(const bf16x8*)((as) + rowa1 * 128 + (swz(rowa1, (ks) * 2 + h) << 4)); \
-        const bf16x8 fb0 = *(const bf16x8*)((ws) + roww0 * 128 + (swz(roww0, (ks) * 2 + h) << 4)); \
-        const bf16x8 fb1 = *(const bf16x8*)((ws) + roww1 * 128 + (swz(roww1, (ks) * 2 + h) << 4)); \
-        if (SWAP) {                                                         \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0, fa0, acc[0][0], 0, 0, 0); \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1, fa0, acc[0][1], 0, 0, 0); \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0, fa1, acc[1][0], 0, 0, 0); \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1, fa1, acc[1][1], 0, 0, 0); \
-        } else {                                                            \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0); \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0); \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0); \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0); \
-        }                                                                   \
+    // Fragment reads are software-pipelined by hand: the reads of k-substep ks+1 are issued BEFORE the MFMAs of ks
+    // (two named fragment sets), so a wave's LDS latency hides under its own MFMAs instead of only under the other
+    // wave of the SIMD (left alone, hipcc reuses one register set: 4 reads -> lgkmcnt(0) -> 4 MFMAs, serialised).
+#define MT_FRAG_READ(S, as, ws, ks)                                                                            \
+    fa0##S = *(const bf16x8*)((as) + rowa0 * 128 + (swz(rowa0, (ks) * 2 + h) << 4));                           \
+    fa1##S = *(const bf16x8*)((as) + rowa1 * 128 + (swz(rowa1, (ks) * 2 + h) << 4));                           \
+    fb0##S = *(const bf16x8*)((ws) + roww0 * 128 + (swz(roww0, (ks) * 2 + h) << 4));                           \
+    fb1##S = *(const bf16x8*)((ws) + roww1 * 128 + (swz(roww1, (ks) * 2 + h) << 4));
+#define MT_MFMA4(S)                                                                                            \
+    if (SWAP) {                                                                                                \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0##S, fa0##S, acc[0][0], 0, 0, 0);               \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1##S, fa0##S, acc[0][1], 0, 0, 0);               \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0##S, fa1##S, acc[1][0], 0, 0, 0);               \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1##S, fa1##S, acc[1][1], 0, 0, 0);               \
+    } else {                                                                                                   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0##S, fb0##S, acc[0][0], 0, 0, 0);               \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0##S, fb1##S, acc[0][1], 0, 0, 0);               \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1##S, fb0##S, acc[1][0], 0, 0, 0);               \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1##S, fb1##S, acc[1][1], 0, 0, 0);               \
     }
 #define MT_COMPUTE(buf)                                                     \
     do {                                                                    \
         const char* as = smem + (buf) * (BM + BN) * BK * 2;                 \
         const char* ws = as + BM * BK * 2;                                  \
-        MT_KSTEP(as, ws, 0) MT_KSTEP(as, ws, 1) MT_KSTEP(as, ws, 2) MT_KSTEP(as, ws, 3) \
+        bf16x8 fa0A, fa1A, fb0A, fb1A, fa0B, fa1B, fb0B, fb1B;              \
+        MT_FRAG_READ(A, as, ws, 0)                                          \
+        MT_FRAG_READ(B, as, ws, 1)                                          \
+        __builtin_amdgcn_sched_barrier(0);   /* pin: reads of ks+1 stay ahead of the MFMAs of ks */ \
+        MT_MFMA4(A)                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        MT_FRAG_READ(A, as, ws, 2)                                          \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        MT_MFMA4(B)                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        MT_FRAG_READ(B, as, ws, 3)                                          \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        MT_MFMA4(A)                                                         \
+        MT_MFMA4(B)                                                         \
     } while (0)
 
+    const int rowa0 = wm * 64 + r, rowa1 = rowa0 + 32, roww0 = wn * 64 + r, roww1 = roww0 + 32;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -146,7 +161,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
 #undef MT_DMA
 #undef MT_DMA1
 #undef MT_COMPUTE
-#undef MT_KSTEP
+#undef MT_FRAG_READ
+#undef MT_MFMA4
 
     // ---- epilogue.  acc[i][j]: M sub-tile i, N sub-tile j.  Unswapped: lane column = n, register rows = m.
     //      Swapped: lane column = m, register rows = n.
