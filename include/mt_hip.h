@@ -242,6 +242,11 @@ int    mt_predict_threshold(const float* logits, float* roll, long long n, float
 /* counts[b] = {TP, FP, FN} (uint64) over the first lengths[b] frames (evaluate.py:361-373). */
 int    mt_f1_counts(const float* pred, const float* target, const long long* lengths,
                     unsigned long long* counts, int B, int P, int T, mt_stream_t stream);
+/* counts[b][k] = {TP, FP, FN} of (sigmoid(logits) > thresholds[k]) for K <= 16 thresholds in one pass:
+ * the data side of evaluate.py's threshold tuning (:524-618) without re-running the model.          */
+int    mt_f1_sweep_counts(const float* logits, const float* target, const long long* lengths,
+                          const float* thresholds, int K, unsigned long long* counts, int B, int P, int T,
+                          mt_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer step (training)
  * clip_grad_norm_(max_norm) + torch.optim.Adam with coupled L2 weight decay over flat f32 buffers

@@ -106,6 +106,7 @@ _SIGS = {
     "mt_onset_offset_targets": (i32, [vp, vp, vp, C.c_longlong, i32, vp]),
     "mt_predict_threshold": (i32, [vp, vp, C.c_longlong, C.c_float, vp]),
     "mt_f1_counts": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mt_f1_sweep_counts": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
     "mt_cnnrnn_workspace_bytes": (sz, [C.POINTER(CnnRnnWeights), i32, i32]),
     "mt_cnnrnn_status_offset": (sz, [C.POINTER(CnnRnnWeights), i32, i32, i32]),
     "mt_cnnrnn_forward": (i32, [C.POINTER(CnnRnnWeights), vp, vp, i32, i32, vp, vp, sz, vp]),

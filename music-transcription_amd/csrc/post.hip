@@ -87,6 +87,42 @@ __global__ void f1_counts_kernel(const float* __restrict__ pred, const float* __
     }
 }
 
+// counts[b][k] = {TP, FP, FN} at threshold thr[k] for every k in ONE pass over the logits (the reference re-runs the
+// whole model per threshold, evaluate.py:524-553).  K <= 16 thresholds per launch; counters live in registers.
+constexpr int F1_MAXK = 16;
+__global__ void f1_sweep_kernel(const float* __restrict__ logits, const float* __restrict__ target, const long long* __restrict__ lengths,
+                                const float* __restrict__ thr, int K, unsigned long long* __restrict__ counts, int P, int T) {
+    const int b = blockIdx.y;
+    const int L = lengths ? (int)min((long long)T, max(0ll, lengths[b])) : T;
+    unsigned tp[F1_MAXK], fp[F1_MAXK], fn[F1_MAXK];
+    float th[F1_MAXK];
+#pragma unroll
+    for (int k = 0; k < F1_MAXK; ++k) { tp[k] = fp[k] = fn[k] = 0; th[k] = k < K ? thr[k] : 2.0f; }
+    const size_t base = (size_t)b * P * T;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)P * T; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = i % T;
+        if (t >= L) continue;
+        const float pr = 1.0f / (1.0f + expf(-logits[base + i]));       // same expression as predict_kernel
+        const bool yt = target[base + i] > 0.5f;
+#pragma unroll
+        for (int k = 0; k < F1_MAXK; ++k) {
+            const bool yp = pr > th[k];
+            tp[k] += (yp && yt); fp[k] += (yp && !yt); fn[k] += (!yp && yt);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < F1_MAXK; ++k) {
+        unsigned a = tp[k], c = fp[k], d = fn[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); c += __shfl_xor(c, o); d += __shfl_xor(d, o); }
+        if ((threadIdx.x & 63) == 0 && k < K) {
+            atomicAdd(counts + ((size_t)b * K + k) * 3 + 0, (unsigned long long)a);
+            atomicAdd(counts + ((size_t)b * K + k) * 3 + 1, (unsigned long long)c);
+            atomicAdd(counts + ((size_t)b * K + k) * 3 + 2, (unsigned long long)d);
+        }
+    }
+}
+
 }  // namespace mt
 
 using namespace mt;
@@ -136,6 +172,17 @@ extern "C" int mt_f1_counts(const float* pred, const float* target, const long l
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * 3 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(f1_counts_kernel, dim3(8, B), dim3(256), 0, st, pred, target, lengths, counts, P, T);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_f1_sweep_counts(const float* logits, const float* target, const long long* lengths, const float* thresholds, int K,
+                                  unsigned long long* counts, int B, int P, int T, mt_stream_t stream) {
+    MT_REQUIRE(logits && target && thresholds && counts && B > 0 && P > 0 && T > 0 && K >= 1 && K <= F1_MAXK, MT_EINVAL,
+               "mt_f1_sweep_counts: bad arguments (1 <= K <= %d)", F1_MAXK);
+    hipStream_t st = (hipStream_t)stream;
+    MT_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * K * 3 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(f1_sweep_kernel, dim3(8, B), dim3(256), 0, st, logits, target, lengths, thresholds, K, counts, P, T);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: offline transcription of a whole corpus (MAESTRO-test sized: ~177 recordings, ~20 h),
+recordings sharded over the GPUs of one node, end-to-end wall-clock + framewise F1.
+
+    python scripts/transcribe_corpus.py [--wav-dir DIR | --synthetic 177 --hours 20] [--model CKPT.pth]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 scripts/transcribe_corpus.py ...
+
+One process per GPU; recordings are assigned longest-first (LPT) so ranks finish together; there is NO data-path
+collective: every rank runs chunk -> mel -> model -> threshold on its own recordings; one small all-reduce gathers the
+per-recording F1 values at the end.  With --wav-dir, `<name>.wav` is transcribed and, if `<name>.roll.npy`
+((88, T_total) {0,1}) exists, scored against it.  Without data (no MAESTRO in this image) --synthetic draws
+recording durations to the requested total, synthesises noise + decaying tones on the GPU and scores against random
+rolls: that exercises the whole path and gives throughput, the F1 is then meaningless.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--wav-dir")
+    ap.add_argument("--synthetic", type=int, default=177)
+    ap.add_argument("--hours", type=float, default=20.0)
+    ap.add_argument("--model")
+    ap.add_argument("--model-type", default="cnn_rnn_large")
+    ap.add_argument("--n-mels", type=int, default=320)
+    ap.add_argument("--hidden-size", type=int, default=512)
+    ap.add_argument("--num-layers", type=int, default=3)
+    ap.add_argument("--threshold", type=float, default=0.5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    backend = os.environ.get("MT_BENCH_BACKEND", "nccl")
+    dev_index = local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = f"cuda:{dev_index}"
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    import music_transcription_amd as mta
+    from music_transcription_amd import transcribe as tr
+    from music_transcription_amd.parallel import lpt_assign, gather_values
+    SR, CH = 16000, 480000
+
+    model = mta.TranscriptionModel(args.model_type, n_mels=args.n_mels, hidden_size=args.hidden_size, num_layers=args.num_layers, device=dev)
+    if args.model:
+        model.load_state_dict(torch.load(args.model, map_location=dev))
+    else:                                   # no checkpoint in this image: seeded random weights, same on every rank
+        torch.manual_seed(1234)
+        for p in model.parameters():
+            if p.dim() > 1:
+                torch.nn.init.uniform_(p, -0.05, 0.05)
+    model.eval()
+
+    if args.wav_dir:
+        names = sorted(f[:-4] for f in os.listdir(args.wav_dir) if f.endswith(".wav"))
+        durations = [os.path.getsize(os.path.join(args.wav_dir, n + ".wav")) for n in names]      # bytes ~ duration
+    else:
+        rng = np.random.default_rng(args.seed)
+        raw = rng.gamma(2.5, 1.0, size=args.synthetic)
+        durations = list(raw / raw.sum() * args.hours * 3600.0)                                    # seconds, MAESTRO-like spread
+        names = [f"synthetic_{i:03d}" for i in range(args.synthetic)]
+    mine = lpt_assign(durations, world)[rank]
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    f1s, n_chunks = [], 0
+    for i in mine:
+        if args.wav_dir:
+            y = tr.load_audio(os.path.join(args.wav_dir, names[i] + ".wav"), SR)
+            chunks, _ = tr.split_into_chunks(y)
+            chunks_t = torch.from_numpy(chunks)
+        else:                               # synthesise on the GPU: noise + a few decaying partials, clipped
+            n = int(durations[i] * SR)
+            g = torch.Generator(device=dev).manual_seed(args.seed * 100003 + i)
+            nch = max(1, -(-n // CH))
+            t = torch.arange(nch * CH, device=dev, dtype=torch.float32) / SR
+            y = 0.1 * torch.randn(nch * CH, device=dev, generator=g)
+            for k in range(4):
+                f0 = 27.5 * 2.0 ** (float(torch.randint(0, 88, (1,), device=dev, generator=g)) / 12.0)
+                y += 0.3 * torch.exp(-((t * (0.5 + k)) % 3.0)) * torch.sin(2 * torch.pi * f0 * t)
+            y[n:] = 0.0                     # zero-pad the last chunk in the waveform domain (main.py:93-95)
+            chunks_t = y.clamp_(-1, 1).view(nch, CH)
+        rolls = []
+        with torch.no_grad():
+            fe = mta.get_frontend(SR, args.n_mels, 512, dev)
+            for s in range(0, chunks_t.shape[0], args.batch):
+                wave = chunks_t[s:s + args.batch].to(dev)
+                mel, cmax = fe(wave, clamp=False)
+                logits = model.model(mel, chunk_max_power=cmax)
+                rolls.append(mta.predict_from_logits(logits, args.threshold))
+        roll = torch.cat(rolls).permute(1, 0, 2).reshape(88, -1)                                    # (88, T_total)
+        n_chunks += chunks_t.shape[0]
+        ref_path = os.path.join(args.wav_dir, names[i] + ".roll.npy") if args.wav_dir else None
+        if ref_path and os.path.exists(ref_path):
+            ref = torch.from_numpy(np.load(ref_path)).float().to(dev)
+        else:
+            ref = (torch.rand(roll.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(i)) < 0.04).float()
+        L = min(ref.shape[1], roll.shape[1])
+        f1s.append(mta.framewise_f1(roll[None, :, :L].contiguous(), ref[None, :, :L].contiguous())[0])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    allf1 = gather_values(mine, f1s, len(names))
+    tot_chunks = gather_values([rank], [float(n_chunks)], world)
+    if rank == 0:
+        print(json.dumps({"workload": "offline corpus transcription (BASELINE.json configs[4])", "recordings": len(names),
+                          "audio_hours": round(sum(durations) / 3600.0, 2) if not args.wav_dir else None, "n_gpus": world,
+                          "chunks": int(sum(tot_chunks)), "wall_s": round(wall, 3), "chunks_per_s": round(sum(tot_chunks) / wall, 1),
+                          "mean_f1": float(np.mean(allf1)), "model": args.model_type, "data": "wav" if args.wav_dir else "synthetic"}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -289,3 +289,44 @@ def test_fused_adam_clip_matches_torch(mta):
     my_params[0].grad[0, 0, 0, 0] = float("nan")
     st = opt.step(sync_grads=False).cpu()
     assert float(st[1]) == 0.0 and torch.equal(flat, before)
+
+
+# ------------------------------------------------------------------ evaluation loop + one-pass threshold sweep
+def test_evaluate_and_tune_threshold(mta, tmp_path):
+    from music_transcription_amd import evaluate as ev
+    nm, hs, nl = 32, 16, 1
+    sd = R.make_state_dict("cnn_rnn", nm, hs, nl, seed=4)
+    sd["model.fc.bias"] += 0.3
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(1)
+    cache = str(tmp_path / "cache")
+    Ts = [60, 60, 45, 60, 45]
+    for i, T in enumerate(Ts):
+        mel = _mel_in(1, nm, T, 50 + i)[0]
+        with torch.no_grad():
+            ref_logits = R.cnnrnn_forward(sd, mel[None])[0]
+        roll = ((ref_logits + 0.3 * torch.randn(88, T, generator=g)) > 0.1).float()     # correlated labels
+        mta.write_cache_chunk(cache, "test", i, mel, roll)
+    mta.write_cache_metadata(cache, "test", [{} for _ in Ts], n_mels=nm)
+    ds = mta.CachedMaestroDataset(cache, "test")
+    mean_f1, per = ev.evaluate_dataset(model, ds, threshold=0.5)
+    # reference semantics on the CPU oracle: batch 1, sigmoid > t, sklearn-style F1, unweighted mean
+    want = []
+    for i in range(len(ds)):
+        mel, roll = ds[i]
+        with torch.no_grad():
+            pred = R.predict(R.cnnrnn_forward(sd, mel[None]), 0.5)[0]
+        want.append(R.f1_binary(roll, pred))
+    assert np.allclose(per, want, atol=2e-2) and abs(mean_f1 - np.mean(want)) < 1e-2   # only |logit| ~ 0 cells can flip
+    # one-pass sweep == per-threshold predict + F1 on the same logits (exact)
+    lr = ev.collect_logits(model, ds, range(len(ds)))
+    ths = [0.05, 0.3, 0.5, 0.7, 0.95]
+    sweep = ev.f1_at_thresholds(lr, ths)
+    for n, (_, lg, roll) in enumerate(lr):
+        for k, t in enumerate(ths):
+            direct = mta.framewise_f1(mta.predict_from_logits(lg[None], t), roll[None])[0]
+            assert abs(sweep[n, k] - direct) < 1e-12
+    best_t, best_f1 = ev.tune_threshold(model, ds, log=None)
+    grid = ev.f1_at_thresholds(lr, np.arange(0.01, 0.995, 0.005)).mean(0)
+    assert best_f1 >= grid.max() - 5e-3 and 0.01 <= best_t <= 0.99                       # coarse-to-fine finds the plateau
