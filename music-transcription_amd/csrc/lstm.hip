@@ -294,6 +294,181 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
 #endif
 }
 
+// XCD-local variant with FATTER workgroups: 16 hidden units (64 gate rows = two MFMA M-tiles) per workgroup, so a
+// (direction, batch group) lane has H/16 workgroups, all on one XCD, and that XCD's L2 carries half the all-gather
+// copies (the XCD-local hand-off of lstm_rec_kernel<.., true> lost at H = 512 because 64 copies of h per step went
+// through one L2).  A workgroup's 16 units are exactly one 16-wide k-step of the published layout, so it writes
+// one whole hi block and one whole lo block per step.  Everything else (row order, split-precision product,
+// poison check, bounded spins) is as in lstm_rec_kernel.
+template <int NKSW>
+__global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4][32][64];       // [k-slice wave][M-tile*16 + reg][lane]
+    __shared__ __attribute__((aligned(16))) bf16_t hs[2][64][8];        // [hi|lo][(unit>>3)*32 + batch][unit & 7]
+    __shared__ int abort_s;
+    __shared__ int ident_s[2];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int H = a.H, T = a.T, nkb = H >> 3, nks = H >> 4, nwg = H >> 4;
+    if (tid == 0) {
+        const int xcc = __builtin_amdgcn_s_getreg(20 /*HW_REG_XCC_ID*/ | (0 << 6) | ((4 - 1) << 11));
+        const int ln = (xcc - a.xcd_off) & 7;
+        ident_s[0] = ln;
+        ident_s[1] = ln < a.nlanes ? (int)__hip_atomic_fetch_add(a.tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+        abort_s = 0;
+    }
+    __syncthreads();
+    const int ln = ident_s[0], wg = ident_s[1];
+    if (ln >= a.nlanes || wg >= nwg) return;
+    const int d = ln & 1, g = a.g0 + (ln >> 1);
+    const int b = lane & 31, hh = lane >> 5;
+    const int Bg = min(32, a.B - g * 32);
+
+    const int r = lane & 31, q = r >> 3, rh = (r >> 2) & 1, p = r & 3;
+    bf16x8 whi[2][NKSW], wlo[2][NKSW];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int wrow = p * H + wg * 16 + m * 8 + 2 * q + rh;
+        const float* wsrc = a.w_hh + ((size_t)d * 4 * H + wrow) * H;
+#pragma unroll
+        for (int i = 0; i < NKSW; ++i) {
+            const int ks = wv * NKSW + i;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16_t hi = 0, lo = 0;
+                if (ks < nks) split_bf16(wsrc[ks * 16 + 8 * hh + j], hi, lo);
+                whi[m][i][j] = (short)hi;
+                wlo[m][i][j] = (short)lo;
+            }
+        }
+    }
+    const int jl = 2 * wv + hh;                         // unit inside an 8-unit half (M-tile m): unit = 8m + jl
+    float c[2] = {0.0f, 0.0f};
+    const size_t gd_blocks = (size_t)T * 2 * nkb;
+    const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
+    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 1024;
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 1024), 0x00020000);
+    unsigned* flags = a.flags + ((size_t)g * 2 + d) * nkb;     // the first nwg words of the lane's flag row are used
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d ? (T - 1 - s) : s;
+        const int tprev = d ? (t + 1) : (t - 1);
+        float gxv[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float* gxp = gx_g + (((size_t)t * 2 + d) * nkb + 2 * wg + m) * 1024 + jl * 32 + b;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) gxv[m][pp] = (b < Bg) ? gxp[pp * 256] : 0.0f;
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+        if (s > 0) {
+            if (wv == 0) {
+                const unsigned* p1 = flags + (lane < nwg ? lane : nwg - 1);
+                long long t0 = 0;
+                bool ok = false;
+                for (unsigned it = 0;; ++it) {
+                    const unsigned v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned v2 = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__any(v2 != 0)) break;
+                    if (__all(v1 >= (unsigned)s)) { ok = true; break; }
+                    if ((it & 255u) == 255u) {
+                        const long long now = __builtin_amdgcn_s_memrealtime();
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > LSTM_SPIN_LIMIT_TICKS) {
+                            if (lane == 0) __hip_atomic_store(a.status, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                if (!ok && lane == 0) abort_s = 1;
+            }
+            __syncthreads();
+            if (abort_s) return;
+            const int hbase = ((tprev * 2 + d) * nkb) * 1024 + lane * 16;
+            long long t1 = 0;
+            for (unsigned it = 0;; ++it) {
+                typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+                u32x4 rhi[NKSW], rlo[NKSW];
+#pragma unroll
+                for (int i = 0; i < NKSW; ++i) {
+                    const int ks = wv * NKSW + i;
+                    if (ks < nks) {
+                        rhi[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 2048, 0, 16 /*sc1: bypass L1, served by this XCD's L2*/);
+                        rlo[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 2048 + 1024, 0, 16);
+                    } else {
+                        rhi[i] = u32x4{0, 0, 0, 0};
+                        rlo[i] = u32x4{0, 0, 0, 0};
+                    }
+                }
+                unsigned worst = 0;
+#pragma unroll
+                for (int i = 0; i < NKSW; ++i) {
+                    worst = max(max(worst, max(rhi[i][0], rhi[i][1])), max(rhi[i][2], rhi[i][3]));
+                    worst = max(max(worst, max(rlo[i][0], rlo[i][1])), max(rlo[i][2], rlo[i][3]));
+                    const bf16x8 hhi = __builtin_bit_cast(bf16x8, rhi[i]), hlo = __builtin_bit_cast(bf16x8, rlo[i]);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[m][i], hhi, acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[m][i], hlo, acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[m][i], hhi, acc[m], 0, 0, 0);
+                    }
+                }
+                if (!__any(worst == H_POISON)) break;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+                if ((it & 255u) == 255u) {
+                    const long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t1 == 0) t1 = now;
+                    else if (now - t1 > LSTM_SPIN_LIMIT_TICKS) {
+                        if (lane == 0) {
+                            __hip_atomic_store(a.status, 0x40000000u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            abort_s = 1;
+                        }
+                        break;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wv][m * 16 + e][lane] = acc[m][e];
+        __syncthreads();
+        if (abort_s) return;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float pre[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int e = m * 16 + 4 * wv + pp;
+                pre[pp] = ((red[0][e][lane] + red[1][e][lane]) + (red[2][e][lane] + red[3][e][lane])) + gxv[m][pp];
+            }
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+            c[m] = fmaf(fg, c[m], ig * gg);
+            const float hval = og * tanhf_(c[m]);
+            bf16_t hi, lo;
+            split_bf16(hval, hi, lo);
+            hs[0][m * 32 + b][jl] = hi;                  // block lane = (k half = m)*32 + batch, element = unit & 7
+            hs[1][m * 32 + b][jl] = lo;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+            const u32x4 phi = *(const u32x4*)(&hs[0][lane][0]);
+            const u32x4 plo = *(const u32x4*)(&hs[1][lane][0]);
+            const int hoff = ((t * 2 + d) * nkb) * 1024 + wg * 2048 + lane * 16;
+            __builtin_amdgcn_raw_buffer_store_b128(phi, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
+            __builtin_amdgcn_raw_buffer_store_b128(plo, hrsrc, hoff + 1024, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) *(volatile unsigned*)(flags + wg) = (unsigned)(s + 1);
+        }
+    }
+}
+
 // Layer output for (g, t, d): nks blocks of 2 KB: [hi | lo][lane = (k half)*32 + batch][8 bf16], k = 16 ks + 8 half + j.
 // hx -> X[(t*B + b)][d*H + k] bf16 (next layer's GEMM A matrix) = the hi pieces (bf16(h), round-to-nearest).
 // H = layout hidden size (multiple of 16), Hv <= H = real hidden size (units >= Hv are zero padding and are
@@ -340,6 +515,12 @@ __global__ void lstm_unpack_kernel(const bf16_t* __restrict__ hx, float* __restr
         const int e = (((k >> 3) & 1) * 32 + bl) * 8 + (k & 7);
         y[id] = bf16_to_f32(blk[e]) + bf16_to_f32(blk[512 + e]);
     }
+}
+
+template <int NKSW>
+static int launch_rec16(const LstmArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((lstm_rec16_kernel<NKSW>), dim3(8 * (a.H >> 4)), dim3(256), 0, st, a);
+    return 0;
 }
 
 template <int NKSW>
@@ -403,7 +584,13 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
         a.xcd_off = xcd_local ? (int)(rotate.fetch_add(2 * n) & 7) : 0;
         if (xcd_local && g0 > 0) MT_CHECK_HIP(hipMemsetAsync((char*)sync_ws + 32, 0, 32, st));   // fresh tickets per launch
         const bool x = xcd_local != 0;
-        if (nksw <= 1) launch_rec<1>(a, n, x, st);
+        if (xcd_local == 2) {                  // XCD-local, 16 units per workgroup
+            if (nksw <= 1) launch_rec16<1>(a, st);
+            else if (nksw <= 2) launch_rec16<2>(a, st);
+            else if (nksw <= 4) launch_rec16<4>(a, st);
+            else if (nksw <= 8) launch_rec16<8>(a, st);
+            else launch_rec16<16>(a, st);
+        } else if (nksw <= 1) launch_rec<1>(a, n, x, st);
         else if (nksw <= 2) launch_rec<2>(a, n, x, st);
         else if (nksw <= 4) launch_rec<4>(a, n, x, st);
         else if (nksw <= 8) launch_rec<8>(a, n, x, st);
@@ -418,10 +605,11 @@ extern "C" int mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, 
     return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, 0, stream);
 }
 
-// mode 0: agent-scope hand-off (placement-independent); mode 1: XCD-local hand-off (see lstm_rec_kernel).
+// mode 0: agent-scope hand-off (placement-independent); mode 1: XCD-local hand-off, 8 units per workgroup
+// (see lstm_rec_kernel); mode 2: XCD-local, 16 units per workgroup (lstm_rec16_kernel).
 extern "C" int mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                                     int B, int T, int H, int mode, mt_stream_t stream) {
-    MT_REQUIRE(mode == 0 || mode == 1, MT_EINVAL, "mt_lstm_bidir_fwd_ex: mode must be 0 or 1");
+    MT_REQUIRE(mode >= 0 && mode <= 2, MT_EINVAL, "mt_lstm_bidir_fwd_ex: mode must be 0, 1 or 2");
     return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, mode, stream);
 }
 

@@ -94,7 +94,7 @@ def test_gemm_bf16(mta, M, N, K):
 
 
 # ------------------------------------------------------------------ LSTM layer (input projection + recurrence)
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,T,H,K", [(2, 20, 16, 64), (5, 33, 32, 128), (32, 40, 512, 1024), (33, 12, 256, 192), (1, 50, 64, 64),
                                      (150, 9, 64, 64)])
 def test_lstm_layer_matches_oracle(mta, B, T, H, K, mode):
