@@ -60,6 +60,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __ex
 // tanh(x) = 2 sigmoid(2x) - 1: absolute error ~1e-7 (v_exp_f32 based), saturates cleanly for |x| large
 __device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }
 constexpr unsigned H_POISON = 0xFFFFFFFFu;   // never the bit pattern of a hidden state (|h| < 1)
+#ifndef MT_FLAG_REPL
+#define MT_FLAG_REPL 8
+#endif
+constexpr int FLAG_REPL = MT_FLAG_REPL;      // replicas of every step flag (see lstm_rec_kernel)
 
 // Diagnostic build only (-DMT_LSTM_DIAG): per-phase wall-clock shares of a step, accumulated by wave 0
 // lane 0 of every workgroup into mt_lstm_diag[workgroup][phase] (10 ns ticks).  Never in the shipped build.
@@ -142,7 +146,11 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
     char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 1024;
     // buffer resource over this group's hx (all t, both d): offsets stay < 2^31
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 1024), 0x00020000);
-    unsigned* flags = a.flags + ((size_t)g * 2 + d) * nkb;
+    // step flags are kept in FLAG_REPL replicas on separate cache lines: a producer writes all replicas with one
+    // wave instruction, a consumer polls the replica kb % FLAG_REPL, so each flag line has nkb / FLAG_REPL pollers
+    // instead of nkb (loads that bypass the caches serialise at the line's home memory channel)
+    unsigned* flags_all = a.flags + ((size_t)g * 2 + d) * FLAG_REPL * nkb;
+    unsigned* flags = flags_all + (kb % FLAG_REPL) * nkb;
     if (tid == 0) abort_s = 0;
     __syncthreads();
 #ifdef MT_LSTM_DIAG
@@ -167,16 +175,17 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
             //      poll: every lane loads one flag and, in the same burst, a second flag (H > 512) or the abort word.
             if (wv == 0) {
                 const unsigned* p1 = flags + (lane < nkb ? lane : nkb - 1);
-                const unsigned* p2 = (lane + 64 < nkb) ? flags + lane + 64 : a.status;
                 const bool p2_is_flag = (lane + 64 < nkb);
+                const unsigned* p2 = p2_is_flag ? flags + lane + 64 : flags + (lane < nkb ? lane : nkb - 1);
                 long long t0 = 0;
                 bool ok = false;
                 for (unsigned it = 0;; ++it) {
                     const unsigned v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned v2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ready = (v1 >= (unsigned)s) && (!p2_is_flag || v2 >= (unsigned)s);
-                    if (__any(!p2_is_flag && v2 != 0)) break;                         // another workgroup gave up
+                    const unsigned v2 = p2_is_flag ? __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v1;
+                    const bool ready = (v1 >= (unsigned)s) && (v2 >= (unsigned)s);
                     if (__all(ready)) { ok = true; break; }
+                    // the abort word is one line polled by every workgroup of the launch: look at it only now and then
+                    if ((it & 15u) == 15u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
                     if ((it & 255u) == 255u) {
                         const long long now = __builtin_amdgcn_s_memrealtime();
                         if (t0 == 0) t0 = now;
@@ -279,9 +288,9 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
             if (XCD) __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
             else __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1: write-through*/);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pieces are in L2 / memory before the flag says so
-            if (lane == 0) {
-                if (XCD) *(volatile unsigned*)(flags + kb) = (unsigned)(s + 1);   // plain store: stays in this XCD's L2
-                else __hip_atomic_store(flags + kb, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < FLAG_REPL) {
+                if (XCD) *(volatile unsigned*)(flags_all + lane * nkb + kb) = (unsigned)(s + 1);   // plain store: stays in this XCD's L2
+                else __hip_atomic_store(flags_all + lane * nkb + kb, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         DIAG_STAMP(6);
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
     const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
     char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 1024;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 1024), 0x00020000);
-    unsigned* flags = a.flags + ((size_t)g * 2 + d) * nkb;     // the first nwg words of the lane's flag row are used
+    unsigned* flags = a.flags + ((size_t)g * 2 + d) * FLAG_REPL * nkb;   // replica 0 of the lane's flags; the first nwg words are used
 
     for (int s = 0; s < T; ++s) {
         const int t = d ? (T - 1 - s) : s;
@@ -536,7 +545,7 @@ using namespace mt;
 
 extern "C" size_t mt_lstm_gx_bytes(int B, int T, int H) { return (size_t)cdiv(B, 32) * T * 2 * (H >> 3) * 4096; }
 extern "C" size_t mt_lstm_hx_bytes(int B, int T, int H) { return (size_t)cdiv(B, 32) * T * 2 * (H >> 3) * 1024; }
-extern "C" size_t mt_lstm_sync_bytes(int B, int H) { return align_up(64 + (size_t)cdiv(B, 32) * 2 * (H >> 3) * 4, 16); }
+extern "C" size_t mt_lstm_sync_bytes(int B, int H) { return align_up(256 + (size_t)cdiv(B, 32) * 2 * FLAG_REPL * (H >> 3) * 4, 256); }
 
 // One bidirectional LSTM layer's recurrence.  gx from mt_gemm_lstm_gx, w_hh = [fwd; reverse] (2 x 4H x H f32),
 // hx receives every step's hidden state (layer output, MFMA-operand layout).  sync_ws: mt_lstm_sync_bytes().
@@ -570,7 +579,8 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
     MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
-    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 64), (unsigned*)sync_ws, B, T, H, 0, (unsigned*)((char*)sync_ws + 32), 0, 0};
+    // sync_ws: [0] status word, [32..64) XCD tickets, [256..) flags (own cache lines, away from the polled status word)
+    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, 0, (unsigned*)((char*)sync_ws + 32), 0, 0};
     // every workgroup of a launch must be resident (they wait on each other).  Agent-scope variant: at most 256
     // workgroups (one per CU) per launch; XCD-local variant: at most 8 lanes = 4 batch groups per launch, each lane's
     // H/8 workgroups share one XCD (H/8 <= 128 -> at most 4 per CU).  Further groups run as further launches.
