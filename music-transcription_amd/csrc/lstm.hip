@@ -25,17 +25,20 @@
 //   * the published blocks of ALL steps are kept: they are the layer's output, re-laid out for
 //     the next GEMM by lstm_relayout_kernel, so nothing else is stored on the critical path and
 //     no slot is ever reused (no WAR hazard between steps).
-// Hand-off (MI355X_MICROARCH.md, "Valid forms", write-through row): the workgroup's 1-KB block is
-// assembled in LDS and written by ONE wave as one 16-B-per-lane sc1 (write-through) store; that
-// wave drains vmcnt(0) and its lane 0 stores the monotonic step flag (relaxed, agent scope).
-// Consumers poll the S flags of their direction with ONE wave, one memory round trip per poll
-// (flags and the abort word in the same burst), workgroup barrier, then every payload load is
-// an sc1 buffer load (bypasses the per-CU L1, which is never refreshed by other CUs' stores).
-// Belt and braces: hx is filled with the poison pattern 0xFFFFFFFF (never a hidden state,
-// |h| < 1) before every launch, and a consumer that still sees a poisoned dword redoes its
-// loads -- so a flag that overtook its payload costs time, never correctness.
-// Every spin is bounded: on timeout the workgroup raises the abort word, which every other
-// workgroup's spin also watches, and all workgroups drain.
+// Hand-off.  The workgroup's 1-KB block is assembled in LDS and written by ONE wave as one 16-B-per-lane sc1
+// (write-through) store; its lanes 0..7 then store the monotonic step flag into 8 REPLICAS on separate cache
+// lines (relaxed, agent scope) -- WITHOUT draining the payload store first.  Consumers poll the replica
+// kb % 8 with ONE wave, one memory round trip per poll (all flags of the direction in one burst; the abort word
+// only every 16th poll), workgroup barrier, then every payload load is an sc1 buffer load (bypasses the per-CU L1,
+// which is never refreshed by other CUs' stores).  Two measured facts shape this:
+//   * loads that bypass the caches serialise at their line's home memory channel: with all 64 workgroups of a
+//     direction polling one flag line a step took 4.2 us, with 8 pollers per line 3.3 us (more replicas: no gain);
+//   * the flag is a HINT, not a release.  hx is filled with the poison pattern 0xFFFFFFFF (never a hidden state,
+//     |h| < 1) before every launch and a consumer that still sees a poisoned word redoes its loads: every word is
+//     written exactly once by one store, so it is either poison or final -- correctness never depends on the
+//     order in which the flag and the payload become visible.  Dropping the drain: 3.30 -> 3.05 us/step.
+// Every spin is bounded: on timeout the workgroup raises the abort word, which every other workgroup's spin also
+// watches, and all workgroups drain.
 #include "mt_common.h"
 #include <atomic>
 
@@ -56,9 +59,10 @@ struct LstmArgs {
     int nlanes, xcd_off;  // lane l runs on the XCD with hardware id (l + xcd_off) & 7
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// tanh(x) = 2 sigmoid(2x) - 1: absolute error ~1e-7 (v_exp_f32 based), saturates cleanly for |x| large
-__device__ __forceinline__ float tanhf_(float x) { return 2.0f / (1.0f + __expf(-2.0f * x)) - 1.0f; }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): absolute error ~1e-7, saturate cleanly for |x| large
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// tanh(x) = 2 sigmoid(2x) - 1
+__device__ __forceinline__ float tanhf_(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
 constexpr unsigned H_POISON = 0xFFFFFFFFu;   // never the bit pattern of a hidden state (|h| < 1)
 #ifndef MT_FLAG_REPL
 #define MT_FLAG_REPL 8
@@ -92,7 +96,7 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
 // start-up shows a different distribution.
 template <int NKSW, bool XCD>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
 __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4][16][64];
+    __shared__ __attribute__((aligned(16))) float red[4][64][20];       // [k-slice wave][lane][16 regs + pad]: 80-B lane stride, conflict-free b128
     __shared__ __attribute__((aligned(16))) bf16_t hs[2][32][8];       // [hi|lo][batch][unit]
 #ifdef MT_LSTM_LDS_PAD
     __shared__ char lds_pad[MT_LSTM_LDS_PAD];                          // experiment: inflate the LDS footprint
@@ -252,15 +256,18 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
         DIAG_STAMP(2);
         // ---- sum the four K-slices through LDS; wave wv finishes gate rows 8wv + 4h + p
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[wv][e][lane] = acc[e];
+        for (int e4 = 0; e4 < 4; ++e4)
+            *(f32x4*)(&red[wv][lane][4 * e4]) = f32x4{acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]};
         __syncthreads();
         DIAG_STAMP(3);
         if (abort_s) return;                           // a payload spin gave up (status word says where)
         float pre[4];
+        {
+            const f32x4 r0 = *(const f32x4*)(&red[0][lane][4 * wv]), r1 = *(const f32x4*)(&red[1][lane][4 * wv]);
+            const f32x4 r2 = *(const f32x4*)(&red[2][lane][4 * wv]), r3 = *(const f32x4*)(&red[3][lane][4 * wv]);
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp)
-            pre[pp] = ((red[0][4 * wv + pp][lane] + red[1][4 * wv + pp][lane]) +
-                       (red[2][4 * wv + pp][lane] + red[3][4 * wv + pp][lane])) + gxv[pp];
+            for (int pp = 0; pp < 4; ++pp) pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + gxv[pp];
+        }
         // ---- cell update (PyTorch LSTM): c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')
         const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
         c = fmaf(fg, c, ig * gg);
@@ -287,7 +294,13 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
             const int hoff = ((t * 2 + d) * nkb) * 1024 + (kb >> 1) * 2048 + hh * 1024 + ((kb & 1) * 32 + b) * 16;
             if (XCD) __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
             else __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1: write-through*/);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the pieces are in L2 / memory before the flag says so
+#ifdef MT_LSTM_DRAIN
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // classic form: the pieces have landed before the flag says so
+#endif
+            // Default: NO drain.  The flag is then only a hint that the stores were issued; a consumer that gets ahead
+            // of the payload sees the poison pattern in the words that have not landed and redoes its loads (every
+            // word is written exactly once by one store, so it is either poison or final).  Measured 3.05 vs 3.30
+            // us/step: the store round trip leaves the critical path.
             if (lane < FLAG_REPL) {
                 if (XCD) *(volatile unsigned*)(flags_all + lane * nkb + kb) = (unsigned)(s + 1);   // plain store: stays in this XCD's L2
                 else __hip_atomic_store(flags_all + lane * nkb + kb, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
