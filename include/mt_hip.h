@@ -258,6 +258,85 @@ int    mt_adam_clip_step(float* params, const float* grads, float* exp_avg, floa
                          float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                          int step, float* stats, void* workspace, size_t workspace_bytes, mt_stream_t stream);
 
+/* ------------------------------------------------------------------ training step
+ * The kernels behind `loss.backward()` of train/train_transcriber.py:130 for CNNRNNModel in train mode
+ * (cnn_rnn_model.py:29-74: BatchNorm2d with BATCH statistics, ReLU, MaxPool2d((2,1)), nn.LSTM, nn.Linear),
+ * orchestrated by music-transcription_amd/train_step.py.  Dense contractions of the backward pass reuse
+ * mt_gemm_* and mt_conv_cl_bf16 on operands these entry points lay out.  bf16 = raw uint16 bits.          */
+/* conv1 (1->32, 3x3) pre-BN statistics, recomputed from the input: sums64[c] = sum z, sums64[32+c] = sum z^2
+ * over all (b, f, t); x [B][F][T] f32, w [32][9], bias [32] (raw parameters).  Zeroes sums64 first.        */
+int    mt_conv1_stats(const float* x, const float* w, const float* bias, double* sums64, int B, int F, int T,
+                      mt_stream_t stream);
+/* sums (sum, sum of squares over `count` elements per channel) -> batch mean / rstd = 1/sqrt(var_biased+eps);
+ * running_mean/var (may be NULL) updated as nn.BatchNorm2d does (momentum, unbiased variance); optionally the
+ * conv parameters with the batch statistics folded in: w_folded = w*gamma*rstd [C][taps],
+ * b_folded = (b-mean)*gamma*rstd + beta (pass NULL to skip).                                              */
+int    mt_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
+                      float* rstd_out, int C, const float* w, const float* b, float* w_folded, float* b_folded,
+                      int taps, mt_stream_t stream);
+/* z [N][C] bf16 channels-last, C in {32,64,128,256}: sums[0..C) = sum z, sums[C..2C) = sum z^2 (zeroed first). */
+int    mt_bn_stats_cl(const void* z, long long N, int C, double* sums, mt_stream_t stream);
+/* z [B][F][T][64] bf16 (pre-BN conv2 output) -> X[(t*B+b)*ldx + fo*64 + c] bf16 = BN + ReLU + MaxPool((2,1)). */
+int    mt_bn_relu_pool_apply(const void* z, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, void* X, int ldx, int B, int F, int T, mt_stream_t stream);
+/* Backward of mt_bn_relu_pool_apply: dX f32 [(t*B+b)*ldd + fo*64 + c] -> dz [B][F][T][64] bf16, dgamma[64],
+ * dbeta[64] (may be NULL).  dz_lo (may be NULL): the bf16 rounding remainder of dz (dz ~= dz + dz_lo to 2^-17),
+ * for the cancellation-prone conv weight gradient.  sums128: 128 doubles of scratch.                       */
+int    mt_bn_pool_bwd(const float* dX, int ldd, const void* z, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, double* sums128, void* dz, void* dz_lo,
+                      float* dgamma, float* dbeta, int B, int F, int T, mt_stream_t stream);
+/* a [B][F][T][32] bf16 -> colT[(tap*32+ci)*ld + (b*F+f)*T + t] = a[b][f+kh-1][t+kw-1][ci] (zero outside),
+ * tap = kh*3+kw: the W operand of the conv2 weight-gradient GEMM (contraction over positions).             */
+int    mt_im2col_t_3x3_c32(const void* a, void* colT, long long ld, int B, int F, int T, mt_stream_t stream);
+/* dst[c*ldd + r] = src[r*lds + c] (bf16), r < R, c < C; every dst element with c < Cd, r < ldd is written
+ * (zero outside the source).                                                                               */
+int    mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd,
+                         mt_stream_t stream);
+/* dst[i0][i1][i2][i3] (contiguous) = alpha * src[i0*s0 + i1*s1 + i2*s2 + i3*s3]: GEMM-layout gradients ->
+ * the reference's parameter shapes (state_dict order).                                                     */
+int    mt_gather4_f32(const float* src, float* dst, int n0, int n1, int n2, int n3, long long s0, long long s1,
+                      long long s2, long long s3, float alpha, mt_stream_t stream);
+/* out[r*ldo + c] = sum_z P[z*stride + r*ldp + c]: reduction of split-K partial products (fixed order).     */
+int    mt_sum_slices_f32(const float* P, long long stride, int ldp, int S, float* out, int ldo, int rows,
+                         int cols, mt_stream_t stream);
+/* out[r] = sum_{c<n} A[r*ld + c] (bf16 rows): bias gradients from the transposed GEMM operands.            */
+int    mt_rowsum_bf16(const void* A, long long ld, long long n, float* out, int rows, mt_stream_t stream);
+/* conv1 + BN + ReLU + pool backward with z1 recomputed from x: da [B][F/2][T][ldc] bf16 (channels 0..31) ->
+ * dW [32][9], db [32], dgamma [32], dbeta [32].  scratch384: 384 doubles.                                  */
+int    mt_conv1_bwd(const float* x, const float* w, const float* bias, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, const void* da, int ldc, double* scratch384,
+                    float* dW, float* db, float* dgamma, float* dbeta, int B, int F, int T, mt_stream_t stream);
+/* Train-mode recurrence: as mt_lstm_bidir_fwd; additionally the ACTIVATED gates overwrite gx in place and the
+ * cell states go to cx [B/32][T][2][H/8][8][32] f32 (mt_lstm_cx_bytes).                                    */
+size_t mt_lstm_cx_bytes(int B, int T, int H);
+int    mt_lstm_bidir_fwd_train(float* gx_inout, const float* w_hh, float* hx, float* cx, void* sync_ws,
+                               size_t sync_bytes, int B, int T, int H, mt_stream_t stream);
+/* hx -> X[(t*B+b)*ldx + d*Hv + j] bf16 with nn.LSTM's inter-layer (inverted) dropout p; the mask is a
+ * counter-based hash of (seed, layer, element) that mt_lstm_dh_relayout regenerates.                       */
+int    mt_lstm_relayout_train(const float* hx, void* X, int ldx, int B, int T, int H, int Hv, float p,
+                              unsigned seed, unsigned layer, mt_stream_t stream);
+/* dX f32 [(t*B+b)*ld + d*Hv + j] (gradient of the layer output) -> dh [B/32][T][2][H/8][8][32] f32.        */
+int    mt_lstm_dh_relayout(const float* dX, int ld, float* dh, int B, int T, int H, int Hv, float p,
+                           unsigned seed, unsigned layer, mt_stream_t stream);
+/* Backward through time (both directions of one layer; persistent kernel, lstm_bwd.hip): gates/cx from
+ * mt_lstm_bidir_fwd_train, dh from mt_lstm_dh_relayout, w_hh [2][4H][H] f32 -> dgx: d(gate pre-activations)
+ * as bf16 MFMA-operand images (mt_lstm_dgx_bytes).  H % 16 == 0, H <= 512.  sync_ws: mt_lstm_sync_bytes.   */
+size_t mt_lstm_dgx_bytes(int B, int T, int H);
+int    mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx,
+                         void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream);
+/* dgx -> dG [(t*B+b)*ldg + d*4H + gate*H + j] bf16 and dGT [(d*4H + gate*H + j)*ldt + t*B + b] bf16
+ * (pre-zeroed by the caller: padded rows / columns are not written).                                       */
+int    mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, long long ldt, int B, int T, int H,
+                         mt_stream_t stream);
+/* hx -> HT[(d*rows_per_dir + k)*ld + t*B + b] = bf16 h of the forward pass's PREVIOUS step (zero at the
+ * sequence boundary): W operand of dW_hh[d] = dG_d^T . Hprev_d.                                            */
+int    mt_lstm_hprev_t(const float* hx, void* HT, long long ld, int rows_per_dir, int B, int T, int H,
+                       mt_stream_t stream);
+/* dlogits [B][P][T] f32 -> dL [(t*B+b)*128 + p] bf16 and dLT [p*ldt + t*B + b] bf16 (p < 128, zero for p >= P). */
+int    mt_dlogits_pack(const float* dlogits, void* dL, void* dLT, long long ldt, int B, int P, int T,
+                       mt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

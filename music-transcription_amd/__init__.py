@@ -10,6 +10,8 @@ from .frontend import MelFrontend, audio_to_mel, get_frontend, mel_filterbank, n
 from .model import CNNRNNModel, CNNRNNModelLarge, TranscriptionModel                          # noqa: F401
 from . import ops                                                                             # noqa: F401
 from .ops import compute_loss, framewise_f1, mean_f1, predict_from_logits                     # noqa: F401
+from .optim import FusedAdamClip, flatten_parameters, allreduce_mean_                        # noqa: F401
+from .train import make_optimizer, train_one_epoch                                            # noqa: F401  (train.evaluate = validation loss)
 from .data import CachedMaestroDataset, collate_fn, write_cache_chunk, write_cache_metadata   # noqa: F401
 
 __version__ = "0.1.0"

@@ -107,6 +107,26 @@ _SIGS = {
     "mt_predict_threshold": (i32, [vp, vp, C.c_longlong, C.c_float, vp]),
     "mt_f1_counts": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "mt_f1_sweep_counts": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
+    "mt_conv1_stats": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mt_bn_finalize": (i32, [vp, C.c_double, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, vp, vp, vp, vp, i32, vp]),
+    "mt_bn_stats_cl": (i32, [vp, ll, i32, vp, vp]),
+    "mt_bn_relu_pool_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_bn_pool_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mt_im2col_t_3x3_c32": (i32, [vp, vp, ll, i32, i32, i32, vp]),
+    "mt_transpose_bf16": (i32, [vp, ll, ll, i32, vp, ll, i32, vp]),
+    "mt_gather4_f32": (i32, [vp, vp, i32, i32, i32, i32, ll, ll, ll, ll, C.c_float, vp]),
+    "mt_sum_slices_f32": (i32, [vp, ll, i32, i32, vp, i32, i32, i32, vp]),
+    "mt_rowsum_bf16": (i32, [vp, ll, ll, vp, i32, vp]),
+    "mt_conv1_bwd": (i32, [vp] * 8 + [i32] + [vp] * 5 + [i32, i32, i32, vp]),
+    "mt_lstm_cx_bytes": (sz, [i32, i32, i32]),
+    "mt_lstm_bidir_fwd_train": (i32, [vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "mt_lstm_relayout_train": (i32, [vp, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),
+    "mt_lstm_dh_relayout": (i32, [vp, i32, vp, i32, i32, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),
+    "mt_lstm_dgx_bytes": (sz, [i32, i32, i32]),
+    "mt_lstm_bidir_bwd": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "mt_lstm_dg_unpack": (i32, [vp, vp, i32, vp, ll, i32, i32, i32, vp]),
+    "mt_lstm_hprev_t": (i32, [vp, vp, ll, i32, i32, i32, i32, vp]),
+    "mt_dlogits_pack": (i32, [vp, vp, vp, ll, i32, i32, i32, vp]),
     "mt_cnnrnn_workspace_bytes": (sz, [C.POINTER(CnnRnnWeights), i32, i32]),
     "mt_cnnrnn_status_offset": (sz, [C.POINTER(CnnRnnWeights), i32, i32, i32]),
     "mt_cnnrnn_forward": (i32, [C.POINTER(CnnRnnWeights), vp, vp, i32, i32, vp, vp, sz, vp]),

@@ -57,6 +57,9 @@ struct LstmArgs {
     // XCD-local mode (see lstm_rec_kernel): lanes = (direction, batch group) pairs of this launch,
     unsigned* tickets;    // [8] per-XCD arrival counters, zeroed before every launch
     int nlanes, xcd_off;  // lane l runs on the XCD with hardware id (l + xcd_off) & 7
+    // train mode (lstm_rec_kernel<.., TRAIN = true>): what the backward pass needs (lstm_bwd.hip)
+    float* gates_out;     // = gx: the ACTIVATED gates i, f, g, o overwrite the pre-activations in place
+    float* cx;            // [NG][T][2][NKB][8][32] cell states
 };
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): absolute error ~1e-7, saturate cleanly for |x| large
@@ -94,7 +97,7 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
 // the status word), never a stale read.  The host sizes the grid 8 x S (the dispatcher deals workgroups
 // round-robin over the 8 XCDs) and falls back to the agent-scope variant (XCD = false) if a census launch at
 // start-up shows a different distribution.
-template <int NKSW, bool XCD>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
+template <int NKSW, bool XCD, bool TRAIN = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
 __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][64][20];       // [k-slice wave][lane][16 regs + pad]: 80-B lane stride, conflict-free b128
     __shared__ __attribute__((aligned(16))) bf16_t hs[2][32][8];       // [hi|lo][batch][unit]
@@ -272,6 +275,11 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
         const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
         c = fmaf(fg, c, ig * gg);
         const float hval = og * tanhf_(c);
+        if (TRAIN && b < Bg) {                          // saved for the backward pass (off the critical path: fire and forget)
+            float* go = a.gates_out + (size_t)g * gd_blocks * 1024 + (((size_t)t * 2 + d) * nkb + kb) * 1024 + jl * 32 + b;
+            go[0] = ig; go[256] = fg; go[512] = gg; go[768] = og;
+            a.cx[(size_t)g * gd_blocks * 256 + (((size_t)t * 2 + d) * nkb + kb) * 256 + jl * 32 + b] = c;
+        }
 #ifdef MT_LSTM_DIAG
         asm volatile("" :: "v"(hval));
 #endif
@@ -547,7 +555,8 @@ static int launch_rec16(const LstmArgs& a, hipStream_t st) {
 
 template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, bool xcd, hipStream_t st) {
-    if (xcd) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, true>), dim3(8 * (a.H >> 3)), dim3(256), 0, st, a);
+    if (a.cx) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
+    else if (xcd) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, true>), dim3(8 * (a.H >> 3)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
     return 0;
 }
@@ -582,7 +591,7 @@ extern "C" int mt_xcd_census(int* counts_host, void* scratch32, int nwg, mt_stre
 }
 
 static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
-                         int B, int T, int H, int xcd_local, mt_stream_t stream) {
+                         int B, int T, int H, int xcd_local, mt_stream_t stream, float* cx = nullptr) {
     MT_REQUIRE(gx && w_hh && hx && sync_ws, MT_EINVAL, "mt_lstm_bidir_fwd: null pointer");
     MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 1024, MT_EUNSUPPORTED,
                "mt_lstm_bidir_fwd: hidden size %d unsupported (multiple of 16, <= 1024)", H);
@@ -593,7 +602,8 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
     MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
     // sync_ws: [0] status word, [32..64) XCD tickets, [256..) flags (own cache lines, away from the polled status word)
-    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, 0, (unsigned*)((char*)sync_ws + 32), 0, 0};
+    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, 0, (unsigned*)((char*)sync_ws + 32), 0, 0,
+               cx ? const_cast<float*>(gx) : nullptr, cx};
     // every workgroup of a launch must be resident (they wait on each other).  Agent-scope variant: at most 256
     // workgroups (one per CU) per launch; XCD-local variant: at most 8 lanes = 4 batch groups per launch, each lane's
     // H/8 workgroups share one XCD (H/8 <= 128 -> at most 4 per CU).  Further groups run as further launches.
@@ -626,6 +636,14 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
 extern "C" int mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                                  int B, int T, int H, mt_stream_t stream) {
     return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, 0, stream);
+}
+
+// Train-mode forward: as mt_lstm_bidir_fwd, and additionally the activated gates overwrite gx in place and the cell
+// states go to cx (mt_lstm_cx_bytes) -- the tensors mt_lstm_bidir_bwd consumes.
+extern "C" int mt_lstm_bidir_fwd_train(float* gx_inout, const float* w_hh, float* hx, float* cx, void* sync_ws, size_t sync_bytes,
+                                       int B, int T, int H, mt_stream_t stream) {
+    MT_REQUIRE(cx, MT_EINVAL, "mt_lstm_bidir_fwd_train: null cx");
+    return lstm_fwd_impl(gx_inout, w_hh, hx, sync_ws, sync_bytes, B, T, H, 0, stream, cx);
 }
 
 // mode 0: agent-scope hand-off (placement-independent); mode 1: XCD-local hand-off, 8 units per workgroup

@@ -1,0 +1,372 @@
+// Backward pass through time of the bidirectional LSTM (the autograd half of nn.LSTM that
+// train/train_transcriber.py:130 `scaler.scale(loss).backward()` runs; forward: lstm.hip).
+//
+// Saved by the train-mode forward (lstm_rec_kernel<.., TRAIN = true>): the ACTIVATED gates i, f, g, o in the gx
+// layout [g][t][d][H/8][gate][8][32] and the cell states cx [g][t][d][H/8][8][32] (f32).  Per time step, in the
+// reverse of the forward order:
+//   dh      = dh_out[t] + W_hh^T dgates[t_next]                 (the only cross-workgroup dependency)
+//   do      = dh tanh(c_t) o (1-o);   dc = dh o (1 - tanh^2 c_t) + dc[t_next] f[t_next]
+//   di, df, dg = dc g i(1-i),  dc c_prev f(1-f),  dc i (1-g^2)
+// Decomposition mirrors the forward kernel: a (direction, batch group) is sliced over NW = ceil(H/32) persistent
+// workgroups; workgroup w owns hidden units 32w..32w+31, keeps its 32 x 4H slice of W_hh^T in registers as bf16
+// MFMA A-operands, and every step all-gathers the 4H x 32 dgates of the previous step (published by all NW
+// workgroups as bf16 MFMA B-operand images) through L2: v_mfma_f32_32x32x16_bf16, K = 4H split over the 4 waves,
+// partial tiles summed through LDS, cell math lane-local with dc carried in registers.  The published images of ALL
+// steps are kept: they are dgates for the weight-gradient and input-gradient GEMMs (re-laid out by
+// lstm_dg_unpack_kernel).  K order of the dgates vector: k = 128 w' + 32 gate + u  (producer w', unit u).
+// Hand-off: sc1 stores, drain, workgroup barrier, replicated step flags (as lstm.hip); bounded spins.
+#include "mt_common.h"
+
+namespace mt {
+
+constexpr int BPTT_SPIN_LIMIT_TICKS = 200000000;   // 2 s of the 100 MHz s_memrealtime clock
+constexpr int BW_FLAG_REPL = 8;
+
+struct LstmBwdArgs {
+    const float* gates;   // [NG][T][2][NKB][4][8][32]
+    const float* cx;      // [NG][T][2][NKB][8][32]
+    const float* dh;      // [NG][T][2][NKB][8][32]
+    const float* w_hh;    // [2][4H][H]
+    bf16_t* dgx;          // [NG][T][2][NW][8][64][8]
+    unsigned* flags;      // [NG][2][BW_FLAG_REPL][NW], zeroed before every launch
+    unsigned* status;     // abort word, zeroed before every launch
+    int B, T, H;
+};
+
+__device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
+
+template <int NKSW_MAX>
+__global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4][64][20];
+    __shared__ __attribute__((aligned(16))) bf16_t img[8][64][8];
+    __shared__ int abort_s;
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int H = a.H, T = a.T, nkb = H >> 3, NW = (H + 31) >> 5, nksw = 2 * NW;
+    const int w = blockIdx.x, d = blockIdx.y, g = blockIdx.z;
+    const int b = lane & 31, hh = lane >> 5;
+    const int Bg = min(32, a.B - g * 32);
+
+    // ---- W_hh^T slice as MFMA A-operands: lane (row r <-> unit j = 32w + r, k half hh) holds, for k-step ks,
+    //      W_hh[gate*H + 32w' + u][j] at k = 16ks + 8hh + e = 128w' + 32 gate + u
+    const int r = lane & 31, j = 32 * w + r;
+    bf16x8 wt[NKSW_MAX];
+#pragma unroll
+    for (int i = 0; i < NKSW_MAX; ++i) {
+        const int ks = wv * nksw + i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + 8 * hh + e, wp = k >> 7, kl = k & 127, p = kl >> 5, u = kl & 31, jp = 32 * wp + u;
+            float v = 0.0f;
+            if (i < nksw && jp < H && j < H) v = a.w_hh[((size_t)d * 4 * H + (size_t)p * H + jp) * H + j];
+            wt[i][e] = (short)f32_to_bf16(v);
+        }
+    }
+
+    // this thread's cells: units u = 8wv + 4hh + e (e = 0..3) of the workgroup, batch row b
+    const int kb = 4 * w + wv;
+    const bool live = (kb < nkb) && (b < Bg);
+    const size_t g_blocks = (size_t)T * 2 * nkb;
+    const float* gates_g = a.gates + g * g_blocks * 1024;
+    const float* cx_g = a.cx + g * g_blocks * 256;
+    const float* dh_g = a.dh + g * g_blocks * 256;
+    const size_t dg_bytes = (size_t)T * 2 * NW * 8 * 1024;
+    char* dgx_g = (char*)a.dgx + g * dg_bytes;
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dgx_g, 0, (int)dg_bytes, 0x00020000);
+    unsigned* flags_all = a.flags + ((size_t)g * 2 + d) * BW_FLAG_REPL * NW;
+    const unsigned* flags = flags_all + (w % BW_FLAG_REPL) * NW;
+    if (tid == 0) abort_s = 0;
+    __syncthreads();
+
+    float carry[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // dc[t_next] * f[t_next]
+    float ccur[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int s = 0; s < T; ++s) {
+        const int t = d ? s : (T - 1 - s);            // reverse of the forward processing order
+        const int tn = d ? (t - 1) : (t + 1);         // the step processed just before this one
+        const int tp = d ? (t + 1) : (t - 1);         // the forward pass's previous step (source of c_prev)
+        // ---- everything the cell math needs from the forward pass (independent of the recurrence: issued first)
+        float gt[4][4], cprev[4], dhin[4];
+        {
+            const size_t blk = ((size_t)t * 2 + d) * nkb + kb;
+            const size_t blkp = ((size_t)tp * 2 + d) * nkb + kb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int off = (4 * hh + e) * 32 + b;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) gt[p][e] = live ? gates_g[blk * 1024 + p * 256 + off] : 0.0f;
+                dhin[e] = live ? dh_g[blk * 256 + off] : 0.0f;
+                if (s == 0) ccur[e] = live ? cx_g[blk * 256 + off] : 0.0f;
+                cprev[e] = (live && tp >= 0 && tp < T) ? cx_g[blkp * 256 + off] : 0.0f;
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        if (s > 0) {
+            if (wv == 0) {
+                const unsigned* p1 = flags + (lane < NW ? lane : NW - 1);
+                long long t0 = 0;
+                bool ok = false;
+                for (unsigned it = 0;; ++it) {
+                    const unsigned v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all(v1 >= (unsigned)s)) { ok = true; break; }
+                    if ((it & 15u) == 15u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if ((it & 255u) == 255u) {
+                        const long long now = __builtin_amdgcn_s_memrealtime();
+                        if (t0 == 0) t0 = now;
+                        else if (now - t0 > BPTT_SPIN_LIMIT_TICKS) {
+                            if (lane == 0) __hip_atomic_store(a.status, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                if (!ok && lane == 0) abort_s = 1;
+            }
+            __syncthreads();
+            if (abort_s) return;                       // uniform: every wave of the workgroup leaves
+            const int gbase = ((tn * 2 + d) * NW * 8) * 1024 + lane * 16;
+#pragma unroll
+            for (int i = 0; i < NKSW_MAX; ++i) {
+                if (i < nksw) {
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(drsrc, gbase + (wv * nksw + i) * 1024, 0, 16 /*sc1*/);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[i], __builtin_bit_cast(bf16x8, raw), acc, 0, 0, 0);
+                }
+            }
+        }
+        // ---- sum the four K-slices through LDS; wave wv finishes rows (units) 8wv + 4hh + e
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4)
+            *(f32x4*)(&red[wv][lane][4 * e4]) = f32x4{acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]};
+        __syncthreads();
+        const f32x4 r0 = *(const f32x4*)(&red[0][lane][4 * wv]), r1 = *(const f32x4*)(&red[1][lane][4 * wv]);
+        const f32x4 r2 = *(const f32x4*)(&red[2][lane][4 * wv]), r3 = *(const f32x4*)(&red[3][lane][4 * wv]);
+        // ---- cell backward (lane-local)
+        bf16_t o4[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dhv = dhin[e] + ((r0[e] + r1[e]) + (r2[e] + r3[e]));
+            const float ig = gt[0][e], fg = gt[1][e], gg = gt[2][e], og = gt[3][e];
+            const float tc = tanh_fast(ccur[e]);
+            const float dc = fmaf(dhv * og, 1.0f - tc * tc, carry[e]);
+            float di = dc * gg * ig * (1.0f - ig);
+            float df = dc * cprev[e] * fg * (1.0f - fg);
+            float dgg = dc * ig * (1.0f - gg * gg);
+            float dov = dhv * tc * og * (1.0f - og);
+            carry[e] = dc * fg;
+            ccur[e] = cprev[e];
+            if (!live) { di = df = dgg = dov = 0.0f; carry[e] = 0.0f; }
+            o4[0][e] = f32_to_bf16(di); o4[1][e] = f32_to_bf16(df); o4[2][e] = f32_to_bf16(dgg); o4[3][e] = f32_to_bf16(dov);
+        }
+        // ---- assemble the workgroup's 8 B-operand images: (gate p, unit u) -> image 2p + (u >> 4),
+        //      lane ((u >> 3) & 1)*32 + batch, element u & 7;  u = 8wv + 4hh + e
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned lo = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16), hi = (unsigned)o4[p][2] | ((unsigned)o4[p][3] << 16);
+            *(uint2*)(&img[2 * p + (wv >> 1)][(wv & 1) * 32 + b][4 * hh]) = make_uint2(lo, hi);
+        }
+        __syncthreads();                                // images assembled; every wave is done with `red`
+        {
+            const int obase = (((t * 2 + d) * NW + w) * 8) * 1024;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int i = tid + 256 * h2;
+                const u32x4 piece = *(const u32x4*)(&img[i >> 6][i & 63][0]);
+                __builtin_amdgcn_raw_buffer_store_b128(piece, drsrc, obase + i * 16, 0, 16 /*sc1: write-through*/);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's pieces have landed
+        }
+        __syncthreads();                                // ... and so have everyone's: raise the step flag
+        if (wv == 0 && lane < BW_FLAG_REPL)
+            __hip_atomic_store(flags_all + lane * NW + w, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// dgx images -> dG [(t*B+b)*ldg + d*4H + p*H + j] bf16 (GEMM A rows) and dGT [(d*4H + p*H + j)*ldt + t*B + b] bf16
+__global__ __launch_bounds__(256) void lstm_dg_unpack_kernel(const bf16_t* __restrict__ dgx, bf16_t* __restrict__ dG, int ldg,
+                                                             bf16_t* __restrict__ dGT, long long ldt, int B, int T, int H) {
+    __shared__ __attribute__((aligned(16))) bf16_t img[8][64][8];
+    const int NW = (H + 31) >> 5;
+    const int w = blockIdx.x, t = blockIdx.y >> 1, d = blockIdx.y & 1, g = blockIdx.z;
+    const int Bg = min(32, B - g * 32);
+    const uint4* src = (const uint4*)(dgx + ((((size_t)g * T + t) * 2 + d) * NW + w) * 4096);
+    ((uint4*)&img[0][0][0])[threadIdx.x] = src[threadIdx.x];
+    ((uint4*)&img[0][0][0])[threadIdx.x + 256] = src[threadIdx.x + 256];
+    __syncthreads();
+    {   // dG rows: thread (u = tid & 31, row slot = tid >> 5)
+        const int u = threadIdx.x & 31, jj = 32 * w + u;
+        for (int c = threadIdx.x >> 5; c < 128; c += 8) {
+            const int bb = c >> 2, p = c & 3;
+            if (bb < Bg && jj < H)
+                dG[((size_t)t * B + g * 32 + bb) * ldg + (size_t)d * 4 * H + (size_t)p * H + jj] = img[2 * p + (u >> 4)][((u >> 3) & 1) * 32 + bb][u & 7];
+        }
+    }
+    {   // dGT rows: thread (batch = tid & 31, slot = tid >> 5)
+        const int bb = threadIdx.x & 31;
+        for (int c = threadIdx.x >> 5; c < 128; c += 8) {
+            const int p = c >> 5, u = c & 31, jj = 32 * w + u;
+            if (bb < Bg && jj < H)
+                dGT[((size_t)d * 4 * H + (size_t)p * H + jj) * ldt + (size_t)t * B + g * 32 + bb] = img[2 * p + (u >> 4)][((u >> 3) & 1) * 32 + bb][u & 7];
+        }
+    }
+}
+
+// hx (hi pieces) -> HT[(d*rows_per_dir + k)*ld + t*B + b] = bf16(h^d at the forward pass's PREVIOUS step of t)[k][b]
+// (t-1 for the forward direction, t+1 for the reverse one; zero at the sequence boundary): the W operand of
+// dW_hh[d] = dG_d^T . Hprev_d
+__global__ __launch_bounds__(256) void lstm_hprevT_kernel(const bf16_t* __restrict__ hx, bf16_t* __restrict__ HT, long long ld,
+                                                          int rows_per_dir, int B, int T, int H) {
+    const int nkb = H >> 3;
+    const int ks = blockIdx.x, t = blockIdx.y >> 1, d = blockIdx.y & 1, g = blockIdx.z;
+    const int Bg = min(32, B - g * 32);
+    const int tp = d ? (t + 1) : (t - 1);
+    const bool have = tp >= 0 && tp < T;
+    const bf16_t* src = hx + ((((size_t)g * T + (have ? tp : 0)) * 2 + d) * nkb) * 512 + (size_t)ks * 1024;   // hi block of k-step ks
+    const int bb = threadIdx.x & 31;
+    for (int kl = threadIdx.x >> 5; kl < 16; kl += 8) {
+        const bf16_t v = have ? src[((kl >> 3) * 32 + bb) * 8 + (kl & 7)] : (bf16_t)0;
+        if (bb < Bg) HT[((size_t)d * rows_per_dir + ks * 16 + kl) * ld + (size_t)t * B + g * 32 + bb] = v;
+    }
+}
+
+__device__ __forceinline__ bool dropout_keep(unsigned seed, unsigned layer, unsigned long long idx, float p) {
+    unsigned long long z = idx + ((((unsigned long long)seed) << 8) ^ layer) * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
+}
+
+// hx (hi + lo pieces = f32-accurate h) -> X[(t*B+b)*ldx + d*Hv + j] bf16 with inverted dropout (nn.LSTM's
+// inter-layer dropout; the mask is a counter-based hash of (seed, layer, element), regenerated in the backward pass)
+__global__ void lstm_relayout_train_kernel(const bf16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, int B, int T, int H, int Hv,
+                                           float p, unsigned seed, unsigned layer) {
+    const int nkb = H >> 3;
+    const long long n = (long long)T * B * 2 * Hv;
+    const float scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % (2 * Hv));
+        const long long m = i / (2 * Hv);
+        const int bq = (int)(m % B), t = (int)(m / B), d = col / Hv, jj = col - d * Hv, g = bq >> 5, bl = bq & 31;
+        const bf16_t* blk = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 512 + (size_t)(jj >> 4) * 1024;
+        const int e = (((jj >> 3) & 1) * 32 + bl) * 8 + (jj & 7);
+        float v = bf16_to_f32(blk[e]) + bf16_to_f32(blk[512 + e]);
+        if (p > 0.0f) v = dropout_keep(seed, layer, (unsigned long long)i, p) ? v * scale : 0.0f;
+        X[(size_t)m * ldx + col] = f32_to_bf16(v);
+    }
+}
+
+// dX [(t*B+b)*ld + d*Hv + j] f32 (gradient of the layer OUTPUT, after dropout) -> dh [g][t][d][H/8][8][32] f32
+__global__ void lstm_dh_relayout_kernel(const float* __restrict__ dX, int ld, float* __restrict__ dh, int B, int T, int H, int Hv,
+                                        float p, unsigned seed, unsigned layer) {
+    const int nkb = H >> 3, NG = (B + 31) >> 5;
+    const long long n = (long long)NG * T * 2 * nkb * 256;
+    const float scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int bl = (int)(i & 31), jl = (int)((i >> 5) & 7);
+        long long q = i >> 8;
+        const int kb = (int)(q % nkb); q /= nkb;
+        const int d = (int)(q & 1); q >>= 1;
+        const int t = (int)(q % T), g = (int)(q / T);
+        const int jj = kb * 8 + jl, bq = g * 32 + bl;
+        float v = 0.0f;
+        if (jj < Hv && bq < B) {
+            const long long m = (long long)t * B + bq;
+            const int col = d * Hv + jj;
+            v = dX[(size_t)m * ld + col];
+            if (p > 0.0f) v = dropout_keep(seed, layer, (unsigned long long)(m * 2 * Hv + col), p) ? v * scale : 0.0f;
+        }
+        dh[i] = v;
+    }
+}
+
+// dlogits [B][P][T] f32 -> dL [(t*B+b)*128 + p] bf16 and dLT [p*ldt + t*B + b] bf16 (p < 128; zero for p >= P)
+__global__ void dlogits_pack_kernel(const float* __restrict__ dl, bf16_t* __restrict__ dL, bf16_t* __restrict__ dLT, long long ldt,
+                                    int B, int P, int T) {
+    const long long n = (long long)T * B * 128;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i & 127);
+        const long long m = i >> 7;
+        const int bq = (int)(m % B), t = (int)(m / B);
+        const bf16_t v = p < P ? f32_to_bf16(dl[((size_t)bq * P + p) * T + t]) : (bf16_t)0;
+        dL[i] = v;
+        dLT[(size_t)p * ldt + m] = v;
+    }
+}
+
+}  // namespace mt
+
+using namespace mt;
+
+extern "C" size_t mt_lstm_dgx_bytes(int B, int T, int H) {
+    return (size_t)((B + 31) / 32) * T * 2 * ((H + 31) / 32) * 8 * 1024;
+}
+extern "C" size_t mt_lstm_cx_bytes(int B, int T, int H) { return (size_t)((B + 31) / 32) * T * 2 * (H / 8) * 256 * sizeof(float); }
+
+// sync_ws: >= mt_lstm_sync_bytes(B, H) bytes (word 0 = status, flags from byte 256)
+extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx, void* sync_ws,
+                                 size_t sync_bytes, int B, int T, int H, mt_stream_t stream) {
+    MT_REQUIRE(gates && cx && dh && w_hh && dgx && sync_ws, MT_EINVAL, "mt_lstm_bidir_bwd: null pointer");
+    MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 512, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: H=%d unsupported (16..512, multiple of 16)", H);
+    const int NG = (B + 31) / 32, NW = (H + 31) / 32;
+    MT_REQUIRE((size_t)T * 2 * NW * 8 * 1024 < (size_t)1 << 31, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: T=%d too long for one buffer descriptor", T);
+    const size_t need = 256 + (size_t)NG * 2 * BW_FLAG_REPL * NW * 4;
+    MT_REQUIRE(sync_bytes >= need, MT_EWORKSPACE, "mt_lstm_bidir_bwd: sync workspace %zu < %zu", sync_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, need, st));
+    LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
+    dim3 grid(NW, 2, NG);
+    MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);
+    const int nksw = 2 * NW;
+    if (nksw <= 2) hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(256), 0, st, a);
+    else if (nksw <= 4) hipLaunchKernelGGL(lstm_bptt_kernel<4>, grid, dim3(256), 0, st, a);
+    else if (nksw <= 8) hipLaunchKernelGGL(lstm_bptt_kernel<8>, grid, dim3(256), 0, st, a);
+    else if (nksw <= 16) hipLaunchKernelGGL(lstm_bptt_kernel<16>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lstm_bptt_kernel<32>, grid, dim3(256), 0, st, a);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, long long ldt, int B, int T, int H, mt_stream_t stream) {
+    MT_REQUIRE(dgx && dG && dGT && B > 0 && T > 0 && H % 16 == 0 && ldg >= 8 * H && ldt >= (long long)T * B, MT_EINVAL, "mt_lstm_dg_unpack: bad arguments");
+    hipLaunchKernelGGL(lstm_dg_unpack_kernel, dim3((H + 31) / 32, 2 * T, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dgx, (bf16_t*)dG, ldg, (bf16_t*)dGT, ldt, B, T, H);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_lstm_hprev_t(const float* hx, void* HT, long long ld, int rows_per_dir, int B, int T, int H, mt_stream_t stream) {
+    MT_REQUIRE(hx && HT && B > 0 && T > 0 && H % 16 == 0 && rows_per_dir >= H && ld >= (long long)T * B, MT_EINVAL, "mt_lstm_hprev_t: bad arguments");
+    hipLaunchKernelGGL(lstm_hprevT_kernel, dim3(H / 16, 2 * T, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)hx, (bf16_t*)HT, ld, rows_per_dir, B, T, H);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_lstm_relayout_train(const float* hx, void* X, int ldx, int B, int T, int H, int Hv, float p, unsigned seed, unsigned layer,
+                                      mt_stream_t stream) {
+    MT_REQUIRE(hx && X && B > 0 && T > 0 && H % 16 == 0 && Hv > 0 && Hv <= H && ldx >= 2 * Hv && p >= 0.0f && p < 1.0f, MT_EINVAL, "mt_lstm_relayout_train: bad arguments");
+    long long g = ((long long)T * B * 2 * Hv + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(lstm_relayout_train_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hx, (bf16_t*)X, ldx, B, T, H, Hv, p, seed, layer);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_lstm_dh_relayout(const float* dX, int ld, float* dh, int B, int T, int H, int Hv, float p, unsigned seed, unsigned layer,
+                                   mt_stream_t stream) {
+    MT_REQUIRE(dX && dh && B > 0 && T > 0 && H % 16 == 0 && Hv > 0 && Hv <= H && ld >= 2 * Hv && p >= 0.0f && p < 1.0f, MT_EINVAL, "mt_lstm_dh_relayout: bad arguments");
+    long long g = ((long long)((B + 31) / 32) * T * 2 * (H / 8) * 256 + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(lstm_dh_relayout_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dX, ld, dh, B, T, H, Hv, p, seed, layer);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_dlogits_pack(const float* dlogits, void* dL, void* dLT, long long ldt, int B, int P, int T, mt_stream_t stream) {
+    MT_REQUIRE(dlogits && dL && dLT && B > 0 && P > 0 && P <= 128 && T > 0 && ldt >= (long long)T * B, MT_EINVAL, "mt_dlogits_pack: bad arguments");
+    long long g = ((long long)T * B * 128 + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(dlogits_pack_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dlogits, (bf16_t*)dL, (bf16_t*)dLT, ldt, B, P, T);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}

@@ -1,0 +1,485 @@
+// Training-step kernels of the CNN front end of CNNRNNModel (train/train_transcriber.py:90-158 drives
+// models/cnn_rnn_model.py:29-39 in train mode): BatchNorm with BATCH statistics, ReLU, MaxPool2d((2,1)) and their
+// backward passes, plus the data-movement pieces that let every dense contraction of the backward pass run on the
+// bf16 MFMA GEMM (gemm.hip) or the channels-last conv (convg.hip):
+//   forward   conv1: statistics of the (recomputed) pre-BN activation -> fold batch statistics into the weights ->
+//                    the inference conv1 kernel (conv.hip).  The 1-channel conv is cheaper to recompute than to store.
+//             conv2: mt_conv_cl_bf16 (raw, bf16) -> bn_stats_cl -> bn_relu_pool_apply (writes the GEMM operand X0)
+//   backward  conv2: bn_pool_bwd_reduce / _apply (dz2, channels-last bf16) -> dgrad = mt_conv_cl_bf16 with flipped
+//                    weights; wgrad = dz2^T [64][N] x im2col^T [288][N] as a split-K GEMM over the N positions
+//             conv1: conv1_bwd_reduce / conv1_bwd_wgrad (recompute z1 from the mel input)
+// Sums over millions of positions are accumulated per thread in f32 over short runs and across threads in f64
+// (global_atomic_add_f64), so E[z^2] - E[z]^2 keeps ~1e-12 relative accuracy.
+#include "mt_common.h"
+
+namespace mt {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ conv1 statistics
+// x [B][F][T] f32, w [32][9], bias [32] (RAW conv parameters).  sums[0..31] += sum z, sums[32..63] += sum z^2 over
+// every (b, f, t); z = conv(x)[c] + bias[c].
+__global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, double* __restrict__ sums,
+                                                          int B, int F, int T) {
+    float s[32], q[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s[c] = q[c] = 0.0f;
+    const long long n = (long long)B * F * T;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i % T), f = (int)((i / T) % F), b = (int)(i / ((long long)T * F));
+        const float* m = x + (size_t)b * F * T;
+        float p[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ff = f - 1 + kh, tt = t - 1 + kw;
+                p[kh * 3 + kw] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? m[(size_t)ff * T + tt] : 0.0f;
+            }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            float z = bias[c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) z = fmaf(w[c * 9 + k], p[k], z);
+            s[c] += z;
+            q[c] = fmaf(z, z, q[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const float a = wave_sum(s[c]), b2 = wave_sum(q[c]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(sums + c, (double)a);
+            atomicAdd(sums + 32 + c, (double)b2);
+        }
+    }
+}
+
+// sums -> batch mean / rstd; running statistics updated as nn.BatchNorm2d does (momentum, unbiased variance);
+// optionally the folded conv1 parameters wf = w * gamma * rstd, bf = (b - mean) * gamma * rstd + beta.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float momentum, float eps, float* __restrict__ mean_out,
+                                   float* __restrict__ rstd_out, int C, const float* __restrict__ w, const float* __restrict__ b,
+                                   float* __restrict__ wf, float* __restrict__ bf, int taps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+    if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    if (wf) {
+        const float sc = gamma[c] * rstd;
+        for (int k = 0; k < taps; ++k) wf[c * taps + k] = w[c * taps + k] * sc;
+        bf[c] = (b[c] - (float)mean) * sc + beta[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ channels-last statistics
+// z [N][C] bf16 (C in {32, 64, 128, 256}); sums[0..C) += sum z, sums[C..2C) += sum z^2.
+__global__ __launch_bounds__(256) void bn_stats_cl_kernel(const bf16_t* __restrict__ z, long long N, int C, double* __restrict__ sums) {
+    __shared__ float red[2][256];
+    const int c = threadIdx.x % C, rl = threadIdx.x / C, R = 256 / C;
+    float s = 0.0f, q = 0.0f;
+    for (long long r = (long long)blockIdx.x * R + rl; r < N; r += (long long)gridDim.x * R) {
+        const float v = bf16_to_f32(z[r * C + c]);
+        s += v;
+        q = fmaf(v, v, q);
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float a = 0.0f, b = 0.0f;
+        for (int i = 0; i < R; ++i) { a += red[0][i * C + c]; b += red[1][i * C + c]; }
+        atomicAdd(sums + c, (double)a);
+        atomicAdd(sums + C + c, (double)b);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv2: BN + ReLU + pool
+// z [B][F][T][64] bf16 -> X[(t*B + b)*ldx + fo*64 + c] bf16 = max_i relu(gamma*(z_i - mean)*rstd + beta), i = rows 2fo, 2fo+1
+__global__ __launch_bounds__(256) void bn_relu_pool_apply_kernel(const bf16_t* __restrict__ z, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, bf16_t* __restrict__ X, int ldx,
+                                                                 int B, int F, int T) {
+    const int c = threadIdx.x & 63, Fo = F >> 1;
+    const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
+    const long long n = (long long)B * Fo * T;
+    for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long long)gridDim.x * 4) {
+        const int t = (int)(i % T), fo = (int)((i / T) % Fo), b = (int)(i / ((long long)T * Fo));
+        const size_t p0 = (((size_t)b * F + 2 * fo) * T + t) * 64 + c;
+        const float v0 = fmaf(bf16_to_f32(z[p0]), sc, sh), v1 = fmaf(bf16_to_f32(z[p0 + (size_t)T * 64]), sc, sh);
+        X[((size_t)t * B + b) * ldx + (size_t)fo * 64 + c] = f32_to_bf16(fmaxf(fmaxf(v0, v1), 0.0f));
+    }
+}
+
+// Backward of the same: dX f32 [(t*B+b)*ldd + fo*64 + c] is the gradient of the pooled output.
+// pass 1 (APPLY = false): sums[c] += sum dy, sums[64 + c] += sum dy * xhat over all pre-pool positions
+//        (dy = routed gradient: the pool winner's, if its ReLU output is positive; ties go to the first row)
+// pass 2 (APPLY = true):  dz[b][f][t][c] bf16 = gamma*rstd*(dy - sum_dy/N - xhat*sum_dyxhat/N), N = B*F*T
+//        BatchNorm makes sum dz = 0 and sum dz*z = 0 per channel, so the conv weight gradient sum_n dz[n] a[n+tap] is
+//        a sum with heavy cancellation: the bf16 rounding of dz alone costs ~10 % of it.  dz_lo (optional) carries the
+//        rounding remainder as a second bf16 piece and the weight-gradient GEMM runs over both pieces.
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const float* __restrict__ dX, int ldd, const bf16_t* __restrict__ z,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          double* __restrict__ sums, bf16_t* __restrict__ dz, bf16_t* __restrict__ dz_lo,
+                                                          int B, int F, int T) {
+    __shared__ float red[2][256];
+    const int c = threadIdx.x & 63, Fo = F >> 1, Fh = (F + 1) >> 1;     // Fh pairs; the last one is a single row when F is odd
+    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    const double cnt = (double)B * F * T;
+    float m1 = 0.0f, m2 = 0.0f;
+    if (APPLY) { m1 = (float)(sums[c] / cnt); m2 = (float)(sums[64 + c] / cnt); }
+    float s1 = 0.0f, s2 = 0.0f;
+    const long long n = (long long)B * Fh * T;
+    for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long long)gridDim.x * 4) {
+        const int t = (int)(i % T), fo = (int)((i / T) % Fh), b = (int)(i / ((long long)T * Fh));
+        const size_t p0 = (((size_t)b * F + 2 * fo) * T + t) * 64 + c;
+        const bool pair = fo < Fo;
+        const float x0 = (bf16_to_f32(z[p0]) - mu) * rs;
+        const float x1 = pair ? (bf16_to_f32(z[p0 + (size_t)T * 64]) - mu) * rs : 0.0f;
+        float d0 = 0.0f, d1 = 0.0f;
+        if (pair) {
+            const float y0 = fmaf(ga, x0, be), y1 = fmaf(ga, x1, be);
+            const float g = dX[((size_t)t * B + b) * ldd + (size_t)fo * 64 + c];
+            if (y1 > y0) { if (y1 > 0.0f) d1 = g; }
+            else if (y0 > 0.0f) d0 = g;
+        }
+        if (APPLY) {
+            const float k = ga * rs;
+            const float g0 = k * (d0 - m1 - x0 * m2), g1 = k * (d1 - m1 - x1 * m2);
+            const bf16_t h0 = f32_to_bf16(g0), h1 = f32_to_bf16(g1);
+            dz[p0] = h0;
+            if (pair) dz[p0 + (size_t)T * 64] = h1;
+            if (dz_lo) {                               // second bf16 piece: dz = hi + lo to ~2^-17 (see mt_bn_pool_bwd)
+                dz_lo[p0] = f32_to_bf16(g0 - bf16_to_f32(h0));
+                if (pair) dz_lo[p0 + (size_t)T * 64] = f32_to_bf16(g1 - bf16_to_f32(h1));
+            }
+        } else {
+            s1 += d0 + d1;
+            s2 = fmaf(d0, x0, fmaf(d1, x1, s2));
+        }
+    }
+    if (!APPLY) {
+        red[0][threadIdx.x] = s1;
+        red[1][threadIdx.x] = s2;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            atomicAdd(sums + c, (double)(red[0][c] + red[0][64 + c] + red[0][128 + c] + red[0][192 + c]));
+            atomicAdd(sums + 64 + c, (double)(red[1][c] + red[1][64 + c] + red[1][128 + c] + red[1][192 + c]));
+        }
+    }
+}
+
+// sums (f64) -> f32 gradient vectors: dgamma = sum dy*xhat, dbeta = sum dy
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
+}
+
+// ------------------------------------------------------------------------------------------------ im2col^T for the conv2 wgrad
+// a [B][F][T][32] bf16 -> colT[(tap*32 + ci)*ld + n], n = (b*F + f)*T + t, tap = kh*3 + kw: a[b][f+kh-1][t+kw-1][ci] (0 outside)
+__global__ __launch_bounds__(256) void im2colT_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ colT, long long ld,
+                                                      int B, int F, int T) {
+    __shared__ bf16_t tile[3][66][34];                // [row][t + halo][ci (+2 pad)]
+    const int t0 = blockIdx.x * 64, f = blockIdx.y, b = blockIdx.z;
+    for (int i = threadIdx.x; i < 3 * 66 * 32; i += 256) {
+        const int ci = i & 31, tl = (i >> 5) % 66, r = i / (66 * 32);
+        const int ff = f - 1 + r, tt = t0 - 1 + tl;
+        tile[r][tl][ci] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? a[(((size_t)b * F + ff) * T + tt) * 32 + ci] : (bf16_t)0;
+    }
+    __syncthreads();
+    const int tl = threadIdx.x & 63;
+    if (t0 + tl >= T) return;
+    const long long n = ((long long)b * F + f) * T + t0 + tl;
+    for (int k = threadIdx.x >> 6; k < 288; k += 4) {
+        const int tap = k >> 5, ci = k & 31, kh = tap / 3, kw = tap - 3 * kh;
+        colT[(size_t)k * ld + n] = tile[kh][tl + kw][ci];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ generic bf16 transpose
+// dst[c*ldd + r] = src[r*lds + c] for r < R, c < C; dst rows c < Cd, columns r < ldd are all written (zero outside)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, long long lds, long long R, int C,
+                                                             bf16_t* __restrict__ dst, long long ldd, int Cd) {
+    __shared__ bf16_t tile[64][66];
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rl = i >> 6, cl = i & 63;
+        tile[rl][cl] = (r0 + rl < R && c0 + cl < C) ? src[(r0 + rl) * lds + c0 + cl] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cl = i >> 6, rl = i & 63;
+        if (c0 + cl < Cd && r0 + rl < ldd) dst[(size_t)(c0 + cl) * ldd + r0 + rl] = tile[rl][cl];
+    }
+}
+
+// dst[i0][i1][i2][i3] (contiguous f32) = alpha * src[i0*s0 + i1*s1 + i2*s2 + i3*s3]
+__global__ void gather4_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int n1, int n2, int n3,
+                                   long long s0, long long s1, long long s2, long long s3, float alpha) {
+    const long long n = (long long)n0 * n1 * n2 * n3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int i3 = (int)(i % n3), i2 = (int)((i / n3) % n2), i1 = (int)((i / ((long long)n3 * n2)) % n1);
+        const int i0 = (int)(i / ((long long)n3 * n2 * n1));
+        dst[i] = alpha * src[i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3];
+    }
+}
+
+// out[r*ldo + c] = sum_z P[z*stride + r*ldp + c]   (split-K partial sums, fixed order)
+__global__ void sum_slices_kernel(const float* __restrict__ P, long long stride, int ldp, int S, float* __restrict__ out, int ldo,
+                                  int rows, int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int r = i / cols, c = i - r * cols;
+    float acc = 0.0f;
+    for (int z = 0; z < S; ++z) acc += P[(size_t)z * stride + (size_t)r * ldp + c];
+    out[(size_t)r * ldo + c] = acc;
+}
+
+// out[r] = sum_{c < n} A[r*ld + c]  (bf16 rows, one wave per row; bias gradients from the transposed operands)
+__global__ void rowsum_bf16_kernel(const bf16_t* __restrict__ A, long long ld, long long n, float* __restrict__ out, int rows) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.0f;
+    for (long long c = lane; c < n; c += 64) s += bf16_to_f32(A[(size_t)row * ld + c]);
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ conv1 backward
+// da [B][Fo][T][ldc] bf16 (channels 0..31 used) = gradient of act1 (pooled).  z1 is recomputed from x.
+// pass 1 (WGRAD = false): sums[c] += sum dy, sums[32 + c] += sum dy*xhat
+// pass 2 (WGRAD = true):  dz = gamma*rstd*(dy - m1 - xhat*m2);  acc[c][k] += sum dz * x_tap(k), acc[c][9] += sum dz
+//                         for the channel group blockIdx.y (8 channels): out double [32][10]
+template <bool WGRAD>
+__global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const bf16_t* __restrict__ da, int ldc, double* __restrict__ sums,
+                                                        double* __restrict__ wacc, int B, int F, int T) {
+    const int Fo = F >> 1, Fh = (F + 1) >> 1;
+    const int cg = WGRAD ? blockIdx.y * 8 : 0;
+    constexpr int NC = WGRAD ? 8 : 32;
+    float acc[WGRAD ? 80 : 64];
+#pragma unroll
+    for (int i = 0; i < (WGRAD ? 80 : 64); ++i) acc[i] = 0.0f;
+    const double cnt = (double)B * F * T;
+    const long long n = (long long)B * Fh * T;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int t = (int)(i % T), fo = (int)((i / T) % Fh), b = (int)(i / ((long long)T * Fh));
+        const bool pair = fo < Fo;
+        const float* m = x + (size_t)b * F * T;
+        float p[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const int ff = 2 * fo - 1 + r, tt = t - 1 + cc;
+                p[r][cc] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? m[(size_t)ff * T + tt] : 0.0f;
+            }
+        const bf16_t* dap = da + (((size_t)b * Fo + fo) * T + t) * ldc;
+#pragma unroll
+        for (int ci = 0; ci < NC; ++ci) {
+            const int c = cg + ci;
+            float z0 = bias[c], z1 = bias[c];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float wv = w[c * 9 + kh * 3 + kw];
+                    z0 = fmaf(wv, p[kh][kw], z0);
+                    z1 = fmaf(wv, p[kh + 1][kw], z1);
+                }
+            const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+            const float x0 = (z0 - mu) * rs, x1 = pair ? (z1 - mu) * rs : 0.0f;
+            float d0 = 0.0f, d1 = 0.0f;
+            if (pair) {
+                const float y0 = fmaf(ga, x0, be), y1 = fmaf(ga, x1, be);
+                const float g = bf16_to_f32(dap[c]);
+                if (y1 > y0) { if (y1 > 0.0f) d1 = g; }
+                else if (y0 > 0.0f) d0 = g;
+            }
+            if (!WGRAD) {
+                acc[ci] += d0 + d1;
+                acc[32 + ci] = fmaf(d0, x0, fmaf(d1, x1, acc[32 + ci]));
+            } else {
+                const float m1 = (float)(sums[c] / cnt), m2 = (float)(sums[32 + c] / cnt), k = ga * rs;
+                const float dz0 = k * (d0 - m1 - x0 * m2);
+                const float dz1 = pair ? k * (d1 - m1 - x1 * m2) : 0.0f;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        acc[ci * 10 + kh * 3 + kw] = fmaf(dz0, p[kh][kw], fmaf(dz1, p[kh + 1][kw], acc[ci * 10 + kh * 3 + kw]));
+                acc[ci * 10 + 9] += dz0 + dz1;
+            }
+        }
+    }
+    if (!WGRAD) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const float v = wave_sum(acc[i]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(sums + i, (double)v);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 80; ++i) {
+            const float v = wave_sum(acc[i]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(wacc + cg * 10 + i, (double)v);
+        }
+    }
+}
+
+// wacc double [32][10] -> dW1 [32][9], db1 [32]
+__global__ void conv1_wgrad_out_kernel(const double* __restrict__ wacc, float* __restrict__ dW, float* __restrict__ db) {
+    const int i = threadIdx.x;
+    if (i < 320) {
+        const int c = i / 10, k = i - 10 * c;
+        if (k < 9) dW[c * 9 + k] = (float)wacc[i];
+        else db[c] = (float)wacc[i];
+    }
+}
+
+}  // namespace mt
+
+using namespace mt;
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int mt_conv1_stats(const float* x, const float* w, const float* bias, double* sums64, int B, int F, int T, mt_stream_t stream) {
+    MT_REQUIRE(x && w && bias && sums64 && B > 0 && F > 0 && T > 0, MT_EINVAL, "mt_conv1_stats: bad arguments");
+    MT_CHECK_HIP(hipMemsetAsync(sums64, 0, 64 * sizeof(double), ST(stream)));
+    const long long n = (long long)B * F * T;
+    const int grid = (int)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
+    hipLaunchKernelGGL(conv1_stats_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, ST(stream), x, w, bias, sums64, B, F, T);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, float momentum, float eps, float* mean_out, float* rstd_out, int C,
+                              const float* w, const float* b, float* w_folded, float* b_folded, int taps, mt_stream_t stream) {
+    MT_REQUIRE(sums && mean_out && rstd_out && C > 0 && count > 0, MT_EINVAL, "mt_bn_finalize: bad arguments");
+    MT_REQUIRE(!w_folded || (w && b && b_folded && gamma && beta && taps > 0), MT_EINVAL, "mt_bn_finalize: folding needs w, b, gamma, beta");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST(stream), sums, count, gamma, beta, running_mean, running_var,
+                       momentum, eps, mean_out, rstd_out, C, w, b, w_folded, b_folded, taps);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_bn_stats_cl(const void* z, long long N, int C, double* sums, mt_stream_t stream) {
+    MT_REQUIRE(z && sums && N > 0 && (C == 32 || C == 64 || C == 128 || C == 256), MT_EINVAL, "mt_bn_stats_cl: bad arguments (C=%d)", C);
+    MT_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST(stream)));
+    const int R = 256 / C;
+    long long g = (N + (long long)R * 64 - 1) / ((long long)R * 64);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(bn_stats_cl_kernel, dim3((unsigned)(g > 0 ? g : 1)), dim3(256), 0, ST(stream), (const bf16_t*)z, N, C, sums);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_bn_relu_pool_apply(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     void* X, int ldx, int B, int F, int T, mt_stream_t stream) {
+    MT_REQUIRE(z && mean && rstd && gamma && beta && X && B > 0 && F >= 2 && T > 0 && ldx >= (F / 2) * 64, MT_EINVAL, "mt_bn_relu_pool_apply: bad arguments");
+    long long g = ((long long)B * (F / 2) * T + 63) / 64;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(bn_relu_pool_apply_kernel, dim3((unsigned)g), dim3(256), 0, ST(stream), (const bf16_t*)z, mean, rstd, gamma, beta,
+                       (bf16_t*)X, ldx, B, F, T);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_bn_pool_bwd(const float* dX, int ldd, const void* z, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, double* sums128, void* dz, void* dz_lo, float* dgamma, float* dbeta, int B, int F,
+                              int T, mt_stream_t stream) {
+    MT_REQUIRE(dX && z && mean && rstd && gamma && beta && sums128 && dz && B > 0 && F >= 2 && T > 0, MT_EINVAL, "mt_bn_pool_bwd: bad arguments");
+    MT_CHECK_HIP(hipMemsetAsync(sums128, 0, 128 * sizeof(double), ST(stream)));
+    long long g = ((long long)B * ((F + 1) / 2) * T + 63) / 64;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(bn_pool_bwd_kernel<false>, dim3((unsigned)g), dim3(256), 0, ST(stream), dX, ldd, (const bf16_t*)z, mean, rstd, gamma, beta,
+                       sums128, (bf16_t*)nullptr, (bf16_t*)nullptr, B, F, T);
+    hipLaunchKernelGGL(bn_pool_bwd_kernel<true>, dim3((unsigned)g), dim3(256), 0, ST(stream), dX, ldd, (const bf16_t*)z, mean, rstd, gamma, beta,
+                       sums128, (bf16_t*)dz, (bf16_t*)dz_lo, B, F, T);
+    if (dgamma && dbeta) hipLaunchKernelGGL(bn_param_grads_kernel, dim3(1), dim3(64), 0, ST(stream), sums128, dgamma, dbeta, 64);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_im2col_t_3x3_c32(const void* a, void* colT, long long ld, int B, int F, int T, mt_stream_t stream) {
+    MT_REQUIRE(a && colT && B > 0 && F > 0 && T > 0 && ld >= (long long)B * F * T, MT_EINVAL, "mt_im2col_t_3x3_c32: bad arguments");
+    hipLaunchKernelGGL(im2colT_kernel, dim3(cdiv(T, 64), F, B), dim3(256), 0, ST(stream), (const bf16_t*)a, (bf16_t*)colT, ld, B, F, T);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd, mt_stream_t stream) {
+    MT_REQUIRE(src && dst && R > 0 && C > 0 && lds >= C && ldd >= R && Cd >= C, MT_EINVAL, "mt_transpose_bf16: bad arguments");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((ldd + 63) / 64), cdiv(Cd, 64)), dim3(256), 0, ST(stream),
+                       (const bf16_t*)src, lds, R, C, (bf16_t*)dst, ldd, Cd);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_gather4_f32(const float* src, float* dst, int n0, int n1, int n2, int n3, long long s0, long long s1, long long s2,
+                              long long s3, float alpha, mt_stream_t stream) {
+    MT_REQUIRE(src && dst && n0 > 0 && n1 > 0 && n2 > 0 && n3 > 0, MT_EINVAL, "mt_gather4_f32: bad arguments");
+    const long long n = (long long)n0 * n1 * n2 * n3;
+    long long g = (n + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(gather4_f32_kernel, dim3((unsigned)g), dim3(256), 0, ST(stream), src, dst, n0, n1, n2, n3, s0, s1, s2, s3, alpha);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_sum_slices_f32(const float* P, long long stride, int ldp, int S, float* out, int ldo, int rows, int cols, mt_stream_t stream) {
+    MT_REQUIRE(P && out && S > 0 && rows > 0 && cols > 0 && ldp >= cols && ldo >= cols, MT_EINVAL, "mt_sum_slices_f32: bad arguments");
+    hipLaunchKernelGGL(sum_slices_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, ST(stream), P, stride, ldp, S, out, ldo, rows, cols);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_rowsum_bf16(const void* A, long long ld, long long n, float* out, int rows, mt_stream_t stream) {
+    MT_REQUIRE(A && out && rows > 0 && n > 0 && ld >= n, MT_EINVAL, "mt_rowsum_bf16: bad arguments");
+    hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), (const bf16_t*)A, ld, n, out, rows);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_conv1_bwd(const float* x, const float* w, const float* bias, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, const void* da, int ldc, double* scratch384, float* dW, float* db, float* dgamma,
+                            float* dbeta, int B, int F, int T, mt_stream_t stream) {
+    MT_REQUIRE(x && w && bias && mean && rstd && gamma && beta && da && scratch384 && dW && db && dgamma && dbeta, MT_EINVAL, "mt_conv1_bwd: null pointer");
+    MT_REQUIRE(B > 0 && F >= 2 && T > 0 && ldc >= 32, MT_EINVAL, "mt_conv1_bwd: bad dims");
+    MT_CHECK_HIP(hipMemsetAsync(scratch384, 0, 384 * sizeof(double), ST(stream)));
+    const long long n = (long long)B * ((F + 1) / 2) * T;
+    long long g = (n + 256 * 8 - 1) / (256 * 8);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    double* sums = scratch384;
+    double* wacc = scratch384 + 64;
+    hipLaunchKernelGGL(conv1_bwd_kernel<false>, dim3((unsigned)g), dim3(256), 0, ST(stream), x, w, bias, mean, rstd, gamma, beta,
+                       (const bf16_t*)da, ldc, sums, wacc, B, F, T);
+    hipLaunchKernelGGL(conv1_bwd_kernel<true>, dim3((unsigned)g, 4), dim3(256), 0, ST(stream), x, w, bias, mean, rstd, gamma, beta,
+                       (const bf16_t*)da, ldc, sums, wacc, B, F, T);
+    hipLaunchKernelGGL(conv1_wgrad_out_kernel, dim3(1), dim3(320), 0, ST(stream), wacc, dW, db);
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(1), dim3(64), 0, ST(stream), sums, dgamma, dbeta, 32);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}

@@ -75,36 +75,32 @@ def _pad2(t, rows, cols):
 
 
 def _pack_bilstm(rnn: nn.LSTM, layers: int, H: int, k0_cols, dev):
-    """Pack a bidirectional nn.LSTM for mt_gemm_lstm_gx + mt_lstm_bidir_fwd.  The hidden size is laid out
-    padded to Hp = roundup(H, 16): a padded unit has zero weights and bias, so its gates are 0 and its c, h
-    stay 0.  Gate row p*Hp + j; directions stacked [fwd; reverse]; layer 0's columns are re-ordered by
-    `k0_cols` (index tensor: kernel column -> reference column); deeper layers take the compact
-    [fwd H | reverse H] rows padded to roundup(2H, 64) columns.  Returns (w_ih[], b_gates[], w_hh[])."""
+    """Pack a bidirectional nn.LSTM for mt_gemm_lstm_gx + mt_lstm_bidir_fwd (computed on `dev`: the training
+    step re-packs after every optimizer step).  The hidden size is laid out padded to Hp = roundup(H, 16): a
+    padded unit has zero weights and bias, so its gates are 0 and its c, h stay 0.  Gate row p*Hp + j;
+    directions stacked [fwd; reverse]; layer 0's columns are re-ordered by `k0_cols` (index tensor: kernel
+    column -> reference column); deeper layers take the compact [fwd H | reverse H] rows padded to
+    roundup(2H, 64) columns.  Returns (w_ih[], b_gates[], w_hh[])."""
     Hp = _round_up(H, 16)
     K1 = _round_up(2 * H, 64)
+    k0 = k0_cols.to(dev)
     w_ih, b_g, w_hh = [], [], []
     for l in range(layers):
-        wi, bb, wh = [], [], []
-        for suf in ("", "_reverse"):
-            w = getattr(rnn, f"weight_ih_l{l}{suf}").detach().float().cpu()
-            w = w[:, k0_cols] if l == 0 else w
-            K = w.shape[1]
-            wpad = torch.zeros(4, Hp, K)
-            wpad[:, :H] = w.reshape(4, H, K)
-            wi.append(wpad.reshape(4 * Hp, K))
-            b = (getattr(rnn, f"bias_ih_l{l}{suf}") + getattr(rnn, f"bias_hh_l{l}{suf}")).detach().float().cpu()
-            bpad = torch.zeros(4, Hp)
-            bpad[:, :H] = b.reshape(4, H)
-            bb.append(bpad.reshape(-1))
-            h = getattr(rnn, f"weight_hh_l{l}{suf}").detach().float().cpu()
-            hpad = torch.zeros(4, Hp, Hp)
-            hpad[:, :H, :H] = h.reshape(4, H, H)
-            wh.append(hpad.reshape(4 * Hp, Hp))
-        wcat = torch.cat(wi, 0)
-        Kp = wcat.shape[1] if l == 0 else K1
-        w_ih.append(_bf16(_pad2(wcat, _round_up(8 * Hp, 128), Kp)).to(dev))
-        b_g.append(torch.cat(bb).contiguous().to(dev))
-        w_hh.append(torch.stack(wh).contiguous().to(dev))
+        K = k0.numel() if l == 0 else 2 * H
+        Kp = K if l == 0 else K1
+        wcat = torch.zeros(_round_up(8 * Hp, 128), Kp, dtype=torch.float32, device=dev)
+        bcat = torch.zeros(2, 4, Hp, dtype=torch.float32, device=dev)
+        hcat = torch.zeros(2, 4, Hp, Hp, dtype=torch.float32, device=dev)
+        for di, suf in enumerate(("", "_reverse")):
+            w = getattr(rnn, f"weight_ih_l{l}{suf}").detach().to(dev, torch.float32)
+            w = w[:, k0] if l == 0 else w
+            wcat[di * 4 * Hp:(di + 1) * 4 * Hp].view(4, Hp, Kp)[:, :H, :K] = w.reshape(4, H, K)
+            b = (getattr(rnn, f"bias_ih_l{l}{suf}") + getattr(rnn, f"bias_hh_l{l}{suf}")).detach().to(dev, torch.float32)
+            bcat[di, :, :H] = b.reshape(4, H)
+            hcat[di, :, :H, :H] = getattr(rnn, f"weight_hh_l{l}{suf}").detach().to(dev, torch.float32).reshape(4, H, H)
+        w_ih.append(wcat.to(torch.bfloat16))
+        b_g.append(bcat.reshape(-1).contiguous())
+        w_hh.append(hcat.reshape(2, 4 * Hp, Hp).contiguous())
     return w_ih, b_g, w_hh
 
 
@@ -176,14 +172,20 @@ class CNNRNNModel(nn.Module, _HipForward):
 
     def forward(self, x, chunk_max_power: Optional[torch.Tensor] = None, check_status: bool = False, events=None):
         self._require_cuda(x)
-        if self.training or (torch.is_grad_enabled() and x.requires_grad):
-            raise NotImplementedError("the HIP path implements the eval-mode forward; the training step "
-                                      "(backward kernels) is not built yet -- call model.eval() / torch.no_grad()")
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.n_mels:
             raise ValueError(f"expected (B, 1, {self.n_mels}, T), got {tuple(x.shape)}")
         B, _, _, T = x.shape
         if T == 0:   # the reference's guard (cnn_rnn_model.py:65-66); its own conv raises before reaching it
             return torch.zeros(B, self.output_dim, 1, device=x.device)
+        if x.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the input mel are not implemented (the reference never asks for them)")
+        if self.training:
+            # train mode: BatchNorm batch statistics, LSTM dropout, activations saved, autograd edge to the HIP
+            # backward pass (train_step.py); under torch.no_grad() the same kernels run without the graph edge
+            if self.hidden_size > 512:
+                raise NotImplementedError("training: the backward recurrence kernel supports hidden_size <= 512")
+            from .train_step import train_forward
+            return train_forward(self, x)
         pk = self._ensure_packed(x.device)
         w = pk["struct"]
         x = x.contiguous().float()

@@ -1,0 +1,70 @@
+"""Training loop of the reference over the HIP training step.
+
+`train_one_epoch` / `evaluate` keep the reference's signatures and control flow
+(train/train_transcriber.py:90-158,:161-191): NaN/Inf-loss batches are skipped, more than 10 raise, a
+non-finite gradient norm skips the optimizer step, the epoch returns (mean loss, step losses).  Differences, all
+on the device side: no GradScaler (bf16 operands with f32 accumulation need no loss scaling), clip + Adam are
+ONE fused pass over a flat buffer (optim.FusedAdamClip), and with torch.distributed initialised the flat
+gradient is all-reduced (mean) over RCCL before the clip -- the data-parallel step of BASELINE config 4.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, List, Tuple
+
+import torch
+
+from .optim import FusedAdamClip, flatten_parameters
+
+
+def make_optimizer(model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-5,
+                   max_grad_norm: float = 1.0) -> FusedAdamClip:
+    """optim.Adam(model.parameters(), lr, eps=1e-8, weight_decay=1e-5) of scripts/train_cnn.py:290, fused with
+    clip_grad_norm_ (train_transcriber.py:134).  Parameters become views of one flat buffer."""
+    flat, grads = flatten_parameters(model.parameters())
+    return FusedAdamClip(flat, grads, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_grad_norm)
+
+
+def train_one_epoch(model, dataloader: Iterable, optimizer: FusedAdamClip, device, max_grad_norm: float = 1.0,
+                    log=None) -> Tuple[float, List[float]]:
+    if not isinstance(optimizer, FusedAdamClip):
+        raise TypeError("train_one_epoch drives the fused HIP optimizer: build it with make_optimizer(model, ...)")
+    model.train()
+    optimizer.max_norm = float(max_grad_norm)
+    total, step_losses, nan_count, n_batches = 0.0, [], 0, 0
+    for batch in dataloader:
+        n_batches += 1
+        optimizer.zero_grad()
+        mel, roll, lengths = batch
+        mel, roll = mel.to(device, non_blocking=True), roll.to(device, non_blocking=True)
+        logits = model(mel)
+        loss = model.compute_loss(logits, roll, lengths)
+        step_loss = float(loss.item())
+        if math.isnan(step_loss) or math.isinf(step_loss):
+            nan_count += 1
+            if nan_count > 10:
+                raise RuntimeError("Too many NaN losses - training unstable!")
+            continue
+        loss.backward()
+        stats = optimizer.step().tolist()              # {grad norm before clipping, 1.0 if the step was taken}
+        if stats[1] == 0.0:                            # non-finite gradient norm: step skipped on the device
+            nan_count += 1
+            continue
+        total += step_loss
+        step_losses.append(step_loss)
+        if log is not None:
+            log(len(step_losses), step_loss, stats[0])
+    avg = total / n_batches if step_losses else float("nan")
+    return avg, step_losses
+
+
+@torch.no_grad()
+def evaluate(model, dataloader: Iterable, device) -> float:
+    """Mean validation loss (train_transcriber.py:161-191)."""
+    model.eval()
+    total, n = 0.0, 0
+    for mel, roll, lengths in dataloader:
+        logits = model(mel.to(device, non_blocking=True))
+        total += float(model.compute_loss(logits, roll.to(device, non_blocking=True), lengths).item())
+        n += 1
+    return total / max(n, 1)

@@ -1,0 +1,274 @@
+"""Train-mode forward and backward of CNNRNNModel on the HIP library.
+
+What `loss.backward()` does in the reference's training loop (train/train_transcriber.py:104-131) for
+models/cnn_rnn_model.py:57-74 in train mode -- BatchNorm2d with batch statistics (running statistics updated),
+ReLU, MaxPool2d((2,1)), the 3-layer bidirectional nn.LSTM with inter-layer dropout, nn.Linear -- as a
+torch.autograd.Function whose forward and backward are sequences of libmt_hip.so launches (csrc/train.hip,
+lstm_bwd.hip, lstm.hip, gemm.hip, convg.hip, conv.hip).  torch only owns the buffers and the autograd graph edge.
+
+Numerics: GEMM/conv operands bf16, accumulation f32, LSTM state/gates f32 (the reference: fp16 autocast around
+convs/fc, fp32 LSTM), BatchNorm statistics f64-accumulated.  Dropout masks come from a counter-based hash seeded
+from torch's CPU generator (reproducible under torch.manual_seed; not bit-identical to cuDNN's Philox stream).
+
+One training step may be in flight per model: scratch buffers are cached per (B, T) and reused by the next call.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _ru(v: int, a: int) -> int:
+    return (v + a - 1) // a * a
+
+
+def _st():
+    return _lib.stream_ptr()
+
+
+def pack_train(model, dev) -> Dict[str, object]:
+    """Device-side operand layouts of the CURRENT parameters (re-done every step: the optimizer moves them)."""
+    from .model import _pack_bilstm
+    H, L, F = model.hidden_size, model.num_layers, model.n_mels
+    Hp, K1, Fo2 = _ru(H, 16), _ru(2 * H, 64), (F // 2) // 2
+    K0 = Fo2 * 64
+    f32 = dict(device=dev, dtype=torch.float32)
+    t: Dict[str, object] = {}
+    c1, bn1, c2, bn2 = model.cnn[0], model.cnn[1], model.cnn[4], model.cnn[5]
+    t["w1"] = c1.weight.detach().to(**f32).reshape(32, 9).contiguous()
+    t["b1"] = c1.bias.detach().to(**f32).contiguous()
+    w2 = c2.weight.detach().to(**f32)
+    t["w2"] = w2.permute(0, 2, 3, 1).reshape(64, 288).to(torch.bfloat16).contiguous()           # [co][tap*32 + ci]
+    t["b2"] = c2.bias.detach().to(**f32).contiguous()
+    wd = torch.zeros(64, 576, **f32)                                                             # dgrad: [ci (pad 64)][tap'*64 + co]
+    wd[:32] = w2.flip(2, 3).permute(1, 2, 3, 0).reshape(32, 576)
+    t["w2d"] = wd.to(torch.bfloat16)
+    t["zero64"] = torch.zeros(64, **f32)
+    for i, bn in ((1, bn1), (2, bn2)):
+        t[f"g{i}"] = bn.weight.detach().to(**f32).contiguous()
+        t[f"be{i}"] = bn.bias.detach().to(**f32).contiguous()
+    cols = (torch.arange(64)[None, :] * Fo2 + torch.arange(Fo2)[:, None]).reshape(-1)             # kernel col f*64+c -> ref col c*Fo2+f
+    t["w_ih"], t["b_g"], t["w_hh"] = _pack_bilstm(model.rnn, L, H, cols, dev)
+    t["w_ihT"] = []
+    for l in range(L):
+        K = K0 if l == 0 else K1
+        wT = torch.zeros(_ru(K, 128), 8 * Hp, device=dev, dtype=torch.bfloat16)
+        wT[:K] = t["w_ih"][l][:8 * Hp].t()
+        t["w_ihT"].append(wT)
+    fw = torch.zeros(128, K1, **f32)
+    fw[:88, :2 * H] = model.fc.weight.detach().to(**f32)
+    t["fc_w"] = fw.to(torch.bfloat16)
+    fwT = torch.zeros(_ru(K1, 128), 128, device=dev, dtype=torch.bfloat16)
+    fwT[:K1] = t["fc_w"].t()
+    t["fc_wT"] = fwT
+    t["fc_b"] = model.fc.bias.detach().to(**f32).contiguous()
+    t["dims"] = dict(H=H, Hp=Hp, L=L, F=F, F1=F // 2, Fo2=Fo2, K0=K0, K1=K1)
+    return t
+
+
+def _gemm(A, lda, W, ldw, C, ldc, M, N, K, bias=None):
+    check(lib.mt_gemm_bf16_f32acc(ptr(A), lda, ptr(W), ldw, ptr(bias), ptr(C), ldc, M, N, K, _st()), "mt_gemm_bf16_f32acc")
+
+
+def _gather4(src, src_off, dst, n, s, alpha=1.0):
+    """dst (contiguous, prod(n) elements) = alpha * src.flatten()[src_off + sum i_k s_k]"""
+    base = src.reshape(-1)[src_off:]
+    check(lib.mt_gather4_f32(ptr(base), ptr(dst), n[0], n[1], n[2], n[3], s[0], s[1], s[2], s[3], float(alpha), _st()), "mt_gather4_f32")
+
+
+def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
+    """Returns (logits (B,88,T) f32, saved state for backward_train).  Updates the BatchNorm running statistics."""
+    dev = x.device
+    B, _, F, T = x.shape
+    pk = pack_train(model, dev)
+    d = pk["dims"]
+    H, Hp, L, F1, K0, K1 = d["H"], d["Hp"], d["L"], d["F1"], d["K0"], d["K1"]
+    M, Mpad = T * B, _ru(T * B, 128)
+    x = x.contiguous().float()
+    bf = dict(device=dev, dtype=torch.bfloat16)
+    f32 = dict(device=dev, dtype=torch.float32)
+    sums = torch.zeros(512, device=dev, dtype=torch.float64)
+    sv: Dict[str, object] = {"pk": pk, "x": x, "B": B, "T": T, "dropout": dropout, "seed": seed}
+    bn1, bn2 = model.cnn[1], model.cnn[5]
+    with torch.cuda.device(dev):
+        # ---- conv1: batch statistics of the recomputed pre-BN activation, folded into the inference kernel's weights
+        mean1, rstd1 = torch.empty(32, **f32), torch.empty(32, **f32)
+        wf1, bf1 = torch.empty(32, 9, **f32), torch.empty(32, **f32)
+        check(lib.mt_conv1_stats(ptr(x), ptr(pk["w1"]), ptr(pk["b1"]), ptr(sums), B, F, T, _st()), "mt_conv1_stats")
+        check(lib.mt_bn_finalize(ptr(sums), float(B * F * T), ptr(pk["g1"]), ptr(pk["be1"]), ptr(bn1.running_mean), ptr(bn1.running_var),
+                                 BN_MOMENTUM, BN_EPS, ptr(mean1), ptr(rstd1), 32, ptr(pk["w1"]), ptr(pk["b1"]), ptr(wf1), ptr(bf1), 9, _st()),
+              "mt_bn_finalize")
+        a1 = torch.empty(B, F1, T, 32, **bf)
+        check(lib.mt_conv1_bn_relu_pool(ptr(x), None, ptr(wf1), ptr(bf1), ptr(a1), B, F, T, _st()), "mt_conv1_bn_relu_pool")
+        # ---- conv2: raw bf16 output -> statistics -> BN + ReLU + pool straight into the GEMM operand
+        z2 = torch.empty(B, F1, T, 64, **bf)
+        check(lib.mt_conv_cl_bf16(ptr(a1), None, ptr(pk["w2"]), ptr(pk["b2"]), ptr(z2), B, F1, T, 32, 0, 64, 3, 0, 0, 0, 0, _st()), "mt_conv_cl_bf16")
+        sums2 = sums[128:]
+        mean2, rstd2 = torch.empty(64, **f32), torch.empty(64, **f32)
+        check(lib.mt_bn_stats_cl(ptr(z2), B * F1 * T, 64, ptr(sums2), _st()), "mt_bn_stats_cl")
+        check(lib.mt_bn_finalize(ptr(sums2), float(B * F1 * T), ptr(pk["g2"]), ptr(pk["be2"]), ptr(bn2.running_mean), ptr(bn2.running_var),
+                                 BN_MOMENTUM, BN_EPS, ptr(mean2), ptr(rstd2), 64, None, None, None, None, 0, _st()), "mt_bn_finalize")
+        X0 = torch.zeros(Mpad, K0, **bf)
+        check(lib.mt_bn_relu_pool_apply(ptr(z2), ptr(mean2), ptr(rstd2), ptr(pk["g2"]), ptr(pk["be2"]), ptr(X0), K0, B, F1, T, _st()),
+              "mt_bn_relu_pool_apply")
+        sv.update(mean1=mean1, rstd1=rstd1, a1=a1, z2=z2, mean2=mean2, rstd2=rstd2)
+        # ---- LSTM layers
+        Xs: List[torch.Tensor] = [X0]
+        gates, cxs, hxs = [], [], []
+        sync = torch.empty(lib.mt_lstm_sync_bytes(B, Hp), device=dev, dtype=torch.uint8)
+        for l in range(L):
+            K = K0 if l == 0 else K1
+            gx = torch.empty(lib.mt_lstm_gx_bytes(B, T, Hp) // 4, **f32)
+            cx = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
+            hx = torch.empty(lib.mt_lstm_hx_bytes(B, T, Hp) // 4, **f32)
+            check(lib.mt_gemm_lstm_gx(ptr(Xs[l]), K, ptr(pk["w_ih"][l]), K, ptr(pk["b_g"][l]), ptr(gx), B, T, Hp, K, _st()), "mt_gemm_lstm_gx")
+            check(lib.mt_lstm_bidir_fwd_train(ptr(gx), ptr(pk["w_hh"][l]), ptr(hx), ptr(cx), ptr(sync), sync.numel(), B, T, Hp, _st()),
+                  "mt_lstm_bidir_fwd_train")
+            Xn = torch.zeros(Mpad, K1, **bf)
+            p = dropout if l < L - 1 else 0.0
+            check(lib.mt_lstm_relayout_train(ptr(hx), ptr(Xn), K1, B, T, Hp, H, float(p), seed, l, _st()), "mt_lstm_relayout_train")
+            gates.append(gx); cxs.append(cx); hxs.append(hx); Xs.append(Xn)
+        logits = torch.empty(B, 88, T, **f32)
+        check(lib.mt_gemm_logits(ptr(Xs[L]), K1, ptr(pk["fc_w"]), K1, ptr(pk["fc_b"]), ptr(logits), B, T, 88, K1, _st()), "mt_gemm_logits")
+    sv.update(Xs=Xs, gates=gates, cxs=cxs, hxs=hxs)
+    for bn in (bn1, bn2):
+        bn.num_batches_tracked += 1
+    return logits, sv
+
+
+def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict[str, torch.Tensor]:
+    """Gradients of every parameter (reference names without the `model.` prefix, reference shapes)."""
+    pk = sv["pk"]
+    d = pk["dims"]
+    H, Hp, L, F, F1, Fo2, K0, K1 = d["H"], d["Hp"], d["L"], d["F"], d["F1"], d["Fo2"], d["K0"], d["K1"]
+    B, T, x = sv["B"], sv["T"], sv["x"]
+    dev = x.device
+    M, Mpad = T * B, _ru(T * B, 128)
+    bf = dict(device=dev, dtype=torch.bfloat16)
+    f32 = dict(device=dev, dtype=torch.float32)
+    g: Dict[str, torch.Tensor] = {}
+    dlogits = dlogits.contiguous().float()
+    Xs = sv["Xs"]
+    with torch.cuda.device(dev):
+        # ---- fc: dW = dL^T X_L, db = sum dL, dX_L = dL W
+        dL, dLT = torch.zeros(Mpad, 128, **bf), torch.zeros(128, Mpad, **bf)
+        check(lib.mt_dlogits_pack(ptr(dlogits), ptr(dL), ptr(dLT), Mpad, B, 88, T, _st()), "mt_dlogits_pack")
+        Kmax = max(K0, K1)
+        XT = torch.empty(_ru(Kmax, 128) * Mpad, **bf)
+        check(lib.mt_transpose_bf16(ptr(Xs[L]), K1, M, K1, ptr(XT), Mpad, K1, _st()), "mt_transpose_bf16")
+        gfc = torch.empty(128, K1, **f32)
+        _gemm(dLT, Mpad, XT, Mpad, gfc, K1, 88, K1, Mpad)
+        g["fc.weight"] = torch.empty(88, 2 * H, **f32)
+        _gather4(gfc, 0, g["fc.weight"], (1, 1, 88, 2 * H), (0, 0, K1, 1))
+        g["fc.bias"] = torch.empty(88, **f32)
+        check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(g["fc.bias"]), 88, _st()), "mt_rowsum_bf16")
+        dXn = torch.empty(M, K1, **f32)
+        _gemm(dL, 128, pk["fc_wT"], 128, dXn, K1, M, K1, 128)
+        # ---- LSTM layers, top to bottom
+        sync = torch.empty(lib.mt_lstm_sync_bytes(B, Hp), device=dev, dtype=torch.uint8)
+        dh = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
+        dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
+        Hr = _ru(Hp, 128)
+        HT = torch.zeros(2 * Hr, Mpad, **bf)
+        gb = torch.empty(8 * Hp, **f32)
+        dX0 = None
+        for l in range(L - 1, -1, -1):
+            K = K0 if l == 0 else K1
+            p = sv["dropout"] if l < L - 1 else 0.0
+            check(lib.mt_lstm_dh_relayout(ptr(dXn), K1, ptr(dh), B, T, Hp, H, float(p), sv["seed"], l, _st()), "mt_lstm_dh_relayout")
+            check(lib.mt_lstm_bidir_bwd(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(sync), sync.numel(),
+                                        B, T, Hp, _st()), "mt_lstm_bidir_bwd")
+            dG, dGT = torch.zeros(Mpad, 8 * Hp, **bf), torch.zeros(_ru(8 * Hp, 128), Mpad, **bf)
+            check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * Hp, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
+            check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
+            check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XT), Mpad, K, _st()), "mt_transpose_bf16")
+            gwi = torch.empty(8 * Hp, K, **f32)
+            _gemm(dGT, Mpad, XT, Mpad, gwi, K, 8 * Hp, K, Mpad)
+            check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HT), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
+            gwh = torch.empty(2, 4 * Hp, Hp, **f32)
+            for di in range(2):
+                _gemm(dGT[di * 4 * Hp:], Mpad, HT[di * Hr:], Mpad, gwh[di], Hp, 4 * Hp, Hp, Mpad)
+            if l > 0:
+                _gemm(dG, 8 * Hp, pk["w_ihT"][l], 8 * Hp, dXn, K1, M, K1, 8 * Hp)
+            else:
+                dX0 = torch.empty(M, K0, **f32)
+                _gemm(dG, 8 * Hp, pk["w_ihT"][0], 8 * Hp, dX0, K0, M, K0, 8 * Hp)
+            for di, suf in enumerate(("", "_reverse")):
+                wi = torch.empty(4 * H, 64 * Fo2 if l == 0 else 2 * H, **f32)
+                if l == 0:
+                    _gather4(gwi, di * 4 * Hp * K, wi, (4, H, 64, Fo2), (Hp * K, K, 1, 64))
+                else:
+                    _gather4(gwi, di * 4 * Hp * K, wi, (4, H, 1, 2 * H), (Hp * K, K, 0, 1))
+                wh = torch.empty(4 * H, H, **f32)
+                _gather4(gwh, di * 4 * Hp * Hp, wh, (4, H, 1, H), (Hp * Hp, Hp, 0, 1))
+                bb = torch.empty(4 * H, **f32)
+                _gather4(gb, di * 4 * Hp, bb, (1, 1, 4, H), (0, 0, Hp, 1))
+                g[f"rnn.weight_ih_l{l}{suf}"], g[f"rnn.weight_hh_l{l}{suf}"] = wi, wh
+                g[f"rnn.bias_ih_l{l}{suf}"], g[f"rnn.bias_hh_l{l}{suf}"] = bb, bb.clone()
+        # ---- conv2: BN + ReLU + pool backward, dgrad (flipped-weight conv), wgrad (split-K GEMM over positions)
+        sums = torch.zeros(512, device=dev, dtype=torch.float64)
+        Npos = B * F1 * T
+        dz2, dz2lo = torch.empty(Npos, 64, **bf), torch.empty(Npos, 64, **bf)
+        g["cnn.5.weight"], g["cnn.5.bias"] = torch.empty(64, **f32), torch.empty(64, **f32)
+        check(lib.mt_bn_pool_bwd(ptr(dX0), K0, ptr(sv["z2"]), ptr(sv["mean2"]), ptr(sv["rstd2"]), ptr(pk["g2"]), ptr(pk["be2"]), ptr(sums),
+                                 ptr(dz2), ptr(dz2lo), ptr(g["cnn.5.weight"]), ptr(g["cnn.5.bias"]), B, F1, T, _st()), "mt_bn_pool_bwd")
+        da1 = torch.empty(B, F1, T, 64, **bf)
+        check(lib.mt_conv_cl_bf16(ptr(dz2), None, ptr(pk["w2d"]), ptr(pk["zero64"]), ptr(da1), B, F1, T, 64, 0, 64, 3, 0, 0, 0, 0, _st()),
+              "mt_conv_cl_bf16 (dgrad)")
+        n64 = (Npos + 63) // 64
+        S = max(1, min(256, n64 // 8))
+        Ks = 64 * ((n64 + S - 1) // S)
+        S = (n64 * 64 + Ks - 1) // Ks
+        Np = S * Ks
+        dz2T, colT = torch.zeros(2, 128, Np, **bf), torch.zeros(384, Np, **bf)      # dz2T[0] = hi piece, [1] = lo piece
+        check(lib.mt_transpose_bf16(ptr(dz2), 64, Npos, 64, ptr(dz2T[0]), Np, 64, _st()), "mt_transpose_bf16")
+        check(lib.mt_transpose_bf16(ptr(dz2lo), 64, Npos, 64, ptr(dz2T[1]), Np, 64, _st()), "mt_transpose_bf16")
+        check(lib.mt_im2col_t_3x3_c32(ptr(sv["a1"]), ptr(colT), Np, B, F1, T, _st()), "mt_im2col_t_3x3_c32")
+        P = torch.empty(2 * S, 64, 288, **f32)          # batch z = piece * S + slice
+        check(lib.mt_gemm_batched_f32(ptr(dz2T), Np, 128 * Np, Ks, ptr(colT), Np, 0, Ks, None, ptr(P), 288, S * 64 * 288, 64 * 288,
+                                      64, 288, Ks, 2 * S, S, _st()), "mt_gemm_batched_f32 (wgrad)")
+        gw2 = torch.empty(64, 288, **f32)
+        check(lib.mt_sum_slices_f32(ptr(P), 64 * 288, 288, 2 * S, ptr(gw2), 288, 64, 288, _st()), "mt_sum_slices_f32")
+        g["cnn.4.weight"] = torch.empty(64, 32, 3, 3, **f32)
+        _gather4(gw2, 0, g["cnn.4.weight"], (1, 64, 32, 9), (0, 288, 1, 32))
+        g["cnn.4.bias"] = torch.empty(64, **f32)
+        check(lib.mt_rowsum_bf16(ptr(dz2T[0]), Np, Npos, ptr(g["cnn.4.bias"]), 64, _st()), "mt_rowsum_bf16")
+        if debug is not None:
+            debug.update(dX0=dX0, dz2=dz2, dz2lo=dz2lo, da1=da1, gw2=gw2, P=P)
+        # ---- conv1 (z1 recomputed from the input)
+        g["cnn.0.weight"], g["cnn.0.bias"] = torch.empty(32, 1, 3, 3, **f32), torch.empty(32, **f32)
+        g["cnn.1.weight"], g["cnn.1.bias"] = torch.empty(32, **f32), torch.empty(32, **f32)
+        check(lib.mt_conv1_bwd(ptr(x), ptr(pk["w1"]), ptr(pk["b1"]), ptr(sv["mean1"]), ptr(sv["rstd1"]), ptr(pk["g1"]), ptr(pk["be1"]),
+                               ptr(da1), 64, ptr(sums[128:]), ptr(g["cnn.0.weight"]), ptr(g["cnn.0.bias"]), ptr(g["cnn.1.weight"]),
+                               ptr(g["cnn.1.bias"]), B, F, T, _st()), "mt_conv1_bwd")
+    return g
+
+
+class CnnRnnTrainFn(torch.autograd.Function):
+    """logits = CNNRNNModel(x) in train mode; backward returns the gradient of every parameter."""
+
+    @staticmethod
+    def forward(ctx, model, x, dropout, seed, names, *params):
+        logits, sv = forward_train(model, x, dropout, seed)
+        ctx.model, ctx.sv, ctx.names = model, sv, names
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        g = backward_train(ctx.model, ctx.sv, dlogits)
+        ctx.sv = None
+        return (None, None, None, None, None) + tuple(g[n] for n in ctx.names)
+
+
+def train_forward(model, x: torch.Tensor) -> torch.Tensor:
+    names = [n for n, _ in model.named_parameters()]
+    params = [p for _, p in model.named_parameters()]
+    p = float(model.rnn.dropout) if model.num_layers > 1 else 0.0
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0.0 else 0
+    return CnnRnnTrainFn.apply(model, x, p, seed, names, *params)

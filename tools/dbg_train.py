@@ -1,0 +1,66 @@
+"""Debug: intermediates of the HIP training step vs torch (CPU, f64) on the same tensors."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.nn.functional as F
+import music_transcription_amd as mta
+from music_transcription_amd import train_step as TS
+from oracle import model_ref as R
+
+nm, H, L, B, T = 64, 48, 2, 5, 21
+g = torch.Generator().manual_seed(9)
+mel = (torch.rand(B, 1, nm, T, generator=g) * 60.0 - 70.0 + 10.0 * torch.randn(B, 1, nm, 1, generator=g))
+g = torch.Generator().manual_seed(10)
+roll = (torch.rand(B, 88, T, generator=g) < 0.1).float()
+lengths = torch.tensor([max(1, T - 3 * (b % 4)) for b in range(B)])
+m = mta.TranscriptionModel(model_type="cnn_rnn", n_mels=nm, hidden_size=H, num_layers=L, dropout=0.0, device="cuda")
+sd = R.make_state_dict("cnn_rnn", nm, H, L, 77)
+m.load_state_dict(sd)
+m.train()
+logits, sv = TS.forward_train(m.model, mel.cuda(), 0.0, 0)
+logits.requires_grad_(True)
+m.compute_loss(logits, roll.cuda(), lengths).backward()
+dbg = {}
+grads = TS.backward_train(m.model, sv, logits.grad, dbg)
+torch.cuda.synchronize()
+F1, Fo2 = nm // 2, nm // 4
+a1 = sv["a1"].double().cpu().permute(0, 3, 1, 2)                # NCHW [B][32][F1][T]
+z2 = sv["z2"].double().cpu().permute(0, 3, 1, 2)                # [B][64][F1][T]
+dz = (dbg["dz2"].double() + dbg["dz2lo"].double()).cpu().reshape(B, F1, T, 64).permute(0, 3, 1, 2)
+# 1. wgrad from HIP's own dz and a1
+ap = F.pad(a1, (1, 1, 1, 1))
+dW = torch.zeros(64, 32, 3, 3, dtype=torch.float64)
+for kh in range(3):
+    for kw in range(3):
+        dW[:, :, kh, kw] = torch.einsum("bcft,bift->ci", dz, ap[:, :, kh:kh + F1, kw:kw + T])
+gw = grads["cnn.4.weight"].double().cpu()
+print("wgrad: HIP vs f64 from HIP dz,a1: max err %.3e  (max |dW| %.3e)" % ((gw - dW).abs().max(), dW.abs().max()))
+# 2. dz from HIP's dX0 and z2 via torch autograd of BN+relu+pool
+dX0 = dbg["dX0"].double().cpu()                                  # [M][K0], m = t*B+b, col fo*64+c
+dpool = dX0.reshape(T, B, Fo2, 64).permute(1, 3, 2, 0)            # [B][64][Fo2][T]
+zt = z2.clone().requires_grad_(True)
+y = F.batch_norm(zt, None, None, sd["model.cnn.5.weight"].double(), sd["model.cnn.5.bias"].double(), True, 0.1, 1e-5)
+h = R.pool_f2(torch.relu(y))
+(h * dpool).sum().backward()
+print("dz: HIP vs torch BN/relu/pool backward on HIP z2,dX0: max err %.3e (max |dz| %.3e)" % ((dz - zt.grad).abs().max(), zt.grad.abs().max()))
+# 3. dgrad
+w2 = sd["model.cnn.4.weight"].bfloat16().double()
+da_ref = F.conv_transpose2d(dbg["dz2"].double().cpu().reshape(B, F1, T, 64).permute(0, 3, 1, 2), w2, padding=1)
+da = dbg["da1"].double().cpu().permute(0, 3, 1, 2)[:, :32]
+print("dgrad: HIP vs torch conv_transpose: max err %.3e (max %.3e)" % ((da - da_ref).abs().max(), da_ref.abs().max()))
+# 4. oracle (emulated) gradient of conv2 weight for reference
+sdo = {k: v.clone() for k, v in sd.items()}
+keys = [k for k, v in sdo.items() if v.dtype.is_floating_point and "running_" not in k]
+for k in keys: sdo[k].requires_grad_(True)
+lo = R.cnnrnn_forward(sdo, mel, R.Opts(gemm_bf16=True), train=True)
+R.compute_loss(lo, roll, lengths).backward()
+ge = sdo["model.cnn.4.weight"].grad.double()
+print("conv2 wgrad: HIP vs emulated oracle: max err %.3e rel %.3e" % ((gw - ge).abs().max(), (gw - ge).abs().max() / ge.abs().max()))
+print("conv2 wgrad: f64-from-HIP-tensors vs emulated oracle: rel %.3e" % ((dW - ge).abs().max() / ge.abs().max()))
+err = (dz - zt.grad).abs()
+print("positions with err > 1e-6:", int((err > 1e-6).sum()), "of", err.numel())
+idx = torch.nonzero(err > 5e-6)[:8]
+for i in idx:
+    b_, c_, f_, t_ = [int(v) for v in i]
+    print((b_, c_, f_, t_), "hip %.3e ref %.3e" % (dz[b_, c_, f_, t_], zt.grad[b_, c_, f_, t_]), "y", float(y[b_, c_, f_, t_]), "pair y", float(y[b_, c_, f_ ^ 1, t_]),
+          "dpool", float(dpool[b_, c_, f_ // 2, t_]))
+print("sum dz per channel (hip/ref):", float(dz.sum((0, 2, 3)).abs().max()), float(zt.grad.sum((0, 2, 3)).abs().max()))
