@@ -114,6 +114,83 @@ def bench_large(args):
                       "model_tflops_per_s": round(flops * K / el / 1e12, 1), "finite": bool(torch.isfinite(out["frame"]).all())}))
 
 
+def bench_train(args):
+    """BASELINE.json configs[3]: chunked training of CNNRNNModel, batch 16 per GPU, data-parallel -- informational (not
+    the bench line).  Step = train-mode forward + masked BCE + backward (HIP kernels) + ONE all-reduce (mean) of the flat
+    gradient over RCCL + fused clip/Adam.  Inputs: cached-format batches, ragged T in [469, 937] right-padded with 0.0
+    (collate_fn semantics), Bernoulli(0.04) rolls; resident in HBM before the timed region."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    backend = os.environ.get("MT_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    import music_transcription_amd as mta
+    from oracle import model_ref
+    B, K, W, T = args.batch, args.steps, args.warmup, 937
+    g = torch.Generator().manual_seed(1234 + rank)
+    sd = model_ref.make_state_dict("cnn_rnn", N_MELS, HIDDEN, LAYERS, seed=0)
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=N_MELS, hidden_size=HIDDEN, num_layers=LAYERS, dropout=0.3, device=str(dev))
+    model.load_state_dict(sd, strict=True)
+    opt = mta.make_optimizer(model, lr=1e-4)
+    batches = []
+    for _ in range(2):
+        lengths = torch.randint(469, T + 1, (B,), generator=g)
+        lengths[0] = T
+        mel = torch.rand(B, 1, N_MELS, T, generator=g) * 60.0 - 70.0
+        roll = (torch.rand(B, 88, T, generator=g) < 0.04).float()
+        for b in range(B):
+            mel[b, :, :, lengths[b]:] = 0.0
+            roll[b, :, lengths[b]:] = 0.0
+        batches.append((mel.to(dev), roll.to(dev), lengths))
+    model.train()
+
+    def step(j):
+        mel, roll, lengths = batches[j % len(batches)]
+        opt.zero_grad()
+        loss = model.compute_loss(model(mel), roll, lengths)
+        loss.backward()
+        opt.step()                                   # all-reduce (mean) of the flat gradient, then clip + Adam
+        return loss
+    for j in range(W):
+        step(j)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(K):
+        loss = step(j)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    if rank == 0:
+        flops = 3.0 * 72.76e9 * B * world * T / 938.0
+        print(json.dumps({"metric": "30 s audio chunks/sec (CNNRNNModel training step)", "value": round(B * world * K / el, 2),
+                          "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / K, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "data": "synthetic",
+                          "config": {"workload": "CNNRNNModel training, batch=16/GPU cached-format chunks, data-parallel "
+                                                 "(BASELINE.json configs[3])", "batch_per_gpu": B, "frames": T,
+                                     "parallelism": f"dp{world} (one RCCL all-reduce of the flat gradient per step)"},
+                          "model_tflops_per_s": round(flops * K / el / 1e12, 1), "final_loss": round(float(loss.item()), 5)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +203,11 @@ def main():
     ap.add_argument("--model", choices=["cnn_rnn", "cnn_rnn_large"], default="cnn_rnn",
                     help="cnn_rnn = the bench line (BASELINE configs[1]); cnn_rnn_large = informational run of configs[2] "
                          "(use --batch 16): whole-step timing only")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = the bench line; train = informational run of configs[3] (use --batch 16 --steps 5)")
     args = ap.parse_args()
+    if args.mode == "train":
+        return bench_train(args)
     if args.model == "cnn_rnn_large":
         return bench_large(args)
 

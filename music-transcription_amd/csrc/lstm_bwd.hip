@@ -14,13 +14,15 @@
 // partial tiles summed through LDS, cell math lane-local with dc carried in registers.  The published images of ALL
 // steps are kept: they are dgates for the weight-gradient and input-gradient GEMMs (re-laid out by
 // lstm_dg_unpack_kernel).  K order of the dgates vector: k = 128 w' + 32 gate + u  (producer w', unit u).
-// Hand-off: sc1 stores, drain, workgroup barrier, replicated step flags (as lstm.hip); bounded spins.
+// Hand-off as in lstm.hip: sc1 stores, workgroup barrier (all stores ISSUED, not drained), replicated step flags; the
+// dgx buffer is poisoned (0xFF) before the launch and a consumer that still sees poison redoes its loads.  Bounded spins.
 #include "mt_common.h"
 
 namespace mt {
 
 constexpr int BPTT_SPIN_LIMIT_TICKS = 200000000;   // 2 s of the 100 MHz s_memrealtime clock
 constexpr int BW_FLAG_REPL = 8;
+constexpr unsigned DG_POISON = 0xFFFFFFFFu;        // two bf16 NaNs with all-ones payload: f32_to_bf16 never produces it
 
 struct LstmBwdArgs {
     const float* gates;   // [NG][T][2][NKB][4][8][32]
@@ -80,25 +82,36 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
 
     float carry[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // dc[t_next] * f[t_next]
     float ccur[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // What the cell math needs from the forward pass (activated gates, c of the forward pass's previous step, dh from
+    // above) does not depend on the recurrence: it is fetched ONE STEP AHEAD, right behind the gather loads of the
+    // current step, so its HBM latency hides under the MFMA chain / publish / next poll (loads return in order: issued
+    // before the gather it would sit in front of it on the critical path).
+    float gt[4][4], cprev[4], dhin[4];
+#define BPTT_FETCH(S_)                                                                                              \
+    do {                                                                                                            \
+        const int t_ = d ? (S_) : (T - 1 - (S_));                                                                   \
+        const int tp_ = d ? (t_ + 1) : (t_ - 1);                                                                    \
+        const size_t blk_ = ((size_t)t_ * 2 + d) * nkb + kb, blkp_ = ((size_t)tp_ * 2 + d) * nkb + kb;             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                             \
+            const int off_ = (4 * hh + e) * 32 + b;                                                                 \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) gt[p][e] = live ? gates_g[blk_ * 1024 + p * 256 + off_] : 0.0f; \
+            dhin[e] = live ? dh_g[blk_ * 256 + off_] : 0.0f;                                                        \
+            cprev[e] = (live && tp_ >= 0 && tp_ < T) ? cx_g[blkp_ * 256 + off_] : 0.0f;                             \
+        }                                                                                                           \
+    } while (0)
+    {
+        const size_t blk0 = ((size_t)(d ? 0 : T - 1) * 2 + d) * nkb + kb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ccur[e] = live ? cx_g[blk0 * 256 + (4 * hh + e) * 32 + b] : 0.0f;
+    }
+    BPTT_FETCH(0);
     for (int s = 0; s < T; ++s) {
         const int t = d ? s : (T - 1 - s);            // reverse of the forward processing order
         const int tn = d ? (t - 1) : (t + 1);         // the step processed just before this one
-        const int tp = d ? (t + 1) : (t - 1);         // the forward pass's previous step (source of c_prev)
-        // ---- everything the cell math needs from the forward pass (independent of the recurrence: issued first)
-        float gt[4][4], cprev[4], dhin[4];
-        {
-            const size_t blk = ((size_t)t * 2 + d) * nkb + kb;
-            const size_t blkp = ((size_t)tp * 2 + d) * nkb + kb;
+        // this step's operands (fetched during the previous step) move out of the prefetch registers
+        float g_i[4], g_f[4], g_g[4], g_o[4], c_prev[4], dh_in[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int off = (4 * hh + e) * 32 + b;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) gt[p][e] = live ? gates_g[blk * 1024 + p * 256 + off] : 0.0f;
-                dhin[e] = live ? dh_g[blk * 256 + off] : 0.0f;
-                if (s == 0) ccur[e] = live ? cx_g[blk * 256 + off] : 0.0f;
-                cprev[e] = (live && tp >= 0 && tp < T) ? cx_g[blkp * 256 + off] : 0.0f;
-            }
-        }
+        for (int e = 0; e < 4; ++e) { g_i[e] = gt[0][e]; g_f[e] = gt[1][e]; g_g[e] = gt[2][e]; g_o[e] = gt[3][e]; c_prev[e] = cprev[e]; dh_in[e] = dhin[e]; }
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -124,36 +137,64 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
             }
             __syncthreads();
             if (abort_s) return;                       // uniform: every wave of the workgroup leaves
+            // ---- gather dgates[t_next] and run the MFMA chain.  The flag is only a hint that the stores were issued
+            //      (no drain on the producer side): a word still holding the poison pattern has not landed -> redo.
             const int gbase = ((tn * 2 + d) * NW * 8) * 1024 + lane * 16;
+            long long t1 = 0;
+            for (unsigned it = 0;; ++it) {
+                u32x4 raw[NKSW_MAX];
 #pragma unroll
-            for (int i = 0; i < NKSW_MAX; ++i) {
-                if (i < nksw) {
-                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(drsrc, gbase + (wv * nksw + i) * 1024, 0, 16 /*sc1*/);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[i], __builtin_bit_cast(bf16x8, raw), acc, 0, 0, 0);
+                for (int i = 0; i < NKSW_MAX; ++i)
+                    raw[i] = (i < nksw) ? __builtin_amdgcn_raw_buffer_load_b128(drsrc, gbase + (wv * nksw + i) * 1024, 0, 16 /*sc1*/) : u32x4{0, 0, 0, 0};
+                __builtin_amdgcn_sched_barrier(0);
+                if (it == 0 && s + 1 < T) BPTT_FETCH(s + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                unsigned worst = 0;
+#pragma unroll
+                for (int i = 0; i < NKSW_MAX; ++i) {
+                    worst = max(max(worst, max(raw[i][0], raw[i][1])), max(raw[i][2], raw[i][3]));
+                    if (i < nksw) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[i], __builtin_bit_cast(bf16x8, raw[i]), acc, 0, 0, 0);
+                }
+                if (!__any(worst == DG_POISON)) break;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                if ((it & 255u) == 255u) {
+                    const long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t1 == 0) t1 = now;
+                    else if (now - t1 > BPTT_SPIN_LIMIT_TICKS) {
+                        if (lane == 0) {
+                            __hip_atomic_store(a.status, 0x40000000u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            abort_s = 1;
+                        }
+                        break;
+                    }
                 }
             }
+        } else if (T > 1) {
+            BPTT_FETCH(1);
         }
         // ---- sum the four K-slices through LDS; wave wv finishes rows (units) 8wv + 4hh + e
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4)
             *(f32x4*)(&red[wv][lane][4 * e4]) = f32x4{acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]};
         __syncthreads();
+        if (abort_s) return;                           // a payload spin gave up (status word says where)
         const f32x4 r0 = *(const f32x4*)(&red[0][lane][4 * wv]), r1 = *(const f32x4*)(&red[1][lane][4 * wv]);
         const f32x4 r2 = *(const f32x4*)(&red[2][lane][4 * wv]), r3 = *(const f32x4*)(&red[3][lane][4 * wv]);
         // ---- cell backward (lane-local)
         bf16_t o4[4][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float dhv = dhin[e] + ((r0[e] + r1[e]) + (r2[e] + r3[e]));
-            const float ig = gt[0][e], fg = gt[1][e], gg = gt[2][e], og = gt[3][e];
+            const float dhv = dh_in[e] + ((r0[e] + r1[e]) + (r2[e] + r3[e]));
+            const float ig = g_i[e], fg = g_f[e], gg = g_g[e], og = g_o[e];
             const float tc = tanh_fast(ccur[e]);
             const float dc = fmaf(dhv * og, 1.0f - tc * tc, carry[e]);
             float di = dc * gg * ig * (1.0f - ig);
-            float df = dc * cprev[e] * fg * (1.0f - fg);
+            float df = dc * c_prev[e] * fg * (1.0f - fg);
             float dgg = dc * ig * (1.0f - gg * gg);
             float dov = dhv * tc * og * (1.0f - og);
             carry[e] = dc * fg;
-            ccur[e] = cprev[e];
+            ccur[e] = c_prev[e];
             if (!live) { di = df = dgg = dov = 0.0f; carry[e] = 0.0f; }
             o4[0][e] = f32_to_bf16(di); o4[1][e] = f32_to_bf16(df); o4[2][e] = f32_to_bf16(dgg); o4[3][e] = f32_to_bf16(dov);
         }
@@ -173,9 +214,8 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
                 const u32x4 piece = *(const u32x4*)(&img[i >> 6][i & 63][0]);
                 __builtin_amdgcn_raw_buffer_store_b128(piece, drsrc, obase + i * 16, 0, 16 /*sc1: write-through*/);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's pieces have landed
         }
-        __syncthreads();                                // ... and so have everyone's: raise the step flag
+        __syncthreads();                                // every wave has ISSUED its pieces (no drain: see the gather): raise the step flag
         if (wv == 0 && lane < BW_FLAG_REPL)
             __hip_atomic_store(flags_all + lane * NW + w, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -313,6 +353,7 @@ extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const floa
     MT_REQUIRE(sync_bytes >= need, MT_EWORKSPACE, "mt_lstm_bidir_bwd: sync workspace %zu < %zu", sync_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, need, st));
+    MT_CHECK_HIP(hipMemsetAsync(dgx, 0xFF, mt_lstm_dgx_bytes(B, T, H), st));     // poison: see the hand-off note
     LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
     dim3 grid(NW, 2, NG);
     MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);

@@ -253,14 +253,27 @@ __global__ void sum_slices_kernel(const float* __restrict__ P, long long stride,
     out[(size_t)r * ldo + c] = acc;
 }
 
-// out[r] = sum_{c < n} A[r*ld + c]  (bf16 rows, one wave per row; bias gradients from the transposed operands)
+// out[r] += sum_{c < n} A[r*ld + c]  (bf16 rows; out zeroed by the host wrapper).  One wave per (row, 16K-column chunk),
+// 16-B loads, f32 atomics across a row's chunks (bias gradients from the transposed GEMM operands).
+constexpr int ROWSUM_CHUNK = 16384;
 __global__ void rowsum_bf16_kernel(const bf16_t* __restrict__ A, long long ld, long long n, float* __restrict__ out, int rows) {
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
+    const long long c0 = (long long)blockIdx.y * ROWSUM_CHUNK, c1 = c0 + ROWSUM_CHUNK < n ? c0 + ROWSUM_CHUNK : n;
+    const bf16_t* p = A + (size_t)row * ld;
     float s = 0.0f;
-    for (long long c = lane; c < n; c += 64) s += bf16_to_f32(A[(size_t)row * ld + c]);
+    for (long long c = c0 + lane * 8; c < c1; c += 512) {
+        if (c + 8 <= c1) {
+            const uint4 v = *(const uint4*)(p + c);
+            const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += __uint_as_float(u[i] << 16) + __uint_as_float(u[i] & 0xFFFF0000u);
+        } else {
+            for (long long cc = c; cc < c1; ++cc) s += bf16_to_f32(p[cc]);
+        }
+    }
     s = wave_sum(s);
-    if (lane == 0) out[row] = s;
+    if (lane == 0) atomicAdd(out + row, s);
 }
 
 // ------------------------------------------------------------------------------------------------ conv1 backward
@@ -456,8 +469,10 @@ extern "C" int mt_sum_slices_f32(const float* P, long long stride, int ldp, int 
 }
 
 extern "C" int mt_rowsum_bf16(const void* A, long long ld, long long n, float* out, int rows, mt_stream_t stream) {
-    MT_REQUIRE(A && out && rows > 0 && n > 0 && ld >= n, MT_EINVAL, "mt_rowsum_bf16: bad arguments");
-    hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ST(stream), (const bf16_t*)A, ld, n, out, rows);
+    MT_REQUIRE(A && out && rows > 0 && n > 0 && ld >= n && ld % 8 == 0, MT_EINVAL, "mt_rowsum_bf16: bad arguments (ld must be a multiple of 8)");
+    MT_CHECK_HIP(hipMemsetAsync(out, 0, rows * sizeof(float), ST(stream)));
+    hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(cdiv(rows, 4), (unsigned)((n + ROWSUM_CHUNK - 1) / ROWSUM_CHUNK)), dim3(256), 0, ST(stream),
+                       (const bf16_t*)A, ld, n, out, rows);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
