@@ -108,7 +108,8 @@ class _HipForward:
     """Mixin: packed-weight cache keyed on parameter versions + per-shape workspaces."""
 
     def _param_signature(self):
-        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        from .optim import WEIGHTS_EPOCH
+        return (WEIGHTS_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def _ensure_packed(self, device):
         sig = (str(device), self._param_signature())

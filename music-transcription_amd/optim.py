@@ -15,6 +15,11 @@ from . import _lib
 from ._lib import lib, check, ptr
 
 
+# Bumped by every in-place update of parameter memory that bypasses torch's version counters (the fused optimizer
+# writes through raw pointers): model._param_signature() includes it, so packed inference weights are rebuilt.
+WEIGHTS_EPOCH = [0]
+
+
 def flatten_parameters(params: Iterable[torch.nn.Parameter]):
     """Re-home parameters as views of one flat fp32 tensor; returns (flat_params, flat_grads) with p.grad views."""
     params = [p for p in params if p.requires_grad]
@@ -66,4 +71,5 @@ class FusedAdamClip:
             check(lib.mt_adam_clip_step(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), self.p.numel(), self.lr, self.betas[0],
                                         self.betas[1], self.eps, self.wd, self.max_norm, self.t, ptr(self.stats), ptr(self.ws),
                                         self.ws.numel(), _lib.stream_ptr()), "mt_adam_clip_step")
+        WEIGHTS_EPOCH[0] += 1
         return self.stats

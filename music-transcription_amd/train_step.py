@@ -73,6 +73,9 @@ def pack_train(model, dev) -> Dict[str, object]:
 
 
 def _gemm(A, lda, W, ldw, C, ldc, M, N, K, bias=None):
+    # the kernel reads whole 128-row tiles of both operands: the views handed in must cover them
+    assert A.numel() >= (_ru(M, 128) - 1) * lda + K and W.numel() >= (_ru(N, 128) - 1) * ldw + K, "GEMM operand smaller than its tiles"
+    assert C.numel() >= (M - 1) * ldc + N
     check(lib.mt_gemm_bf16_f32acc(ptr(A), lda, ptr(W), ldw, ptr(bias), ptr(C), ldc, M, N, K, _st()), "mt_gemm_bf16_f32acc")
 
 
@@ -184,7 +187,8 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             check(lib.mt_lstm_dh_relayout(ptr(dXn), K1, ptr(dh), B, T, Hp, H, float(p), sv["seed"], l, _st()), "mt_lstm_dh_relayout")
             check(lib.mt_lstm_bidir_bwd(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(sync), sync.numel(),
                                         B, T, Hp, _st()), "mt_lstm_bidir_bwd")
-            dG, dGT = torch.zeros(Mpad, 8 * Hp, **bf), torch.zeros(_ru(8 * Hp, 128), Mpad, **bf)
+            # dGT is also read as a GEMM A operand from row 4Hp (reverse direction): whole 128-row tiles must stay inside it
+            dG, dGT = torch.zeros(Mpad, 8 * Hp, **bf), torch.zeros(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
             check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * Hp, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
             check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
             check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XT), Mpad, K, _st()), "mt_transpose_bf16")

@@ -149,6 +149,62 @@ def test_training_loop_matches_reference_losses(mta, golden_dir):
         assert np.abs(a - b).max() <= 3.2 * float(g["lr"]) + 2e-3 * np.abs(b).max(), name
 
 
+def test_eval_after_training_uses_updated_weights(mta, golden_dir):
+    """The fused optimizer writes parameters through raw pointers: the packed inference weights must follow."""
+    g = np.load(os.path.join(golden_dir, "train_step.npz"))
+    nm, H, L, B, T, sw, sx, nb = [int(v) for v in g["cfg"]]
+    data = [(a.cuda(), b.cuda(), c) for a, b, c in _golden_batches(g)]
+    m, _ = _hip_model(mta, nm, H, L, sw)
+    x = data[0][0]
+    m.eval()
+    with torch.no_grad():
+        before = m(x).clone()
+    opt = mta.make_optimizer(m, lr=1e-2)
+    mta.train_one_epoch(m, data, opt, torch.device("cuda"))
+    m.eval()
+    with torch.no_grad():
+        after = m(x).clone()
+    assert (after - before).abs().max() > 1e-3
+    fresh = mta.TranscriptionModel(model_type="cnn_rnn", n_mels=nm, hidden_size=H, num_layers=L, device="cuda")
+    fresh.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    fresh.eval()
+    with torch.no_grad():
+        again = fresh(x)
+    assert torch.equal(after, again)
+    # and the oracle agrees on the trained weights
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = R.cnnrnn_forward(sd, x.cpu())
+    assert (after.cpu() - ref).abs().max() < LOGIT_TOL
+
+
+def test_train_cnn_script_two_epochs(mta, tmp_path):
+    """scripts/train_cnn.py on a tiny cache: runs, writes a reference-loadable checkpoint, loss goes down."""
+    import json
+    import subprocess
+    import sys
+    nm, T = 32, 40
+    cache = str(tmp_path / "cache")
+    for split, n in (("train", 8), ("validation", 3)):
+        for i in range(n):
+            mel = _mel_in(1, nm, T - (i % 3) * 5, 200 + i)[0]
+            roll = _roll_in(1, mel.shape[-1], 300 + i, 0.1)[0]
+            mta.write_cache_chunk(cache, split, i, mel, roll)
+        mta.write_cache_metadata(cache, split, [{} for _ in range(n)], n_mels=nm)
+    run = str(tmp_path / "run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "train_cnn.py"), "--cached_dir", cache, "--batch_size", "4",
+                        "--epochs", "3", "--lr", "3e-3", "--n_mels", str(nm), "--hidden_size", "16", "--num_layers", "2",
+                        "--dropout", "0.1", "--run_dir", run, "--save_every", "3", "--num_workers", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    hist = json.load(open(os.path.join(run, "history.json")))
+    assert len(hist) == 3 and hist[-1]["train_loss"] < hist[0]["train_loss"]
+    ck = torch.load(os.path.join(run, "checkpoints", "model_epoch_3.pth"))
+    man = R.make_state_dict("cnn_rnn", nm, 16, 2, 0)
+    assert set(ck) == set(man) and all(ck[k].shape == man[k].shape for k in man)
+
+
 @pytest.mark.parametrize("nm,H,L,B,T", [(40, 32, 3, 2, 33), (64, 48, 2, 5, 21), (32, 24, 1, 34, 12)])
 def test_train_grads_match_oracle_autograd(mta, nm, H, L, B, T):
     """Other shapes (padded hidden sizes, > 1 batch group, odd T) against torch autograd on the CPU oracle."""

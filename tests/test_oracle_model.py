@@ -147,3 +147,39 @@ def test_manifest_key_names(golden_dir):
         assert {k: list(v.shape) for k, v in sd.items()} == ent["keys"], key
     assert man["cnn_rnn:320:512:3"]["n_params"] == 35785368
     assert man["cnn_rnn_large:320:512:3"]["n_params"] == 89494088
+
+
+def test_oracle_training_step_pinned_by_reference_golden(golden_dir):
+    """oracle.model_ref.train_steps (train-mode forward, autograd, clip, Adam) against the REFERENCE's own gradients,
+    losses and post-step weights (tests/golden/train_step.npz, written by make_golden_train.py)."""
+    g = np.load(os.path.join(golden_dir, "train_step.npz"))
+    nm, H, L, B, T, sw, sx, nb = [int(v) for v in g["cfg"]]
+
+    def mel_in(seed):
+        gen = torch.Generator().manual_seed(seed)
+        return (torch.rand(B, 1, nm, T, generator=gen) * 60.0 - 70.0 + 10.0 * torch.randn(B, 1, nm, 1, generator=gen))
+
+    def roll_in(seed):
+        gen = torch.Generator().manual_seed(seed)
+        return (torch.rand(B, 88, T, generator=gen) < 0.1).float()
+    data = []
+    for k in range(nb):
+        mel, roll = mel_in(sx + k), roll_in(sx + 100 + k)
+        lengths = torch.tensor([T, T - 7, T - 15][:B], dtype=torch.int64)
+        for b in range(B):
+            mel[b, :, :, lengths[b]:] = 0.0
+            roll[b, :, lengths[b]:] = 0.0
+        data.append((mel, roll, lengths))
+    sd = R.make_state_dict("cnn_rnn", nm, H, L, sw)
+    losses, grads, gn, logits0 = R.train_steps(sd, data, lr=float(g["lr"]))
+    assert np.abs(np.array(losses) - g["losses"]).max() < 1e-6
+    assert abs(gn - float(g["gradnorm0"])) < 1e-6
+    assert np.abs(logits0.numpy() - g["logits0"]).max() < 1e-5
+    for k, v in grads.items():
+        assert np.abs(v.numpy() - g["grad::" + k]).max() < 1e-7, k
+    for k, v in sd.items():
+        if not v.dtype.is_floating_point:
+            assert int(v) == int(g["post::" + k]), k
+            continue
+        tol = 3.5e-4 if k.endswith("cnn.0.bias") or k.endswith("cnn.4.bias") else 5e-6   # zero-gradient biases: Adam amplifies rounding noise
+        assert np.abs(v.numpy() - g["post::" + k]).max() < tol, k
