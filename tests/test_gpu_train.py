@@ -344,3 +344,45 @@ def test_train_forward_with_dropout_runs_and_differs(mta):
     with torch.no_grad():
         e = m(x)
     assert torch.isfinite(e).all()
+
+
+def test_preprocess_and_cache_end_to_end(mta, tmp_path):
+    """scripts/preprocess_dataset.py path: synthetic MAESTRO-like tree (44.1 kHz stereo WAV + MIDI + csv) ->
+    cache -> the reader; mel equals the frontend on the resampled slice, labels come from the own MIDI reader."""
+    from scipy.io import wavfile
+    from music_transcription_amd import preprocess as P, transcribe as TR, midi as MD
+    from oracle import frontend_ref as FR
+    root = tmp_path / "maestro"
+    (root / "2004").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    rows = ["canonical_composer,canonical_title,split,year,midi_filename,audio_filename,duration"]
+    durs = {"a": 47.0, "b": 31.5, "c": 12.0}
+    for name, split in (("a", "train"), ("b", "train"), ("c", "validation")):
+        n = int(durs[name] * 44100)
+        t = np.arange(n) / 44100.0
+        sig = 0.3 * np.sin(2 * np.pi * 440.0 * t) * np.exp(-0.5 * (t % 2.0)) + 0.01 * rng.standard_normal(n)
+        wavfile.write(str(root / "2004" / f"{name}.wav"), 44100, (np.stack([sig, 0.5 * sig], 1) * 32767).astype(np.int16))
+        notes = [(69, s, s + 1.5) for s in np.arange(0.0, durs[name] - 2.0, 2.0)]
+        TR.write_midi(notes, str(root / "2004" / f"{name}.midi"))
+        rows.append(f"X,Y,{split},2004,2004/{name}.midi,2004/{name}.wav,{durs[name]}")
+    (root / "maestro-v3.0.0.csv").write_text("\n".join(rows) + "\n")
+    cache = str(tmp_path / "cache")
+    st = P.preprocess_and_cache(str(root), cache, 30.0, 0.0, 64, 16000, 512, "train")
+    # a: 0-30 and 30-47 (17 s >= 15 s); b: 0-30 only (1.5 s tail dropped)
+    assert st == {"cached": 3, "skipped": 0, "failed": 0}
+    assert P.preprocess_and_cache(str(root), cache, 30.0, 0.0, 64, 16000, 512, "train")["skipped"] == 3
+    assert P.preprocess_and_cache(str(root), cache, 30.0, 0.0, 64, 16000, 512, "validation")["cached"] == 0   # 12 s < 15 s
+    ds = mta.CachedMaestroDataset(cache, "train")
+    assert len(ds) == 3 and ds.metadata["n_mels"] == 64 and ds.metadata["chunks"][1]["start_sample"] == 480000
+    mel0, roll0 = ds[0]
+    mel1, roll1 = ds[1]
+    assert mel0.shape == (1, 64, 937) and roll0.shape == (88, 937)            # min(938, int(30*31.25)) frames
+    assert mel1.shape == (1, 64, 531) and roll1.shape == (88, 531)            # 17 s: min(1 + 272000//512, int(17*31.25))
+    y = TR.load_audio(str(root / "2004" / "a.wav"), 16000)
+    ref = FR.audio_to_mel_batch(y[None, :480000], 16000, 64, 512)[0, 0, :, :937]
+    assert np.abs(mel0[0].numpy() - ref).max() < 5e-2
+    # A4 (MIDI 69 -> row 48) sounds for 1.5 s out of every 2 s; nothing else does
+    on = roll0[48].numpy()
+    assert 0.70 < on[:-1].mean() < 0.80 and roll0.sum() == on.sum() and on[-1] == 0
+    m = MD.MidiFile(str(root / "2004" / "a.midi"))
+    assert np.array_equal(roll1.numpy(), MD.chunk_roll(m, 30.0, 47.0)[:, :531])
