@@ -102,11 +102,11 @@ int    mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const floa
 
 /* ------------------------------------------------------------------ bidirectional LSTM recurrence
  * nn.LSTM(batch_first, bidirectional) as the reference runs it (cnn_rnn_model.py:45-52,
- * :69-70): gate order i,f,g,o, zero initial state; fp32 state/gates/accumulation, W_hh h as a
- * split-precision bf16x3 product (fp32-equivalent to ~1e-6 per gate).  H % 16 == 0, H <= 1024.
- * w_hh = [fwd; reverse] x [4H][H] f32.  hx receives every step's h as bf16 hi/lo pieces in
- * the MFMA-operand layout hx[b/32][t][dir][k/16][hi|lo][((k/8)%2)*32 + b%32][k%8] (the hi
- * pieces are bf16(h), the next GEMM's operand).  sync_ws: mt_lstm_sync_bytes(); after the
+ * :69-70): gate order i,f,g,o, zero initial state; fp32 state/gates/accumulation, W_hh h on the
+ * f16 MFMA (W_hh and the exchanged h rounded to f16).  H % 16 == 0, H <= 1024.
+ * w_hh = [fwd; reverse] x [4H][H] f32.  hx receives every step's h as f16 in the MFMA-operand
+ * layout hx[b/32][t][dir][k/16][((k/8)%2)*32 + b%32][k%8] (mt_lstm_hx_bytes; typed float* here,
+ * read it through mt_lstm_relayout_* / mt_lstm_unpack_f32).  sync_ws: mt_lstm_sync_bytes(); after the
  * stream has drained its word 0 is 0 (ok), 1 + step (flag spin timed out) or
  * 0x40000000 + step (payload spin timed out).                                              */
 size_t mt_lstm_gx_bytes(int B, int T, int H);

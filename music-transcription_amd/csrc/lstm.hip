@@ -1,9 +1,11 @@
 // Bidirectional LSTM recurrence for gfx950 (persistent kernel).  The reference runs the LSTM in
 // fp32 (cnn_rnn_model.py:69-70; gate order i,f,g,o; zero initial state; the reverse direction
-// consumes t = T-1 .. 0).  Here state, gates and accumulation are fp32 and the W_hh h product is
-// split-precision bf16 ("bf16x3": W = Whi + Wlo, h = hhi + hlo, three MFMAs, dropped term
-// <= 2^-16 relative): fp32-equivalent to ~1e-6 on a gate, 5x fewer matrix-pipe cycles than the
-// f32-input MFMA, and the published h (hi piece) is already the next GEMM's bf16 operand.
+// consumes t = T-1 .. 0).  Here state, gates and accumulation are fp32; the W_hh h product runs on
+// v_mfma_f32_32x32x16_f16 with W_hh and the exchanged h rounded to f16 (11-bit significand: 8x finer
+// than the bf16 operands of the input projections around it; |h| < 1 and |W_hh| <= 1/sqrt(H) sit well
+// inside f16's range).  An earlier version exchanged h as two bf16 pieces and ran a 3-MFMA
+// split-precision product (fp32-equivalent): 2x the all-gather bytes and 3x the MFMAs for precision the
+// surrounding bf16 GEMMs cannot use -- 2.9 -> 2.5 us per step.
 //
 // One launch = one LSTM layer, both directions, all batch groups.  The input projections
 // W_ih x_t + b_ih + b_hh come from the GEMM (gemm.hip, EPI_LSTM_GX); this kernel does the
@@ -14,18 +16,18 @@
 // and keeps its 32 x H slice of W_hh in REGISTERS as MFMA A-operands for the whole sequence.
 // Per step every workgroup needs the full h_{t-1} (H x 32 batch, 64 KB at H = 512), produced
 // by all S workgroups of its direction: an all-gather through L2 per step.
-//   * v_mfma_f32_32x32x16_bf16 x 3 per 16-wide k-step: D[gate row][batch] += W[row][k] * h[k][batch],
+//   * v_mfma_f32_32x32x16_f16 per 16-wide k-step: D[gate row][batch] += W[row][k] * h[k][batch],
 //     K split over the 4 waves, partial tiles summed through LDS;
 //   * gate rows are ordered row = 8q + 4h + p  <->  unit 2q + h, gate p, so that after the
 //     cross-wave sum lane (batch b, half h) of wave q holds all four gates of ONE unit:
 //     the cell update is lane-local, c_t lives in a register;
-//   * h_t is published in the exact MFMA B-operand layout, as bf16 hi and lo pieces
-//     (hx[g][t][d][k-step][hi|lo][lane = (k half)*32 + batch][8 bf16], 1 KB per workgroup per
-//     step), so consumers fetch it with two 16-B loads per lane per k-step;
+//   * h_t is published in the exact MFMA B-operand layout, as f16
+//     (hx[g][t][d][k-step][lane = (k half)*32 + batch][8 f16], 512 B per workgroup per
+//     step), so consumers fetch it with one 16-B load per lane per k-step;
 //   * the published blocks of ALL steps are kept: they are the layer's output, re-laid out for
 //     the next GEMM by lstm_relayout_kernel, so nothing else is stored on the critical path and
 //     no slot is ever reused (no WAR hazard between steps).
-// Hand-off.  The workgroup's 1-KB block is assembled in LDS and written by ONE wave as one 16-B-per-lane sc1
+// Hand-off.  The workgroup's 512-B block is assembled in LDS and written by ONE wave as one 16-B-per-lane sc1
 // (write-through) store; its lanes 0..7 then store the monotonic step flag into 8 REPLICAS on separate cache
 // lines (relaxed, agent scope) -- WITHOUT draining the payload store first.  Consumers poll the replica
 // kb % 8 with ONE wave, one memory round trip per poll (all flags of the direction in one burst; the abort word
@@ -49,7 +51,7 @@ constexpr int LSTM_SPIN_LIMIT_TICKS = 200000000;   // 2 s of the 100 MHz s_memre
 struct LstmArgs {
     const float* gx;      // [NG][T][2][NKB][4][8][32]
     const float* w_hh;    // [2][4H][H]
-    float* hx;            // [NG][T][2][NKB][64][4]
+    float* hx;            // [NG][T][2][NKB/2][64][8] f16 (typed float* in the C ABI)
     unsigned* flags;      // [NG][2][NKB]   zeroed before every launch
     unsigned* status;     // [0] = abort/timeout word, zeroed before every launch
     int B, T, H;
@@ -81,12 +83,6 @@ __device__ unsigned long long mt_lstm_diag[1024][8];
 #define DIAG_STAMP(i) do { } while (0)
 #endif
 
-// split an fp32 value into two bf16 pieces: x ~= hi + lo with |x - hi - lo| <= 2^-17 |x|
-__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
-    hi = f32_to_bf16(x);
-    lo = f32_to_bf16(x - bf16_to_f32(hi));
-}
-
 // XCD = true: XCD-local hand-off.  The S = H/8 workgroups of one (direction, batch group) "lane" are made up of
 // workgroups that physically sit on ONE XCD: every workgroup reads its hardware XCC id, lanes are bound to XCC
 // ids, and a workgroup takes its slice index from an arrival ticket of its own XCD -- nothing is inferred from
@@ -100,7 +96,7 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
 template <int NKSW, bool XCD, bool TRAIN = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
 __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][64][20];       // [k-slice wave][lane][16 regs + pad]: 80-B lane stride, conflict-free b128
-    __shared__ __attribute__((aligned(16))) bf16_t hs[2][32][8];       // [hi|lo][batch][unit]
+    __shared__ __attribute__((aligned(16))) f16_t hs[32][8];           // [batch][unit]
 #ifdef MT_LSTM_LDS_PAD
     __shared__ char lds_pad[MT_LSTM_LDS_PAD];                          // experiment: inflate the LDS footprint
     if (threadIdx.x == 0) lds_pad[blockIdx.x & 1023] = 1;
@@ -127,32 +123,27 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
     const int b = lane & 31, hh = lane >> 5;
     const int Bg = min(32, a.B - g * 32);            // valid batch rows of this group
 
-    // ---- W_hh slice as MFMA A-operands (bf16 hi + lo): lane (row r, k half hh) holds
+    // ---- W_hh slice as MFMA A-operands (f16): lane (row r, k half hh) holds
     //      W[row][16 ks + 8 hh + j], j = 0..7; row r = 8q + 4h + p <-> unit 2q + h, gate p
     const int r = lane & 31, q = r >> 3, rh = (r >> 2) & 1, p = r & 3;
     const int wrow = p * H + kb * 8 + 2 * q + rh;
     const float* wsrc = a.w_hh + ((size_t)d * 4 * H + wrow) * H;
-    bf16x8 whi[NKSW], wlo[NKSW];
+    f16x8 w16[NKSW];
 #pragma unroll
     for (int i = 0; i < NKSW; ++i) {
         const int ks = wv * NKSW + i;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            bf16_t hi = 0, lo = 0;
-            if (ks < nks) split_bf16(wsrc[ks * 16 + 8 * hh + j], hi, lo);
-            whi[i][j] = (short)hi;
-            wlo[i][j] = (short)lo;
-        }
+        for (int j = 0; j < 8; ++j) w16[i][j] = (ks < nks) ? (f16_t)wsrc[ks * 16 + 8 * hh + j] : (f16_t)0.0f;
     }
 
     // this thread's cell: unit jl = 2*wv + hh of the workgroup, batch row b
     const int jl = 2 * wv + hh;
     float c = 0.0f;
-    const size_t gd_blocks = (size_t)T * 2 * nkb;                       // 1-KB blocks per batch group
+    const size_t gd_blocks = (size_t)T * 2 * nkb;                       // (t, d, kb) blocks per batch group: 4 KB of gx, 512 B of hx each
     const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
-    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 1024;
+    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
     // buffer resource over this group's hx (all t, both d): offsets stay < 2^31
-    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
     // step flags are kept in FLAG_REPL replicas on separate cache lines: a producer writes all replicas with one
     // wave instruction, a consumer polls the replica kb % FLAG_REPL, so each flag line has nkb / FLAG_REPL pollers
     // instead of nkb (loads that bypass the caches serialise at the line's home memory channel)
@@ -208,34 +199,23 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
             __syncthreads();
             DIAG_STAMP(1);
             if (abort_s) return;                       // uniform: every wave of the workgroup leaves
-            // ---- gather h_{t-1} (hi and lo pieces: two 16-B sc1 loads per lane per k-step) and run the
-            //      split-precision MFMA chain  W h ~= Whi hhi + Whi hlo + Wlo hhi  (f32 accumulate).
+            // ---- gather h_{t-1} (one 16-B sc1 load per lane per k-step) and run the f16 MFMA chain (f32 accumulate).
             //      A word still holding the poison pattern means its store has not landed: redo (rare, bounded).
-            const int hbase = ((tprev * 2 + d) * nkb) * 1024 + lane * 16;
+            const int hbase = ((tprev * 2 + d) * nkb) * 512 + lane * 16;
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
                 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-                u32x4 rhi[NKSW], rlo[NKSW];
+                u32x4 rh[NKSW];
 #pragma unroll
                 for (int i = 0; i < NKSW; ++i) {
                     const int ks = wv * NKSW + i;
-                    if (ks < nks) {
-                        rhi[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 2048, 0, 16 /*sc1*/);
-                        rlo[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 2048 + 1024, 0, 16 /*sc1*/);
-                    } else {
-                        rhi[i] = u32x4{0, 0, 0, 0};
-                        rlo[i] = u32x4{0, 0, 0, 0};
-                    }
+                    rh[i] = (ks < nks) ? __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 1024, 0, 16 /*sc1*/) : u32x4{0, 0, 0, 0};
                 }
                 unsigned worst = 0;
 #pragma unroll
                 for (int i = 0; i < NKSW; ++i) {
-                    worst = max(max(worst, max(rhi[i][0], rhi[i][1])), max(rhi[i][2], rhi[i][3]));
-                    worst = max(max(worst, max(rlo[i][0], rlo[i][1])), max(rlo[i][2], rlo[i][3]));
-                    const bf16x8 hhi = __builtin_bit_cast(bf16x8, rhi[i]), hlo = __builtin_bit_cast(bf16x8, rlo[i]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[i], hhi, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[i], hlo, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[i], hhi, acc, 0, 0, 0);
+                    worst = max(max(worst, max(rh[i][0], rh[i][1])), max(rh[i][2], rh[i][3]));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[i], __builtin_bit_cast(f16x8, rh[i]), acc, 0, 0, 0);
                 }
                 if (!__any(worst == H_POISON)) break;
 #pragma unroll
@@ -284,24 +264,21 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
         asm volatile("" :: "v"(hval));
 #endif
         DIAG_STAMP(4);
-        // ---- publish h as bf16 hi/lo pieces in the MFMA B-operand layout.  Units 8kb..8kb+7 are the k-half
-        //      (kb & 1) of k-step kb >> 1: lanes (kb&1)*32 + batch of the [64 lanes][8 bf16] hi block and of
-        //      the lo block.  The two 512-B pieces are assembled in LDS and written by ONE wave as a single
-        //      16-B-per-lane sc1 store (whole 128-B lines); being the only storing wave it also signals.
-        {
-            bf16_t hi, lo;
-            split_bf16(hval, hi, lo);
-            hs[0][b][jl] = hi;
-            hs[1][b][jl] = lo;
-        }
+        // ---- publish h as f16 in the MFMA B-operand layout.  Units 8kb..8kb+7 are the k-half (kb & 1) of k-step
+        //      kb >> 1: lanes (kb&1)*32 + batch of that k-step's [64 lanes][8 f16] block.  The 512-B piece is assembled
+        //      in LDS and written by the first 32 lanes of ONE wave as a single 16-B-per-lane sc1 store (whole 128-B
+        //      lines); being the only storing wave it also signals.
+        hs[b][jl] = (f16_t)hval;
         DIAG_STAMP(5);
         __syncthreads();                                          // pieces assembled; every wave is done with `red`
         if (wv == 0) {
             typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-            const u32x4 piece = *(const u32x4*)(&hs[hh][b][0]);    // lanes 0-31: hi, lanes 32-63: lo
-            const int hoff = ((t * 2 + d) * nkb) * 1024 + (kb >> 1) * 2048 + hh * 1024 + ((kb & 1) * 32 + b) * 16;
-            if (XCD) __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
-            else __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1: write-through*/);
+            const u32x4 piece = *(const u32x4*)(&hs[b][0]);
+            const int hoff = ((t * 2 + d) * nkb) * 512 + (kb >> 1) * 1024 + ((kb & 1) * 32 + b) * 16;
+            if (lane < 32) {
+                if (XCD) __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
+                else __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1: write-through*/);
+            }
 #ifdef MT_LSTM_DRAIN
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // classic form: the pieces have landed before the flag says so
 #endif
@@ -333,7 +310,7 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
 template <int NKSW>
 __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][32][64];       // [k-slice wave][M-tile*16 + reg][lane]
-    __shared__ __attribute__((aligned(16))) bf16_t hs[2][64][8];        // [hi|lo][(unit>>3)*32 + batch][unit & 7]
+    __shared__ __attribute__((aligned(16))) f16_t hs[64][8];            // [(unit>>3)*32 + batch][unit & 7]
     __shared__ int abort_s;
     __shared__ int ident_s[2];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -353,7 +330,7 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
     const int Bg = min(32, a.B - g * 32);
 
     const int r = lane & 31, q = r >> 3, rh = (r >> 2) & 1, p = r & 3;
-    bf16x8 whi[2][NKSW], wlo[2][NKSW];
+    f16x8 w16[2][NKSW];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int wrow = p * H + wg * 16 + m * 8 + 2 * q + rh;
@@ -362,20 +339,15 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
         for (int i = 0; i < NKSW; ++i) {
             const int ks = wv * NKSW + i;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bf16_t hi = 0, lo = 0;
-                if (ks < nks) split_bf16(wsrc[ks * 16 + 8 * hh + j], hi, lo);
-                whi[m][i][j] = (short)hi;
-                wlo[m][i][j] = (short)lo;
-            }
+            for (int j = 0; j < 8; ++j) w16[m][i][j] = (ks < nks) ? (f16_t)wsrc[ks * 16 + 8 * hh + j] : (f16_t)0.0f;
         }
     }
     const int jl = 2 * wv + hh;                         // unit inside an 8-unit half (M-tile m): unit = 8m + jl
     float c[2] = {0.0f, 0.0f};
     const size_t gd_blocks = (size_t)T * 2 * nkb;
     const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
-    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 1024;
-    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 1024), 0x00020000);
+    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
     unsigned* flags = a.flags + ((size_t)g * 2 + d) * FLAG_REPL * nkb;   // replica 0 of the lane's flags; the first nwg words are used
 
     for (int s = 0; s < T; ++s) {
@@ -416,34 +388,24 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
             }
             __syncthreads();
             if (abort_s) return;
-            const int hbase = ((tprev * 2 + d) * nkb) * 1024 + lane * 16;
+            const int hbase = ((tprev * 2 + d) * nkb) * 512 + lane * 16;
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
                 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-                u32x4 rhi[NKSW], rlo[NKSW];
+                u32x4 rh[NKSW];
 #pragma unroll
                 for (int i = 0; i < NKSW; ++i) {
                     const int ks = wv * NKSW + i;
-                    if (ks < nks) {
-                        rhi[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 2048, 0, 16 /*sc1: bypass L1, served by this XCD's L2*/);
-                        rlo[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 2048 + 1024, 0, 16);
-                    } else {
-                        rhi[i] = u32x4{0, 0, 0, 0};
-                        rlo[i] = u32x4{0, 0, 0, 0};
-                    }
+                    rh[i] = (ks < nks) ? __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 1024, 0, 16 /*sc1: bypass L1, served by this XCD's L2*/)
+                                       : u32x4{0, 0, 0, 0};
                 }
                 unsigned worst = 0;
 #pragma unroll
                 for (int i = 0; i < NKSW; ++i) {
-                    worst = max(max(worst, max(rhi[i][0], rhi[i][1])), max(rhi[i][2], rhi[i][3]));
-                    worst = max(max(worst, max(rlo[i][0], rlo[i][1])), max(rlo[i][2], rlo[i][3]));
-                    const bf16x8 hhi = __builtin_bit_cast(bf16x8, rhi[i]), hlo = __builtin_bit_cast(bf16x8, rlo[i]);
+                    worst = max(max(worst, max(rh[i][0], rh[i][1])), max(rh[i][2], rh[i][3]));
+                    const f16x8 hv = __builtin_bit_cast(f16x8, rh[i]);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[m][i], hhi, acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[m][i], hlo, acc[m], 0, 0, 0);
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi[m][i], hhi, acc[m], 0, 0, 0);
-                    }
+                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[m][i], hv, acc[m], 0, 0, 0);
                 }
                 if (!__any(worst == H_POISON)) break;
 #pragma unroll
@@ -480,31 +442,26 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
             c[m] = fmaf(fg, c[m], ig * gg);
             const float hval = og * tanhf_(c[m]);
-            bf16_t hi, lo;
-            split_bf16(hval, hi, lo);
-            hs[0][m * 32 + b][jl] = hi;                  // block lane = (k half = m)*32 + batch, element = unit & 7
-            hs[1][m * 32 + b][jl] = lo;
+            hs[m * 32 + b][jl] = (f16_t)hval;            // block lane = (k half = m)*32 + batch, element = unit & 7
         }
         __syncthreads();
         if (wv == 0) {
             typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-            const u32x4 phi = *(const u32x4*)(&hs[0][lane][0]);
-            const u32x4 plo = *(const u32x4*)(&hs[1][lane][0]);
-            const int hoff = ((t * 2 + d) * nkb) * 1024 + wg * 2048 + lane * 16;
-            __builtin_amdgcn_raw_buffer_store_b128(phi, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
-            __builtin_amdgcn_raw_buffer_store_b128(plo, hrsrc, hoff + 1024, 0, 0);
+            const u32x4 ph = *(const u32x4*)(&hs[lane][0]);
+            const int hoff = ((t * 2 + d) * nkb) * 512 + wg * 1024 + lane * 16;
+            __builtin_amdgcn_raw_buffer_store_b128(ph, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) *(volatile unsigned*)(flags + wg) = (unsigned)(s + 1);
         }
     }
 }
 
-// Layer output for (g, t, d): nks blocks of 2 KB: [hi | lo][lane = (k half)*32 + batch][8 bf16], k = 16 ks + 8 half + j.
-// hx -> X[(t*B + b)][d*H + k] bf16 (next layer's GEMM A matrix) = the hi pieces (bf16(h), round-to-nearest).
+// Layer output for (g, t, d): nks blocks of 1 KB: [lane = (k half)*32 + batch][8 f16], k = 16 ks + 8 half + j.
+// hx -> X[(t*B + b)][d*H + k] bf16 (next layer's GEMM A matrix), round-to-nearest.
 // H = layout hidden size (multiple of 16), Hv <= H = real hidden size (units >= Hv are zero padding and are
 // dropped), col_off = first column of this LSTM's features in a concatenated row.  Optionally also writes
-// the fp32 value hi + lo to Y (residual / LayerNorm input of the Large model).
-__global__ void lstm_relayout_kernel(const bf16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, float* __restrict__ Y, int ldy,
+// the value as fp32 to Y (residual / LayerNorm input of the Large model).
+__global__ void lstm_relayout_kernel(const f16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, float* __restrict__ Y, int ldy,
                                      int col_off, int B, int T, int H, int Hv) {
     const int nkb = H >> 3, nkv = (Hv + 7) >> 3;
     const size_t total = (size_t)T * B * 2 * nkv;
@@ -513,27 +470,24 @@ __global__ void lstm_relayout_kernel(const bf16_t* __restrict__ hx, bf16_t* __re
         const int d = (id / nkv) & 1;
         const size_t m = id / (2 * nkv);
         const int t = m / B, b = m - (size_t)t * B, g = b >> 5, bl = b & 31;
-        const bf16_t* src = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 512 + (size_t)(kb >> 1) * 1024 + ((kb & 1) * 32 + bl) * 8;
+        const f16_t* src = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 256 + (size_t)(kb >> 1) * 512 + ((kb & 1) * 32 + bl) * 8;
         const int c0 = col_off + d * Hv + kb * 8;
-        const uint4 hi = *(const uint4*)src;
+        const f16x8 h8 = *(const f16x8*)src;
         if (X) {
-            if ((c0 & 7) == 0 && kb * 8 + 8 <= Hv) *(uint4*)(X + m * ldx + c0) = hi;
-            else {
-                const bf16_t* e = (const bf16_t*)&hi;
-                for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) X[m * ldx + c0 + j] = e[j];
+            if ((c0 & 7) == 0 && kb * 8 + 8 <= Hv) {
+                *(uint4*)(X + m * ldx + c0) = make_uint4(pack_bf16x2((float)h8[0], (float)h8[1]), pack_bf16x2((float)h8[2], (float)h8[3]),
+                                                         pack_bf16x2((float)h8[4], (float)h8[5]), pack_bf16x2((float)h8[6], (float)h8[7]));
+            } else {
+                for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) X[m * ldx + c0 + j] = f32_to_bf16((float)h8[j]);
             }
         }
-        if (Y) {
-            const uint4 lo = *(const uint4*)(src + 512);
-            const bf16_t* eh = (const bf16_t*)&hi;
-            const bf16_t* el = (const bf16_t*)&lo;
-            for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) Y[m * ldy + c0 + j] = bf16_to_f32(eh[j]) + bf16_to_f32(el[j]);
-        }
+        if (Y)
+            for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) Y[m * ldy + c0 + j] = (float)h8[j];
     }
 }
 
-// hx -> y[b][t][d*H + k] f32 = hi + lo (the reference's batch_first LSTM output; tests and the Large model)
-__global__ void lstm_unpack_kernel(const bf16_t* __restrict__ hx, float* __restrict__ y, int B, int T, int H) {
+// hx -> y[b][t][d*H + k] f32 (the reference's batch_first LSTM output; tests and the Large model)
+__global__ void lstm_unpack_kernel(const f16_t* __restrict__ hx, float* __restrict__ y, int B, int T, int H) {
     const int nkb = H >> 3;
     const size_t total = (size_t)T * B * 2 * H;
     for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
@@ -541,9 +495,8 @@ __global__ void lstm_unpack_kernel(const bf16_t* __restrict__ hx, float* __restr
         const int d = (id / H) & 1;
         const size_t bt = id / (2 * H);
         const int t = bt % T, b = bt / T, g = b >> 5, bl = b & 31;
-        const bf16_t* blk = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 512 + (size_t)(k >> 4) * 1024;
-        const int e = (((k >> 3) & 1) * 32 + bl) * 8 + (k & 7);
-        y[id] = bf16_to_f32(blk[e]) + bf16_to_f32(blk[512 + e]);
+        const f16_t* blk = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 256 + (size_t)(k >> 4) * 512;
+        y[id] = (float)blk[(((k >> 3) & 1) * 32 + bl) * 8 + (k & 7)];
     }
 }
 
@@ -566,7 +519,7 @@ static int launch_rec(const LstmArgs& a, int ngroups, bool xcd, hipStream_t st) 
 using namespace mt;
 
 extern "C" size_t mt_lstm_gx_bytes(int B, int T, int H) { return (size_t)cdiv(B, 32) * T * 2 * (H >> 3) * 4096; }
-extern "C" size_t mt_lstm_hx_bytes(int B, int T, int H) { return (size_t)cdiv(B, 32) * T * 2 * (H >> 3) * 1024; }
+extern "C" size_t mt_lstm_hx_bytes(int B, int T, int H) { return (size_t)cdiv(B, 32) * T * 2 * (H >> 3) * 512; }
 extern "C" size_t mt_lstm_sync_bytes(int B, int H) { return align_up(256 + (size_t)cdiv(B, 32) * 2 * FLAG_REPL * (H >> 3) * 4, 256); }
 
 // One bidirectional LSTM layer's recurrence.  gx from mt_gemm_lstm_gx, w_hh = [fwd; reverse] (2 x 4H x H f32),
@@ -597,7 +550,7 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
                "mt_lstm_bidir_fwd: hidden size %d unsupported (multiple of 16, <= 1024)", H);
     MT_REQUIRE(sync_bytes >= mt_lstm_sync_bytes(B, H), MT_EWORKSPACE, "mt_lstm_bidir_fwd: sync workspace too small");
     const int nkb = H >> 3, ng = cdiv(B, 32);
-    MT_REQUIRE((size_t)T * 2 * nkb * 1024 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_bidir_fwd: T*H too large for one buffer descriptor");
+    MT_REQUIRE((size_t)T * 2 * nkb * 512 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_bidir_fwd: T*H too large for one buffer descriptor");
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
     MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
@@ -660,7 +613,7 @@ extern "C" int mt_lstm_relayout_ex(const float* hx, void* X, int ldx, float* Y, 
     MT_REQUIRE((!X || (ldx >= col_off + 2 * Hv && ldx % 8 == 0)) && (!Y || ldy >= col_off + 2 * Hv), MT_EINVAL, "mt_lstm_relayout_ex: bad leading dimension");
     const size_t total = (size_t)T * B * 2 * ((Hv + 7) >> 3);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(lstm_relayout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hx, (bf16_t*)X, ldx, Y, ldy,
+    hipLaunchKernelGGL(lstm_relayout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, Y, ldy,
                        col_off, B, T, H, Hv);
     MT_CHECK_LAUNCH();
     return MT_OK;
@@ -681,7 +634,7 @@ extern "C" int mt_lstm_unpack_f32(const float* hx, float* y, int B, int T, int H
     MT_REQUIRE(hx && y, MT_EINVAL, "mt_lstm_unpack_f32: null pointer");
     const size_t total = (size_t)T * B * 2 * H;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(lstm_unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hx, y, B, T, H);
+    hipLaunchKernelGGL(lstm_unpack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, y, B, T, H);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

@@ -250,20 +250,20 @@ __global__ __launch_bounds__(256) void lstm_dg_unpack_kernel(const bf16_t* __res
     }
 }
 
-// hx (hi pieces) -> HT[(d*rows_per_dir + k)*ld + t*B + b] = bf16(h^d at the forward pass's PREVIOUS step of t)[k][b]
+// hx (f16) -> HT[(d*rows_per_dir + k)*ld + t*B + b] = bf16(h^d at the forward pass's PREVIOUS step of t)[k][b]
 // (t-1 for the forward direction, t+1 for the reverse one; zero at the sequence boundary): the W operand of
 // dW_hh[d] = dG_d^T . Hprev_d
-__global__ __launch_bounds__(256) void lstm_hprevT_kernel(const bf16_t* __restrict__ hx, bf16_t* __restrict__ HT, long long ld,
+__global__ __launch_bounds__(256) void lstm_hprevT_kernel(const f16_t* __restrict__ hx, bf16_t* __restrict__ HT, long long ld,
                                                           int rows_per_dir, int B, int T, int H) {
     const int nkb = H >> 3;
     const int ks = blockIdx.x, t = blockIdx.y >> 1, d = blockIdx.y & 1, g = blockIdx.z;
     const int Bg = min(32, B - g * 32);
     const int tp = d ? (t + 1) : (t - 1);
     const bool have = tp >= 0 && tp < T;
-    const bf16_t* src = hx + ((((size_t)g * T + (have ? tp : 0)) * 2 + d) * nkb) * 512 + (size_t)ks * 1024;   // hi block of k-step ks
+    const f16_t* src = hx + ((((size_t)g * T + (have ? tp : 0)) * 2 + d) * nkb) * 256 + (size_t)ks * 512;   // block of k-step ks
     const int bb = threadIdx.x & 31;
     for (int kl = threadIdx.x >> 5; kl < 16; kl += 8) {
-        const bf16_t v = have ? src[((kl >> 3) * 32 + bb) * 8 + (kl & 7)] : (bf16_t)0;
+        const bf16_t v = have ? f32_to_bf16((float)src[((kl >> 3) * 32 + bb) * 8 + (kl & 7)]) : (bf16_t)0;
         if (bb < Bg) HT[((size_t)d * rows_per_dir + ks * 16 + kl) * ld + (size_t)t * B + g * 32 + bb] = v;
     }
 }
@@ -276,9 +276,9 @@ __device__ __forceinline__ bool dropout_keep(unsigned seed, unsigned layer, unsi
     return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
 }
 
-// hx (hi + lo pieces = f32-accurate h) -> X[(t*B+b)*ldx + d*Hv + j] bf16 with inverted dropout (nn.LSTM's
+// hx (f16 h) -> X[(t*B+b)*ldx + d*Hv + j] bf16 with inverted dropout (nn.LSTM's
 // inter-layer dropout; the mask is a counter-based hash of (seed, layer, element), regenerated in the backward pass)
-__global__ void lstm_relayout_train_kernel(const bf16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, int B, int T, int H, int Hv,
+__global__ void lstm_relayout_train_kernel(const f16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, int B, int T, int H, int Hv,
                                            float p, unsigned seed, unsigned layer) {
     const int nkb = H >> 3;
     const long long n = (long long)T * B * 2 * Hv;
@@ -287,9 +287,8 @@ __global__ void lstm_relayout_train_kernel(const bf16_t* __restrict__ hx, bf16_t
         const int col = (int)(i % (2 * Hv));
         const long long m = i / (2 * Hv);
         const int bq = (int)(m % B), t = (int)(m / B), d = col / Hv, jj = col - d * Hv, g = bq >> 5, bl = bq & 31;
-        const bf16_t* blk = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 512 + (size_t)(jj >> 4) * 1024;
-        const int e = (((jj >> 3) & 1) * 32 + bl) * 8 + (jj & 7);
-        float v = bf16_to_f32(blk[e]) + bf16_to_f32(blk[512 + e]);
+        const f16_t* blk = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 256 + (size_t)(jj >> 4) * 512;
+        float v = (float)blk[(((jj >> 3) & 1) * 32 + bl) * 8 + (jj & 7)];
         if (p > 0.0f) v = dropout_keep(seed, layer, (unsigned long long)i, p) ? v * scale : 0.0f;
         X[(size_t)m * ldx + col] = f32_to_bf16(v);
     }
@@ -378,7 +377,7 @@ extern "C" int mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, 
 extern "C" int mt_lstm_hprev_t(const float* hx, void* HT, long long ld, int rows_per_dir, int B, int T, int H, mt_stream_t stream) {
     MT_REQUIRE(hx && HT && B > 0 && T > 0 && H % 16 == 0 && rows_per_dir >= H && ld >= (long long)T * B, MT_EINVAL, "mt_lstm_hprev_t: bad arguments");
     hipLaunchKernelGGL(lstm_hprevT_kernel, dim3(H / 16, 2 * T, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)hx, (bf16_t*)HT, ld, rows_per_dir, B, T, H);
+                       (const f16_t*)hx, (bf16_t*)HT, ld, rows_per_dir, B, T, H);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
@@ -388,7 +387,7 @@ extern "C" int mt_lstm_relayout_train(const float* hx, void* X, int ldx, int B, 
     MT_REQUIRE(hx && X && B > 0 && T > 0 && H % 16 == 0 && Hv > 0 && Hv <= H && ldx >= 2 * Hv && p >= 0.0f && p < 1.0f, MT_EINVAL, "mt_lstm_relayout_train: bad arguments");
     long long g = ((long long)T * B * 2 * Hv + 255) / 256;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(lstm_relayout_train_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)hx, (bf16_t*)X, ldx, B, T, H, Hv, p, seed, layer);
+    hipLaunchKernelGGL(lstm_relayout_train_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, B, T, H, Hv, p, seed, layer);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

@@ -44,6 +44,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;    // MFMA A/B fragment (4 VGPRs)
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;  // f16 MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 

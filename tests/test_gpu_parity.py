@@ -108,6 +108,7 @@ def test_lstm_layer_matches_oracle(mta, B, T, H, K, mode):
     b_ih = [u(4 * H) for _ in range(2)]
     b_hh = [u(4 * H) for _ in range(2)]
     ref = torch.cat([R.lstm_dir(x, w_ih[d], w_hh[d], b_ih[d], b_hh[d], bool(d), R.Opts()) for d in range(2)], -1)
+    ref16 = torch.cat([R.lstm_dir(x, w_ih[d], w_hh[d], b_ih[d], b_hh[d], bool(d), R.Opts(lstm_f16=True)) for d in range(2)], -1)
     M = T * B
     Mp, Np = (M + 127) // 128 * 128, (8 * H + 127) // 128 * 128
     X = torch.zeros(Mp, K); X[:M] = x.transpose(0, 1).reshape(M, K)    # row m = t*B + b
@@ -125,17 +126,17 @@ def test_lstm_layer_matches_oracle(mta, B, T, H, K, mode):
     check(lib.mt_lstm_unpack_f32(ptr(hx), ptr(y), B, T, H, s))
     torch.cuda.synchronize()
     assert int(sync[:4].view(torch.int32).item()) == 0, "hand-off timeout"
-    err = (y.cpu() - ref).abs().max().item()
-    assert err < 2e-5, err
+    # against the oracle with the kernel's rounding points (W_hh, exchanged h -> f16): an f16 ulp of h (2^-11) at most
+    # where a rounding decision flips; against the fp32 LSTM of the reference: f16-operand noise, ~1e-3
+    err16, err = (y.cpu() - ref16).abs().max().item(), (y.cpu() - ref).abs().max().item()
+    assert err16 < 6e-4 and (y.cpu() - ref16).abs().mean().item() < 2e-5 and err < 2e-3, (err16, err)
     # next layer's A matrix
     K1 = (2 * H + 63) // 64 * 64
     X1 = torch.zeros(Mp, K1, dtype=torch.bfloat16, device="cuda")
     check(lib.mt_lstm_relayout_bf16(ptr(hx), ptr(X1), K1, B, T, H, s))
-    # X1 holds the hi pieces = bf16(h); y = hi + lo, so bf16(y) == hi except on exact rounding ties
+    # X1 = bf16(published f16 h), round-to-nearest-even
     want = y.transpose(0, 1).reshape(M, 2 * H)
-    got = X1[:M, :2 * H].float()
-    assert ((got - want).abs() <= 2.0 ** -8 * want.abs() + 1e-30).all()
-    assert (got.bfloat16() != want.bfloat16()).float().mean().item() < 1e-2
+    assert torch.equal(X1[:M, :2 * H], want.bfloat16())
 
 
 # ------------------------------------------------------------------ whole model

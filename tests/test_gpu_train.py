@@ -298,9 +298,7 @@ def test_dropout_mask_statistics_and_backward_consistency(mta):
     B, T, H = 3, 17, 32
     dev = "cuda"
     hx = torch.zeros(lib.mt_lstm_hx_bytes(B, T, H) // 4, device=dev)
-    # every h = 1.0 (bf16 hi = 0x3F80, lo = 0): fill hi pieces
-    raw = hx.view(torch.int16).view(-1, 1024)          # per k-step: 512 hi + 512 lo
-    raw[:, :512] = 0x3F80
+    hx.view(torch.int16).fill_(0x3C00)                 # every h = 1.0 (f16)
     M, K1 = T * B, 64
     st = _lib.stream_ptr()
     X = torch.zeros(M, K1, dtype=torch.bfloat16, device=dev)

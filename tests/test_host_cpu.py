@@ -41,7 +41,7 @@ def test_host_entry_points_without_gpu(mta):
     assert lib.mt_mel_num_frames(10, 0) == _lib_code("MT_EINVAL")
     assert lib.mt_mel_plan_bytes(320) > 3 * 8192 and lib.mt_mel_plan_bytes(0) == 0
     assert lib.mt_lstm_gx_bytes(32, 938, 512) == 938 * 2 * 64 * 4096
-    assert lib.mt_lstm_hx_bytes(33, 10, 256) == 2 * 10 * 2 * 32 * 1024
+    assert lib.mt_lstm_hx_bytes(33, 10, 256) == 2 * 10 * 2 * 32 * 512
     fb = np.zeros((4, 1025), np.float32)
     assert lib.mt_mel_filterbank_host(fb.ctypes.data, -1, 4) == _lib_code("MT_EINVAL")
     assert "bad arguments" in _lib.last_error()
