@@ -27,20 +27,18 @@
 //   * the published blocks of ALL steps are kept: they are the layer's output, re-laid out for
 //     the next GEMM by lstm_relayout_kernel, so nothing else is stored on the critical path and
 //     no slot is ever reused (no WAR hazard between steps).
-// Hand-off.  The workgroup's 512-B block is assembled in LDS and written by ONE wave as one 16-B-per-lane sc1
-// (write-through) store; its lanes 0..7 then store the monotonic step flag into 8 REPLICAS on separate cache
-// lines (relaxed, agent scope) -- WITHOUT draining the payload store first.  Consumers poll the replica
-// kb % 8 with ONE wave, one memory round trip per poll (all flags of the direction in one burst; the abort word
-// only every 16th poll), workgroup barrier, then every payload load is an sc1 buffer load (bypasses the per-CU L1,
-// which is never refreshed by other CUs' stores).  Two measured facts shape this:
-//   * loads that bypass the caches serialise at their line's home memory channel: with all 64 workgroups of a
-//     direction polling one flag line a step took 4.2 us, with 8 pollers per line 3.3 us (more replicas: no gain);
-//   * the flag is a HINT, not a release.  hx is filled with the poison pattern 0xFFFFFFFF (never a hidden state,
-//     |h| < 1) before every launch and a consumer that still sees a poisoned word redoes its loads: every word is
-//     written exactly once by one store, so it is either poison or final -- correctness never depends on the
-//     order in which the flag and the payload become visible.  Dropping the drain: 3.30 -> 3.05 us/step.
-// Every spin is bounded: on timeout the workgroup raises the abort word, which every other workgroup's spin also
-// watches, and all workgroups drain.
+// Hand-off (agent-scope variant, the default).  The workgroup's 512-B block is assembled in LDS and written by ONE
+// wave as one 16-B-per-lane sc1 (write-through) store -- and that is all the producer does: there is no flag.  hx is
+// filled with the poison pattern 0xFFFFFFFF (never a hidden state: |h| < 1, and 0xFFFF is an f16 NaN) before every
+// launch; every word is written exactly once by one store, so a consumer sees it either poisoned or final.  The
+// consumers' payload loads (sc1 buffer loads: they bypass the per-CU L1 and the non-coherent L2) ARE the poll: a wave
+// re-issues the loads of its k-steps until none shows poison.  Measured history of the step at H = 512, B = 32:
+//   * flag + drained payload, all 64 workgroups of a direction polling one flag line: 4.2 us; flag replicated over 8
+//     lines (loads that bypass the caches serialise at their line's home channel): 3.3 us;
+//   * flag stored right behind the payload without draining it (poison makes the order irrelevant): 3.05 us;
+//   * f16 exchange instead of two bf16 pieces: 2.45 us;  * no flag at all (one round trip instead of two): 1.88 us.
+// The XCD-local variants (plain stores into one XCD's L2) keep the replicated flags.  Every spin is bounded: on
+// timeout the workgroup raises the abort word, which every other workgroup's spin also watches, and all leave.
 #include "mt_common.h"
 #include <atomic>
 
@@ -72,7 +70,8 @@ constexpr unsigned H_POISON = 0xFFFFFFFFu;   // never the bit pattern of a hidde
 #ifndef MT_FLAG_REPL
 #define MT_FLAG_REPL 8
 #endif
-constexpr int FLAG_REPL = MT_FLAG_REPL;      // replicas of every step flag (see lstm_rec_kernel)
+constexpr int FLAG_REPL = MT_FLAG_REPL;      // replicas of every step flag (XCD-local variants)
+constexpr int PAYLOAD_POLL_SLEEP = 10;       // s_sleep units (64 clocks) before a step's first payload poll: 8..14 measured equal, 24+ slower
 
 // Diagnostic build only (-DMT_LSTM_DIAG): per-phase wall-clock shares of a step, accumulated by wave 0
 // lane 0 of every workgroup into mt_lstm_diag[workgroup][phase] (10 ns ticks).  Never in the shipped build.
@@ -169,7 +168,8 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
         if (s > 0) {
-            // ---- wait until every workgroup of this direction has published step s-1.  One round trip per
+            if (XCD) {
+            // ---- XCD-local variant: wait until every workgroup of this direction has published step s-1.  One round trip per
             //      poll: every lane loads one flag and, in the same burst, a second flag (H > 512) or the abort word.
             if (wv == 0) {
                 const unsigned* p1 = flags + (lane < nkb ? lane : nkb - 1);
@@ -199,6 +199,14 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
             __syncthreads();
             DIAG_STAMP(1);
             if (abort_s) return;                       // uniform: every wave of the workgroup leaves
+            } else {
+                // Agent-scope variant: NO flag wait.  The payload loads themselves are the poll -- a word that still holds the
+                // poison pattern has not been published (or has not landed) -- so a step costs one memory round trip after
+                // the producers' stores become visible instead of two (flag, then payload): 2.45 -> 1.88 us/step.  The short
+                // sleep keeps the first, certain-to-fail attempt (issued right behind this workgroup's own publish) off the
+                // fabric; every wave polls its own k-steps, the only workgroup barrier left is the LDS reduce.
+                __builtin_amdgcn_s_sleep(PAYLOAD_POLL_SLEEP);
+            }
             // ---- gather h_{t-1} (one 16-B sc1 load per lane per k-step) and run the f16 MFMA chain (f32 accumulate).
             //      A word still holding the poison pattern means its store has not landed: redo (rare, bounded).
             const int hbase = ((tprev * 2 + d) * nkb) * 512 + lane * 16;
@@ -220,6 +228,10 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
                 if (!__any(worst == H_POISON)) break;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                if (!XCD && (it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
+                    break;
+                }
                 if ((it & 255u) == 255u) {
                     const long long now = __builtin_amdgcn_s_memrealtime();
                     if (t1 == 0) t1 = now;
@@ -286,10 +298,7 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
             // of the payload sees the poison pattern in the words that have not landed and redoes its loads (every
             // word is written exactly once by one store, so it is either poison or final).  Measured 3.05 vs 3.30
             // us/step: the store round trip leaves the critical path.
-            if (lane < FLAG_REPL) {
-                if (XCD) *(volatile unsigned*)(flags_all + lane * nkb + kb) = (unsigned)(s + 1);   // plain store: stays in this XCD's L2
-                else __hip_atomic_store(flags_all + lane * nkb + kb, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            if (XCD && lane < FLAG_REPL) *(volatile unsigned*)(flags_all + lane * nkb + kb) = (unsigned)(s + 1);   // plain store: stays in this XCD's L2
         }
         DIAG_STAMP(6);
     }
