@@ -14,14 +14,15 @@
 // partial tiles summed through LDS, cell math lane-local with dc carried in registers.  The published images of ALL
 // steps are kept: they are dgates for the weight-gradient and input-gradient GEMMs (re-laid out by
 // lstm_dg_unpack_kernel).  K order of the dgates vector: k = 128 w' + 32 gate + u  (producer w', unit u).
-// Hand-off as in lstm.hip: sc1 stores, workgroup barrier (all stores ISSUED, not drained), replicated step flags; the
-// dgx buffer is poisoned (0xFF) before the launch and a consumer that still sees poison redoes its loads.  Bounded spins.
+// Hand-off as in lstm.hip: sc1 stores and nothing else on the producer side; the dgx buffer is poisoned (0xFF) before the
+// launch and the consumers' gather loads poll the poison pattern (no flags, one round trip per step).  Bounded spins.
 #include "mt_common.h"
 
 namespace mt {
 
 constexpr int BPTT_SPIN_LIMIT_TICKS = 200000000;   // 2 s of the 100 MHz s_memrealtime clock
-constexpr int BW_FLAG_REPL = 8;
+constexpr int BW_FLAG_REPL = 8;                    // (sizing of the sync block only: the hand-off uses no flags)
+constexpr int BPTT_POLL_SLEEP = 10;                // s_sleep units (64 clocks) before a step's first payload poll
 constexpr unsigned DG_POISON = 0xFFFFFFFFu;        // two bf16 NaNs with all-ones payload: f32_to_bf16 never produces it
 
 struct LstmBwdArgs {
@@ -75,8 +76,6 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
     const size_t dg_bytes = (size_t)T * 2 * NW * 8 * 1024;
     char* dgx_g = (char*)a.dgx + g * dg_bytes;
     const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dgx_g, 0, (int)dg_bytes, 0x00020000);
-    unsigned* flags_all = a.flags + ((size_t)g * 2 + d) * BW_FLAG_REPL * NW;
-    const unsigned* flags = flags_all + (w % BW_FLAG_REPL) * NW;
     if (tid == 0) abort_s = 0;
     __syncthreads();
 
@@ -116,29 +115,11 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
         if (s > 0) {
-            if (wv == 0) {
-                const unsigned* p1 = flags + (lane < NW ? lane : NW - 1);
-                long long t0 = 0;
-                bool ok = false;
-                for (unsigned it = 0;; ++it) {
-                    const unsigned v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all(v1 >= (unsigned)s)) { ok = true; break; }
-                    if ((it & 15u) == 15u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    if ((it & 255u) == 255u) {
-                        const long long now = __builtin_amdgcn_s_memrealtime();
-                        if (t0 == 0) t0 = now;
-                        else if (now - t0 > BPTT_SPIN_LIMIT_TICKS) {
-                            if (lane == 0) __hip_atomic_store(a.status, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-                if (!ok && lane == 0) abort_s = 1;
-            }
-            __syncthreads();
-            if (abort_s) return;                       // uniform: every wave of the workgroup leaves
-            // ---- gather dgates[t_next] and run the MFMA chain.  The flag is only a hint that the stores were issued
-            //      (no drain on the producer side): a word still holding the poison pattern has not landed -> redo.
+            // No flag wait (as lstm.hip): the gather below polls the poison pattern of the payload itself.  The short
+            // sleep keeps the certain-to-fail first attempt, issued right behind this workgroup's own publish, off the fabric.
+            __builtin_amdgcn_s_sleep(BPTT_POLL_SLEEP);
+            // ---- gather dgates[t_next] and run the MFMA chain: a word still holding the poison pattern has not been
+            //      published (or has not landed) -> redo the loads.
             const int gbase = ((tn * 2 + d) * NW * 8) * 1024 + lane * 16;
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
@@ -158,6 +139,10 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
                 if (!__any(worst == DG_POISON)) break;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
+                    break;
+                }
                 if ((it & 255u) == 255u) {
                     const long long now = __builtin_amdgcn_s_memrealtime();
                     if (t1 == 0) t1 = now;
@@ -215,9 +200,8 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b128(piece, drsrc, obase + i * 16, 0, 16 /*sc1: write-through*/);
             }
         }
-        __syncthreads();                                // every wave has ISSUED its pieces (no drain: see the gather): raise the step flag
-        if (wv == 0 && lane < BW_FLAG_REPL)
-            __hip_atomic_store(flags_all + lane * NW + w, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // no flag, no drain: consumers poll the payload (see the gather).  `img` is rewritten only after the next step's
+        // LDS-reduce barrier, which every wave reaches after these LDS reads.
     }
 }
 
