@@ -22,6 +22,7 @@
 //                  writes 32 consecutive batch entries (128 B).
 //   EPI_LOGITS   : out[b][n][t] (the reference's logits.transpose(1,2)), m = t*B + b.
 #include "mt_common.h"
+#include <stdlib.h>
 
 namespace mt {
 
@@ -40,6 +41,72 @@ struct GemmEpi {
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// Epilogue of ONE 32x32 accumulator tile whose first row / column is (mb, nb).  Unswapped: lane column = n, register
+// rows = m.  Swapped (EPI_LSTM_GX): lane column = m, register rows = n.
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile(const f32x16& acc, int mb, int nb, int r, int h, int M, int N, const GemmEpi& ep, float* outp) {
+    if (EPI == EPI_ROWMAJOR) {
+        const int n = nb + r;
+        const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < M && n < N) outp[(size_t)m * ep.ldc + n] = acc[e] + bv;
+        }
+    } else if (EPI == EPI_ROWMAJOR_BF16) {
+        const int n = nb + r;
+        const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
+        bf16_t* o = (bf16_t*)outp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
+            float v = acc[e] + bv;
+            if (ep.relu) v = fmaxf(v, 0.0f);
+            if (m < M && n < N) o[(size_t)m * ep.ldc + n] = f32_to_bf16(v);
+        }
+    } else if (EPI == EPI_LOGITS) {
+        // column n = head*88 + pitch (one head when N = 88): out[head][b][pitch][t]
+        const int n = nb + r;
+        const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
+        const int head = n / MT_N_PITCH, pit = n - head * MT_N_PITCH;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < M && n < N) {
+                const int t = m / ep.B, b = m - t * ep.B;
+                outp[(((size_t)head * ep.B + b) * MT_N_PITCH + pit) * ep.T + t] = acc[e] + bv;
+            }
+        }
+    } else {  // EPI_LSTM_GX (swapped): lane column = m, register rows = n
+        const int m = mb + r;
+        if (m < M) {
+            const int t = m / ep.B, b = m - t * ep.B, g = b >> 5, bl = b & 31;
+            const int H = ep.H, nkb = H >> 3;
+            const size_t tg = ((size_t)(g * ep.T + t) * 2) * nkb * 1024 + bl;       // gx block base of (g, t)
+            // the 32 rows of this tile share (direction, gate) when they do not straddle a multiple of H
+            const int d0 = nb / (4 * H), rem0 = nb - d0 * 4 * H, p0 = rem0 / H, jj0 = rem0 - p0 * H;
+            if (jj0 + 32 <= H && nb + 32 <= N) {
+                float* o = outp + tg + (size_t)d0 * nkb * 1024 + p0 * 256;
+                const float* bp = ep.bias + nb;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h, jj = jj0 + row;
+                    o[(size_t)(jj >> 3) * 1024 + (jj & 7) * 32] = acc[e] + bp[row];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (n < N) {
+                        const int d = n / (4 * H), rem = n - d * 4 * H, p = rem / H, jj = rem - p * H;
+                        outp[tg + ((size_t)(d * nkb + (jj >> 3)) * 4 + p) * 256 + (jj & 7) * 32] = acc[e] + ep.bias[n];
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
@@ -164,74 +231,147 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
 #undef MT_FRAG_READ
 #undef MT_MFMA4
 
-    // ---- epilogue.  acc[i][j]: M sub-tile i, N sub-tile j.  Unswapped: lane column = n, register rows = m.
-    //      Swapped: lane column = m, register rows = n.
+    // ---- epilogue.  acc[i][j]: M sub-tile i, N sub-tile j.
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int mb = m0 + wm * 64 + i * 32, nb = n0 + wn * 64 + j * 32;
-            if (EPI == EPI_ROWMAJOR) {
-                const int n = nb + r;
-                const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
+        for (int j = 0; j < 2; ++j) epilogue_tile<EPI>(acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, r, h, M, N, ep, outp);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs each = 4 x 2 MFMA tiles), one workgroup per CU
+// (128 KB of LDS: two K-tile buffers).  Same staging as gemm_kernel (LDS-DMA, source-side swizzle, one barrier per
+// K-tile, the next tile's DMA in flight under this tile's MFMAs), but a wave now feeds 8 MFMAs from 6 fragment reads
+// per 16-wide k-step (gemm_kernel: 4 from 4) and a K-tile carries 4x the MFMA work per barrier.  Rows past the
+// operands' readable extent (a_rows / w_rows = roundup(M or N, 128), the entry points' contract) are clamped to the last
+// readable row: they only feed outputs that are never stored.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int G256_LDS = 2 * (BM2 + BN2) * BK * 2;
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+                                                      int M, int N, int K, GemmEpi ep) {
+    constexpr bool SWAP = (EPI == EPI_LSTM_GX);
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    int m0, n0;
+    {
+        const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = (N + BN2 - 1) / BN2, total = tiles_m * tiles_n;
+        const int bid = blockIdx.x, xcd = bid & 7, q = total >> 3, rmd = total & 7;
+        const int pid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+        constexpr int GM = 4;                              // an XCD's 32 resident tiles: 4 tile rows x 8 tile columns
+        const int per_group = GM * tiles_n, grp = pid / per_group, first_m = grp * GM;
+        const int gm = min(GM, tiles_m - first_m), in_grp = pid - grp * per_group;
+        m0 = (first_m + in_grp % gm) * BM2;
+        n0 = (in_grp / gm) * BN2;
+    }
+    float* outp;
+    {
+        const int z1 = blockIdx.z / ep.zdiv, z2 = blockIdx.z - z1 * ep.zdiv;
+        A += (size_t)(z1 * ep.sA + z2 * ep.sA2);
+        W += (size_t)(z1 * ep.sW + z2 * ep.sW2);
+        const long long oc = z1 * ep.sC + z2 * ep.sC2;
+        outp = ep.out + (EPI == EPI_ROWMAJOR_BF16 ? oc / 2 : oc);
+    }
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wv >> 2, wn = wv & 3;
+    const int a_last = ((M + 127) & ~127) - 1, w_last = ((N + 127) & ~127) - 1;
+
+    typedef __attribute__((address_space(1))) const void gvoid_t;
+    typedef __attribute__((address_space(3))) void lvoid_t;
+    const int drow = lane >> 3, dslot = lane & 7;
+    // wave wv stages rows [32 wv, 32 wv + 32) of both 256-row tiles: 4 + 4 wave instructions of 1 KB per K-tile
+#define G2_DMA1(kt, buf, J)                                                                                   \
+    {                                                                                                         \
+        const int row_ = wv * 32 + (J) * 8 + drow;                                                            \
+        const int chunk_ = dslot ^ ((row_ >> 1) & 7);                                                         \
+        const bf16_t* ga_ = A + (size_t)min(m0 + row_, a_last) * lda + (size_t)(kt) * BK + chunk_ * 8;        \
+        const bf16_t* gw_ = W + (size_t)min(n0 + row_, w_last) * ldw + (size_t)(kt) * BK + chunk_ * 8;        \
+        char* la_ = smem2 + (buf) * (BM2 + BN2) * BK * 2 + (wv * 32 + (J) * 8) * 128;                         \
+        __builtin_amdgcn_global_load_lds((gvoid_t*)ga_, (lvoid_t*)la_, 16, 0, 0);                             \
+        __builtin_amdgcn_global_load_lds((gvoid_t*)gw_, (lvoid_t*)(la_ + BM2 * BK * 2), 16, 0, 0);            \
+    }
+#define G2_DMA(kt, buf) do { G2_DMA1(kt, buf, 0) G2_DMA1(kt, buf, 1) G2_DMA1(kt, buf, 2) G2_DMA1(kt, buf, 3) } while (0)
+#define G2_READ(S, as, ws, ks)                                                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
+        const int ra_ = wm * 128 + i_ * 32 + r;                                                                \
+        fa[S][i_] = *(const bf16x8*)((as) + ra_ * 128 + (swz(ra_, (ks) * 2 + h) << 4));                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                         \
+        const int rw_ = wn * 64 + j_ * 32 + r;                                                                 \
+        fb[S][j_] = *(const bf16x8*)((ws) + rw_ * 128 + (swz(rw_, (ks) * 2 + h) << 4));                        \
+    }
+#define G2_MFMA(S)                                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                       \
+            acc[i_][j_] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][j_], fa[S][i_], acc[i_][j_], 0, 0, 0) \
+                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i_], fb[S][j_], acc[i_][j_], 0, 0, 0);
+#define G2_COMPUTE(buf)                                                     \
+    do {                                                                    \
+        const char* as = smem2 + (buf) * (BM2 + BN2) * BK * 2;              \
+        const char* ws = as + BM2 * BK * 2;                                 \
+        G2_READ(0, as, ws, 0)                                               \
+        G2_READ(1, as, ws, 1)                                               \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        G2_MFMA(0)                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        G2_READ(0, as, ws, 2)                                               \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        G2_MFMA(1)                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        G2_READ(1, as, ws, 3)                                               \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        G2_MFMA(0)                                                          \
+        G2_MFMA(1)                                                          \
+    } while (0)
+
+    bf16x8 fa[2][4], fb[2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (m < M && n < N) outp[(size_t)m * ep.ldc + n] = acc[i][j][e] + bv;
-                }
-            } else if (EPI == EPI_ROWMAJOR_BF16) {
-                const int n = nb + r;
-                const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
-                bf16_t* o = (bf16_t*)outp;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    float v = acc[i][j][e] + bv;
-                    if (ep.relu) v = fmaxf(v, 0.0f);
-                    if (m < M && n < N) o[(size_t)m * ep.ldc + n] = f32_to_bf16(v);
-                }
-            } else if (EPI == EPI_LOGITS) {
-                // column n = head*88 + pitch (one head when N = 88): out[head][b][pitch][t]
-                const int n = nb + r;
-                const float bv = (ep.bias && n < N) ? ep.bias[n] : 0.0f;
-                const int head = n / MT_N_PITCH, pit = n - head * MT_N_PITCH;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (m < M && n < N) {
-                        const int t = m / ep.B, b = m - t * ep.B;
-                        outp[(((size_t)head * ep.B + b) * MT_N_PITCH + pit) * ep.T + t] = acc[i][j][e] + bv;
-                    }
-                }
-            } else {  // EPI_LSTM_GX (swapped): lane column = m, register rows = n
-                const int m = mb + r;
-                if (m < M) {
-                    const int t = m / ep.B, b = m - t * ep.B, g = b >> 5, bl = b & 31;
-                    const int H = ep.H, nkb = H >> 3;
-                    const size_t tg = ((size_t)(g * ep.T + t) * 2) * nkb * 1024 + bl;       // gx block base of (g, t)
-                    // the 32 rows of this tile share (direction, gate) when they do not straddle a multiple of H
-                    const int d0 = nb / (4 * H), rem0 = nb - d0 * 4 * H, p0 = rem0 / H, jj0 = rem0 - p0 * H;
-                    if (jj0 + 32 <= H && nb + 32 <= N) {
-                        float* o = outp + tg + (size_t)d0 * nkb * 1024 + p0 * 256;
-                        const float* bp = ep.bias + nb;
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int row = (e & 3) + 8 * (e >> 2) + 4 * h, jj = jj0 + row;
-                            o[(size_t)(jj >> 3) * 1024 + (jj & 7) * 32] = acc[i][j][e] + bp[row];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                            if (n < N) {
-                                const int d = n / (4 * H), rem = n - d * 4 * H, p = rem / H, jj = rem - p * H;
-                                outp[tg + ((size_t)(d * nkb + (jj >> 3)) * 4 + p) * 256 + (jj & 7) * 32] = acc[i][j][e] + ep.bias[n];
-                            }
-                        }
-                    }
-                }
-            }
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = K / BK;
+    G2_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 1 < nk) G2_DMA(kt + 1, 1);
+        G2_COMPUTE(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) G2_DMA(kt + 2, 0);
+            G2_COMPUTE(1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
+    }
+#undef G2_DMA
+#undef G2_DMA1
+#undef G2_COMPUTE
+#undef G2_READ
+#undef G2_MFMA
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) epilogue_tile<EPI>(acc[i][j], m0 + wm * 128 + i * 32, n0 + wn * 64 + j * 32, r, h, M, N, ep, outp);
+}
+
+template <int EPI>
+static int launch256(const bf16_t* a, int lda, const bf16_t* w, int ldw, int M, int N, int K, const GemmEpi& ep, hipStream_t st, int batch) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, BN2) * cdiv(M, BM2), 1, batch);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), G256_LDS, st, a, lda, w, ldw, M, N, K, ep);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
 }
 
 static int launch(int epi, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st, int batch = 1) {
@@ -240,6 +380,13 @@ static int launch(int epi, const void* A, int lda, const void* W, int ldw, int M
                "gemm: bad dims M=%d N=%d K=%d lda=%d ldw=%d (K must be a multiple of %d)", M, N, K, lda, ldw, BK);
     dim3 grid(cdiv(N, BN) * cdiv(M, BM), 1, batch);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
+    // big problems: the 256 x 256 tile (one workgroup per CU); MT_GEMM_TILE=128 in the environment keeps the small tile
+    static const bool allow256 = !(getenv("MT_GEMM_TILE") && atoi(getenv("MT_GEMM_TILE")) == 128);
+    if (allow256 && M >= 1024 && N >= 512 && N % 128 == 0 && (long long)cdiv(M, BM2) * cdiv(N, BN2) * batch >= 128) {
+        if (epi == EPI_ROWMAJOR) return launch256<EPI_ROWMAJOR>(a, lda, w, ldw, M, N, K, ep, st, batch);
+        if (epi == EPI_LSTM_GX) return launch256<EPI_LSTM_GX>(a, lda, w, ldw, M, N, K, ep, st, batch);
+        if (epi == EPI_ROWMAJOR_BF16) return launch256<EPI_ROWMAJOR_BF16>(a, lda, w, ldw, M, N, K, ep, st, batch);
+    }
     if (epi == EPI_ROWMAJOR) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     else if (epi == EPI_LSTM_GX) hipLaunchKernelGGL(gemm_kernel<EPI_LSTM_GX>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     else if (epi == EPI_ROWMAJOR_BF16) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR_BF16>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);

@@ -78,7 +78,8 @@ def test_audio_to_mel_dropin(mta):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 88, 1024), (4096, 4096, 512)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 88, 1024), (4096, 4096, 512),
+                                   (17000, 640, 192), (33000, 1024, 64)])     # the last three take the 256 x 256 tile
 def test_gemm_bf16(mta, M, N, K):
     from music_transcription_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator().manual_seed(M + N + K)
@@ -96,7 +97,7 @@ def test_gemm_bf16(mta, M, N, K):
 # ------------------------------------------------------------------ LSTM layer (input projection + recurrence)
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("B,T,H,K", [(2, 20, 16, 64), (5, 33, 32, 128), (32, 40, 512, 1024), (33, 12, 256, 192), (1, 50, 64, 64),
-                                     (150, 9, 64, 64)])
+                                     (150, 9, 64, 64), (32, 300, 512, 128)])    # the last: input projection on the 256 x 256 tile
 def test_lstm_layer_matches_oracle(mta, B, T, H, K, mode):
     from music_transcription_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator().manual_seed(B * 1000 + T * 10 + H)
