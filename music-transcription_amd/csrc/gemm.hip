@@ -306,6 +306,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                       \
             acc[i_][j_] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][j_], fa[S][i_], acc[i_][j_], 0, 0, 0) \
                                : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i_], fb[S][j_], acc[i_][j_], 0, 0, 0);
+    // raised wave priority around the MFMA groups: the SIMD's other wave gets the issue slots for its LDS reads and DMA
+    // in between (+6 % measured)
+#define G2_PRIO(x) __builtin_amdgcn_s_setprio(x);
 #define G2_COMPUTE(buf)                                                     \
     do {                                                                    \
         const char* as = smem2 + (buf) * (BM2 + BN2) * BK * 2;              \
@@ -313,16 +316,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
         G2_READ(0, as, ws, 0)                                               \
         G2_READ(1, as, ws, 1)                                               \
         __builtin_amdgcn_sched_barrier(0);                                  \
-        G2_MFMA(0)                                                          \
+        G2_PRIO(1) G2_MFMA(0) G2_PRIO(0)                                    \
         __builtin_amdgcn_sched_barrier(0);                                  \
         G2_READ(0, as, ws, 2)                                               \
         __builtin_amdgcn_sched_barrier(0);                                  \
-        G2_MFMA(1)                                                          \
+        G2_PRIO(1) G2_MFMA(1) G2_PRIO(0)                                    \
         __builtin_amdgcn_sched_barrier(0);                                  \
         G2_READ(1, as, ws, 3)                                               \
         __builtin_amdgcn_sched_barrier(0);                                  \
-        G2_MFMA(0)                                                          \
-        G2_MFMA(1)                                                          \
+        G2_PRIO(1) G2_MFMA(0) G2_PRIO(0)                                    \
+        G2_PRIO(1) G2_MFMA(1) G2_PRIO(0)                                    \
     } while (0)
 
     bf16x8 fa[2][4], fb[2][2];
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 #undef G2_COMPUTE
 #undef G2_READ
 #undef G2_MFMA
+#undef G2_PRIO
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
