@@ -332,3 +332,33 @@ def test_evaluate_and_tune_threshold(mta, tmp_path):
     best_t, best_f1 = ev.tune_threshold(model, ds, log=None)
     grid = ev.f1_at_thresholds(lr, np.arange(0.01, 0.995, 0.005)).mean(0)
     assert best_f1 >= grid.max() - 5e-3 and 0.01 <= best_t <= 0.99                       # coarse-to-fine finds the plateau
+
+
+# ------------------------------------------------------------------ BASELINE-size properties (no oracle needed at this size)
+def test_full_size_batch_independence_and_determinism(mta):
+    """configs[1] shape (B = 32 x 30 s, n_mels 320, hidden 512, 3 layers): chunks are independent data-parallel work, so
+    (i) a chunk's logits do not depend on what else is in the batch or where it sits in it, (ii) the forward is
+    run-to-run deterministic, (iii) mel + forward from waveforms equals forward of the separately computed mel."""
+    from oracle import frontend_ref as FR
+    sd = R.make_state_dict("cnn_rnn", 320, 512, 3, seed=0)
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=320, hidden_size=512, num_layers=3, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    wave = torch.from_numpy(FR.synth_audio(4, 480000, seed=77)).cuda()
+    wave = torch.cat([wave * s for s in (1.0, 0.5, 0.25, 0.9, 0.7, 0.6, 0.8, 0.3)], 0)          # 32 distinct chunks
+    fe = mta.MelFrontend(16000, 320, 512, "cuda")
+    mel, _ = fe(wave, clamp=True)
+    assert mel.shape == (32, 1, 320, 938)
+    with torch.no_grad():
+        full = model(mel).clone()
+        again = model(mel).clone()
+        assert torch.equal(full, again)                                               # (ii)
+        perm = torch.randperm(32, generator=torch.Generator().manual_seed(1)).cuda()
+        shuffled = model(mel[perm].contiguous())
+        assert torch.equal(shuffled, full[perm])                                      # (i) position in the batch
+        for k in (0, 13, 31):
+            alone = model(mel[k:k + 1].contiguous())
+            assert (alone[0] - full[k]).abs().max().item() < 1e-5                     # (i) batch composition (tile shapes differ)
+        sub = model(mel[:7].contiguous())
+        assert (sub - full[:7]).abs().max().item() < 1e-5
+    assert torch.isfinite(full).all() and full.shape == (32, 88, 938)
+    model.model.raise_on_handoff_timeout(32, 938)
