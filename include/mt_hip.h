@@ -223,6 +223,11 @@ size_t mt_cnnrnn_large_status_offset(const mt_cnnrnn_large_weights* w, int B, in
 int    mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power,
                                int B, int T, float* logits3, void* workspace, size_t workspace_bytes,
                                mt_stream_t stream);
+/* As above; with side_stream + two caller-owned hipEvent_t (all three non-NULL) the local LSTM branch runs on side_stream
+ * beside the main LSTM stack (fork after the CNN, join before the attention).                                        */
+int    mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power,
+                                  int B, int T, float* logits3, void* workspace, size_t workspace_bytes,
+                                  mt_stream_t stream, mt_stream_t side_stream, void* ev_fork, void* ev_join);
 
 /* ------------------------------------------------------------------ loss, prediction, F1
  * Masked BCE-with-logits (transcription_model.py:110-162,:196-217):

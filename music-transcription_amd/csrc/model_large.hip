@@ -28,7 +28,7 @@ size_t mt_lstm_sync_bytes(int, int);
 namespace mt {
 struct LargePlan {
     int F1, F2, F3, K0, K1, M, Mpad, Tr, Tp, Hp, Hlp, comb, Cp, Hs, dp, ld3, Ca;
-    size_t act1, r1a, r1, r2a, r2, x0, x1, gx, hx, sync, sync_stride, rb, r32, qkv, S, P, VT, ao, proj, ln, sh, total;
+    size_t act1, r1a, r1, r2a, r2, x0, x1, gx, hx, gx2, hx2, sync, sync_stride, rb, r32, qkv, S, P, VT, ao, proj, ln, sh, total;
 };
 static LargePlan lplan(const mt_cnnrnn_large_weights* w, int B, int T) {
     LargePlan p;
@@ -54,6 +54,8 @@ static LargePlan lplan(const mt_cnnrnn_large_weights* w, int B, int T) {
     p.x1 = take((size_t)p.Mpad * p.K1 * 2);
     p.gx = take(mt_lstm_gx_bytes(B, T, Hmax));
     p.hx = take(mt_lstm_hx_bytes(B, T, Hmax));
+    p.gx2 = take(mt_lstm_gx_bytes(B, T, p.Hlp));          // the local LSTM's own buffers: it may run beside the main stack
+    p.hx2 = take(mt_lstm_hx_bytes(B, T, p.Hlp));
     p.sync_stride = align_up(mt_lstm_sync_bytes(B, Hmax), 256);
     p.sync = take(p.sync_stride * (w->layers + 1));
     p.rb = take((size_t)p.Mpad * p.Cp * 2);
@@ -95,8 +97,12 @@ extern "C" size_t mt_cnnrnn_large_status_offset(const mt_cnnrnn_large_weights* w
 #define RUN(expr) do { int rc_ = (expr); if (rc_ != MT_OK) return rc_; } while (0)
 
 // logits3: [3][B][88][T] f32 (frame, onset, offset) when use_heads, else [1][B][88][T].
-extern "C" int mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
-                                       float* logits3, void* workspace, size_t workspace_bytes, mt_stream_t stream) {
+// side_stream / ev_fork / ev_join (all three, or all NULL): the local LSTM branch (projection, recurrence, re-layout) is
+// issued on side_stream between the two caller-owned events, beside the main LSTM stack -- both are latency-bound and
+// together use 192 of the 256 CUs.  Without them everything runs on `stream` in order.
+extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
+                                          float* logits3, void* workspace, size_t workspace_bytes, mt_stream_t stream,
+                                          mt_stream_t side_stream, void* ev_fork, void* ev_join) {
     RUN(check_large(w));
     MT_REQUIRE(mel && logits3 && workspace && B > 0 && T > 0, MT_EINVAL, "mt_cnnrnn_large_forward: bad arguments");
     const LargePlan p = lplan(w, B, T);
@@ -114,10 +120,17 @@ extern "C" int mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const f
     // ---- concatenated feature rows: bf16 GEMM operand (zero pad columns) + fp32 copy for the residual
     if (p.Cp != p.comb) MT_CHECK_HIP(hipMemsetAsync(ws + p.rb, 0, (size_t)p.Mpad * p.Cp * 2, st));
     if (p.K1 != 2 * Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, st));
-    // local LSTM (1 layer) -> columns [2H, 2H + 2Hl)
-    RUN(mt_gemm_lstm_gx(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx), B, T, p.Hlp, p.K0, stream));
-    RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->local_w_hh, (float*)(ws + p.hx), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode, stream));
-    RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, stream));
+    // local LSTM (1 layer) -> columns [2H, 2H + 2Hl); on the side stream when one is given
+    const bool fork = side_stream && ev_fork && ev_join;
+    mt_stream_t ls = fork ? side_stream : stream;
+    if (fork) {
+        MT_CHECK_HIP(hipEventRecord((hipEvent_t)ev_fork, st));
+        MT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, (hipEvent_t)ev_fork, 0));
+    }
+    RUN(mt_gemm_lstm_gx(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, ls));
+    RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode, ls));
+    RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx2), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, ls));
+    if (fork) MT_CHECK_HIP(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)side_stream));
     // main LSTM
     for (int l = 0; l < w->layers; ++l) {
         const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
@@ -128,6 +141,7 @@ extern "C" int mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const f
         if (l + 1 < w->layers) RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, stream));
         else RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, stream));
     }
+    if (fork) MT_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0));      // both column ranges of rb / r32 are complete
     const void* feat = ws + p.rb;            // [Mpad][Cp] bf16
     if (w->use_attention) {
         const int heads = w->heads, dp = p.dp;
@@ -156,4 +170,9 @@ extern "C" int mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const f
         return mt_gemm_logits(ws + p.sh, p.Hs, w->heads_w, p.Hs, w->heads_b, logits3, B, T, 3 * MT_N_PITCH, p.Hs, stream);
     }
     return mt_gemm_logits(feat, p.Cp, w->fc_w, p.Cp, w->fc_b, logits3, B, T, MT_N_PITCH, p.Cp, stream);
+}
+
+extern "C" int mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
+                                       float* logits3, void* workspace, size_t workspace_bytes, mt_stream_t stream) {
+    return mt_cnnrnn_large_forward_ex(w, mel, chunk_max_power, B, T, logits3, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr);
 }

@@ -377,9 +377,21 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
             self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         ws = self._ws[key]
         w.lstm_mode = lstm_mode(x.device)
+        # a side stream + fork/join events per caller stream: the local LSTM branch runs beside the main LSTM stack
+        if not hasattr(self, "_side"):
+            self._side = {}
+        if key[2] not in self._side:
+            with torch.cuda.device(x.device):
+                side = torch.cuda.Stream(device=x.device)
+                evs = (torch.cuda.Event(), torch.cuda.Event())
+                for e in evs:
+                    e.record()                       # creates the underlying hipEvent_t
+            self._side[key[2]] = (side, evs)
+        side, evs = self._side[key[2]]
         with torch.cuda.device(x.device):
-            check(lib.mt_cnnrnn_large_forward(w, ptr(x), ptr(chunk_max_power), B, T, ptr(out), ptr(ws), ws.numel(),
-                                              _lib.stream_ptr()), "mt_cnnrnn_large_forward")
+            check(lib.mt_cnnrnn_large_forward_ex(w, ptr(x), ptr(chunk_max_power), B, T, ptr(out), ptr(ws), ws.numel(),
+                                                 _lib.stream_ptr(), side.cuda_stream, evs[0].cuda_event, evs[1].cuda_event),
+                  "mt_cnnrnn_large_forward")
         if check_status:
             self.raise_on_handoff_timeout(B, T)
         if heads_out and return_all_heads:
