@@ -1,0 +1,44 @@
+"""Data-parallel training rehearsal: N ranks (torch.distributed.run), each with its own batches, one all-reduce (mean) of
+the flat gradient per step; prints a checksum of the parameters per rank -- they must agree.  Backend: RCCL ("nccl") with
+one GPU per rank, or MT_BENCH_BACKEND=gloo with all ranks on the visible GPU(s) (rehearsal on a one-GPU box)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+backend = os.environ.get("MT_BENCH_BACKEND", "nccl")
+dev_index = local if backend == "nccl" else local % max(torch.cuda.device_count(), 1)
+torch.cuda.set_device(dev_index)
+dev = torch.device("cuda", dev_index)
+if backend == "nccl":
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+else:
+    dist.init_process_group(backend, rank=rank, world_size=world)
+import music_transcription_amd as mta
+from oracle import model_ref
+
+nm, H, L, B, T = 32, 16, 2, 3, 40
+model = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=H, num_layers=L, dropout=0.0, device=str(dev))
+model.load_state_dict(model_ref.make_state_dict("cnn_rnn", nm, H, L, seed=21))
+opt = mta.make_optimizer(model, lr=1e-3)
+g = torch.Generator().manual_seed(1000 + rank)                      # different data on every rank
+batches = []
+for _ in range(3):
+    mel = torch.rand(B, 1, nm, T, generator=g) * 60.0 - 70.0
+    roll = (torch.rand(B, 88, T, generator=g) < 0.1).float()
+    batches.append((mel, roll, torch.tensor([T, T - 5, T - 11])))
+avg, losses = mta.train_one_epoch(model, batches, opt, dev)
+flat = torch.cat([p.detach().reshape(-1).double() for p in model.parameters()])
+mine = torch.tensor([flat.sum().item(), flat.abs().sum().item(), (flat * torch.arange(flat.numel(), device=dev)).sum().item()], dtype=torch.float64)
+where = dev if backend == "nccl" else torch.device("cpu")
+mine = mine.to(where)
+allv = [torch.zeros(3, dtype=torch.float64, device=where) for _ in range(world)]
+dist.all_gather(allv, mine)
+if rank == 0:
+    same = all(torch.equal(allv[0].cpu(), v.cpu()) for v in allv)
+    print(json.dumps({"world": world, "identical_parameters": bool(same), "losses_rank0": losses, "checksum": allv[0].tolist()}))
+dist.destroy_process_group()
