@@ -22,7 +22,8 @@ GRAD_REL_FP32 = 1e-1   # the same against the fp32 reference (bf16 activations f
 # tie) move it by up to ~15 % of its largest entry at these tiny shapes; against the oracle with the same rounding
 # points it agrees to GRAD_REL like every other tensor.
 GRAD_REL_FP32_BY_KEY = {"model.cnn.4.weight": 2e-1}
-GRAD_COS = 0.9995      # cosine of the flat gradient (either reference)
+GRAD_COS = 0.9995      # cosine of the flat gradient against the oracle with the same rounding points
+GRAD_COS_FP32 = 0.998  # ... against the fp32 reference (tiny shapes: a few hundred positions per channel)
 LOGIT_TOL = 3e-2
 ZERO_GRAD_KEYS = ("cnn.0.bias", "cnn.4.bias")   # conv bias in front of BatchNorm: analytically zero gradient
 
@@ -110,7 +111,7 @@ def test_train_step_matches_reference_golden(mta, golden_dir):
     assert set(ref) == set(grads)
     worst, cos = _compare_grads(grads, ref)
     bad = {k: v for k, v in worst.items() if v > GRAD_REL_FP32_BY_KEY.get(k, GRAD_REL_FP32)}
-    assert not bad and cos > GRAD_COS, (bad, cos)
+    assert not bad and cos > GRAD_COS_FP32, (bad, cos)
     _, ref_emu = _oracle_grads(R.make_state_dict("cnn_rnn", nm, H, L, sw), mel, roll, lengths, True)
     worst, cos = _compare_grads(grads, ref_emu)
     bad = {k: v for k, v in worst.items() if v > GRAD_REL}
@@ -205,7 +206,8 @@ def test_train_cnn_script_two_epochs(mta, tmp_path):
     assert set(ck) == set(man) and all(ck[k].shape == man[k].shape for k in man)
 
 
-@pytest.mark.parametrize("nm,H,L,B,T", [(40, 32, 3, 2, 33), (64, 48, 2, 5, 21), (32, 24, 1, 34, 12)])
+@pytest.mark.parametrize("nm,H,L,B,T", [(40, 32, 3, 2, 33), (64, 48, 2, 5, 21), (32, 24, 1, 34, 12),
+                                        (37, 16, 2, 2, 19), (38, 16, 1, 3, 21)])      # odd n_mels / odd n_mels//2: un-pooled tail rows
 def test_train_grads_match_oracle_autograd(mta, nm, H, L, B, T):
     """Other shapes (padded hidden sizes, > 1 batch group, odd T) against torch autograd on the CPU oracle."""
     m, sd = _hip_model(mta, nm, H, L, seed=77)
@@ -220,7 +222,7 @@ def test_train_grads_match_oracle_autograd(mta, nm, H, L, B, T):
     assert np.abs(logits.detach().cpu().numpy() - lo.numpy()).max() < LOGIT_TOL
     worst, cos = _compare_grads(grads, ref)
     bad = {k: v for k, v in worst.items() if v > GRAD_REL_FP32_BY_KEY.get(k, GRAD_REL_FP32)}
-    assert not bad and cos > GRAD_COS, (bad, cos)
+    assert not bad and cos > GRAD_COS_FP32, (bad, cos)
     lo, ref = _oracle_grads(sd, mel, roll, lengths, True)
     assert np.abs(logits.detach().cpu().numpy() - lo.numpy()).max() < 5e-3
     worst, cos = _compare_grads(grads, ref)
