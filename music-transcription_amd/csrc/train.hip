@@ -20,15 +20,30 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Sum `acc[0..NV)` over the 256 threads of the workgroup and add the totals to dst[0..NV) (f64 atomics, one per value
+// per workgroup: per-wave atomics on a few hundred addresses serialise in L2 and dominated these kernels).
+template <int NV>
+__device__ __forceinline__ void block_sum_atomic(float (&acc)[NV], double* dst, float (*lds)[NV]) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) lds[wv][i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV; i += 256) atomicAdd(dst + i, (double)((lds[0][i] + lds[1][i]) + (lds[2][i] + lds[3][i])));
+}
+
 // ------------------------------------------------------------------------------------------------ conv1 statistics
 // x [B][F][T] f32, w [32][9], bias [32] (RAW conv parameters).  sums[0..31] += sum z, sums[32..63] += sum z^2 over
 // every (b, f, t); z = conv(x)[c] + bias[c].
 __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, double* __restrict__ sums,
                                                           int B, int F, int T) {
-    float s[32], q[32];
+    __shared__ float lds[4][64];
+    float sq[64];                                     // [0..31] sum z, [32..63] sum z^2
 #pragma unroll
-    for (int c = 0; c < 32; ++c) s[c] = q[c] = 0.0f;
+    for (int c = 0; c < 64; ++c) sq[c] = 0.0f;
     const long long n = (long long)B * F * T;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int t = (int)(i % T), f = (int)((i / T) % F), b = (int)(i / ((long long)T * F));
@@ -46,18 +61,11 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restric
             float z = bias[c];
 #pragma unroll
             for (int k = 0; k < 9; ++k) z = fmaf(w[c * 9 + k], p[k], z);
-            s[c] += z;
-            q[c] = fmaf(z, z, q[c]);
+            sq[c] += z;
+            sq[32 + c] = fmaf(z, z, sq[32 + c]);
         }
     }
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        const float a = wave_sum(s[c]), b2 = wave_sum(q[c]);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(sums + c, (double)a);
-            atomicAdd(sums + 32 + c, (double)b2);
-        }
-    }
+    block_sum_atomic<64>(sq, sums, lds);
 }
 
 // sums -> batch mean / rstd; running statistics updated as nn.BatchNorm2d does (momentum, unbiased variance);
@@ -294,6 +302,12 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < (WGRAD ? 80 : 64); ++i) acc[i] = 0.0f;
     const double cnt = (double)B * F * T;
+    float m1v[NC], m2v[NC];                           // per-channel means of dy and dy*xhat (pass 2 only): hoisted f64 divisions
+#pragma unroll
+    for (int ci = 0; ci < NC; ++ci) {
+        m1v[ci] = WGRAD ? (float)(sums[cg + ci] / cnt) : 0.0f;
+        m2v[ci] = WGRAD ? (float)(sums[32 + cg + ci] / cnt) : 0.0f;
+    }
     const long long n = (long long)B * Fh * T;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int t = (int)(i % T), fo = (int)((i / T) % Fh), b = (int)(i / ((long long)T * Fh));
@@ -307,7 +321,24 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
                 const int ff = 2 * fo - 1 + r, tt = t - 1 + cc;
                 p[r][cc] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? m[(size_t)ff * T + tt] : 0.0f;
             }
-        const bf16_t* dap = da + (((size_t)b * Fo + fo) * T + t) * ldc;
+        // this thread's NC gradient channels as 16-B loads (cg is a multiple of 8, ldc of 8: aligned)
+        float dav[NC];
+        if (pair) {
+            const uint4* dq = (const uint4*)(da + (((size_t)b * Fo + fo) * T + t) * ldc + cg);
+#pragma unroll
+            for (int q = 0; q < NC / 8; ++q) {
+                const uint4 v = dq[q];
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dav[q * 8 + 2 * e] = __uint_as_float(u[e] << 16);
+                    dav[q * 8 + 2 * e + 1] = __uint_as_float(u[e] & 0xFFFF0000u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ci = 0; ci < NC; ++ci) dav[ci] = 0.0f;
+        }
 #pragma unroll
         for (int ci = 0; ci < NC; ++ci) {
             const int c = cg + ci;
@@ -325,7 +356,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
             float d0 = 0.0f, d1 = 0.0f;
             if (pair) {
                 const float y0 = fmaf(ga, x0, be), y1 = fmaf(ga, x1, be);
-                const float g = bf16_to_f32(dap[c]);
+                const float g = dav[ci];
                 if (y1 > y0) { if (y1 > 0.0f) d1 = g; }
                 else if (y0 > 0.0f) d0 = g;
             }
@@ -333,7 +364,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
                 acc[ci] += d0 + d1;
                 acc[32 + ci] = fmaf(d0, x0, fmaf(d1, x1, acc[32 + ci]));
             } else {
-                const float m1 = (float)(sums[c] / cnt), m2 = (float)(sums[32 + c] / cnt), k = ga * rs;
+                const float m1 = m1v[ci], m2 = m2v[ci], k = ga * rs;
                 const float dz0 = k * (d0 - m1 - x0 * m2);
                 const float dz1 = pair ? k * (d1 - m1 - x1 * m2) : 0.0f;
 #pragma unroll
@@ -345,19 +376,8 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
             }
         }
     }
-    if (!WGRAD) {
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const float v = wave_sum(acc[i]);
-            if ((threadIdx.x & 63) == 0) atomicAdd(sums + i, (double)v);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 80; ++i) {
-            const float v = wave_sum(acc[i]);
-            if ((threadIdx.x & 63) == 0) atomicAdd(wacc + cg * 10 + i, (double)v);
-        }
-    }
+    __shared__ float lds[4][WGRAD ? 80 : 64];
+    block_sum_atomic<WGRAD ? 80 : 64>(acc, WGRAD ? wacc + cg * 10 : sums, lds);
 }
 
 // wacc double [32][10] -> dW1 [32][9], db1 [32]
@@ -380,7 +400,7 @@ extern "C" int mt_conv1_stats(const float* x, const float* w, const float* bias,
     MT_REQUIRE(x && w && bias && sums64 && B > 0 && F > 0 && T > 0, MT_EINVAL, "mt_conv1_stats: bad arguments");
     MT_CHECK_HIP(hipMemsetAsync(sums64, 0, 64 * sizeof(double), ST(stream)));
     const long long n = (long long)B * F * T;
-    const int grid = (int)((n + 256 * 16 - 1) / (256 * 16) < 2048 ? (n + 256 * 16 - 1) / (256 * 16) : 2048);
+    const int grid = (int)((n + 256 * 16 - 1) / (256 * 16) < 512 ? (n + 256 * 16 - 1) / (256 * 16) : 512);
     hipLaunchKernelGGL(conv1_stats_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, ST(stream), x, w, bias, sums64, B, F, T);
     MT_CHECK_LAUNCH();
     return MT_OK;
@@ -481,11 +501,11 @@ extern "C" int mt_conv1_bwd(const float* x, const float* w, const float* bias, c
                             const float* beta, const void* da, int ldc, double* scratch384, float* dW, float* db, float* dgamma,
                             float* dbeta, int B, int F, int T, mt_stream_t stream) {
     MT_REQUIRE(x && w && bias && mean && rstd && gamma && beta && da && scratch384 && dW && db && dgamma && dbeta, MT_EINVAL, "mt_conv1_bwd: null pointer");
-    MT_REQUIRE(B > 0 && F >= 2 && T > 0 && ldc >= 32, MT_EINVAL, "mt_conv1_bwd: bad dims");
+    MT_REQUIRE(B > 0 && F >= 2 && T > 0 && ldc >= 32 && ldc % 8 == 0, MT_EINVAL, "mt_conv1_bwd: bad dims (ldc: >= 32, multiple of 8)");
     MT_CHECK_HIP(hipMemsetAsync(scratch384, 0, 384 * sizeof(double), ST(stream)));
     const long long n = (long long)B * ((F + 1) / 2) * T;
     long long g = (n + 256 * 8 - 1) / (256 * 8);
-    if (g > 2048) g = 2048;
+    if (g > 512) g = 512;
     if (g < 1) g = 1;
     double* sums = scratch384;
     double* wacc = scratch384 + 64;
