@@ -326,10 +326,13 @@ int    mt_lstm_dh_relayout(const float* dX, int ld, float* dh, int B, int T, int
                            unsigned seed, unsigned layer, mt_stream_t stream);
 /* Backward through time (both directions of one layer; persistent kernel, lstm_bwd.hip): gates/cx from
  * mt_lstm_bidir_fwd_train, dh from mt_lstm_dh_relayout, w_hh [2][4H][H] f32 -> dgx: d(gate pre-activations)
- * as bf16 MFMA-operand images (mt_lstm_dgx_bytes).  H % 16 == 0, H <= 512.  sync_ws: mt_lstm_sync_bytes.   */
+ * as bf16 MFMA-operand images (mt_lstm_dgx_bytes).  H % 16 == 0, H <= 512.  part_ws: scratch for the per-step
+ * partial products of the reduce-scatter (mt_lstm_bwd_part_bytes); sync_ws: mt_lstm_sync_bytes.             */
 size_t mt_lstm_dgx_bytes(int B, int T, int H);
+size_t mt_lstm_bwd_part_bytes(int B, int T, int H);
 int    mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx,
-                         void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream);
+                         void* part_ws, size_t part_bytes, void* sync_ws, size_t sync_bytes, int B, int T, int H,
+                         mt_stream_t stream);
 /* dgx -> dG [(t*B+b)*ldg + d*4H + gate*H + j] bf16 and dGT [(d*4H + gate*H + j)*ldt + t*B + b] bf16
  * (pre-zeroed by the caller: padded rows / columns are not written).                                       */
 int    mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, long long ldt, int B, int T, int H,

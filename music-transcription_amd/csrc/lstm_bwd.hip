@@ -7,21 +7,22 @@
 //   dh      = dh_out[t] + W_hh^T dgates[t_next]                 (the only cross-workgroup dependency)
 //   do      = dh tanh(c_t) o (1-o);   dc = dh o (1 - tanh^2 c_t) + dc[t_next] f[t_next]
 //   di, df, dg = dc g i(1-i),  dc c_prev f(1-f),  dc i (1-g^2)
-// Decomposition mirrors the forward kernel: a (direction, batch group) is sliced over NW = ceil(H/32) persistent
-// workgroups; workgroup w owns hidden units 32w..32w+31, keeps its 32 x 4H slice of W_hh^T in registers as bf16
-// MFMA A-operands, and every step all-gathers the 4H x 32 dgates of the previous step (published by all NW
-// workgroups as bf16 MFMA B-operand images) through L2: v_mfma_f32_32x32x16_bf16, K = 4H split over the 4 waves,
-// partial tiles summed through LDS, cell math lane-local with dc carried in registers.  The published images of ALL
-// steps are kept: they are dgates for the weight-gradient and input-gradient GEMMs (re-laid out by
-// lstm_dg_unpack_kernel).  K order of the dgates vector: k = 128 w' + 32 gate + u  (producer w', unit u).
-// Hand-off as in lstm.hip: sc1 stores and nothing else on the producer side; the dgx buffer is poisoned (0xFF) before the
-// launch and the consumers' gather loads poll the poison pattern (no flags, one round trip per step).  Bounded spins.
+// Decomposition: a (direction, batch group) is sliced over NW = ceil(H/32) persistent workgroups; workgroup w owns hidden
+// units 32w..32w+31, i.e. 128 gate rows of W_hh, and the product W_hh^T dgates is a REDUCE-SCATTER instead of the forward
+// kernel's all-gather: from its OWN dgates (which never leave the CU: LDS -> MFMA B operand) a workgroup computes its
+// partial of dh for ALL H units (its 128 x H slice of W_hh sits in registers as bf16 MFMA A-operands, 4 waves x 4 consumer
+// tiles x 8 k-steps) and stores one 2-KB bf16 slice per consumer; a consumer then reads the NW slices addressed to it
+// (32 KB per workgroup per step at H = 512, where all-gathering the 4H x 32 dgates took 128 KB) and sums them in fp32.
+// Cell math is lane-local with dc carried in registers.  The dgates of all steps are kept (bf16 MFMA-operand images,
+// re-laid out by lstm_dg_unpack_kernel) for the weight-gradient and input-gradient GEMMs.
+// Hand-off as in lstm.hip: sc1 stores and nothing else on the producer side; the slice buffer is poisoned (0xFF) before the
+// launch and the consumers' loads poll the poison pattern (no flags, one round trip per step).  Bounded spins.
+// 4.07 us/step at H = 512 (4.3 with the all-gather formulation, 10.2 before the prefetch pipeline and the flagless hand-off).
 #include "mt_common.h"
 
 namespace mt {
 
 constexpr int BPTT_SPIN_LIMIT_TICKS = 200000000;   // 2 s of the 100 MHz s_memrealtime clock
-constexpr int BW_FLAG_REPL = 8;                    // (sizing of the sync block only: the hand-off uses no flags)
 constexpr int BPTT_POLL_SLEEP = 10;                // s_sleep units (64 clocks) before a step's first payload poll
 constexpr unsigned DG_POISON = 0xFFFFFFFFu;        // two bf16 NaNs with all-ones payload: f32_to_bf16 never produces it
 
@@ -31,39 +32,43 @@ struct LstmBwdArgs {
     const float* dh;      // [NG][T][2][NKB][8][32]
     const float* w_hh;    // [2][4H][H]
     bf16_t* dgx;          // [NG][T][2][NW][8][64][8]
-    unsigned* flags;      // [NG][2][BW_FLAG_REPL][NW], zeroed before every launch
+    void* part;           // [NG][T][2][NW consumer][NW producer][8][32][4] bf16 partial products, poisoned before every launch
+    unsigned* flags;      // (unused by the flagless hand-off)
     unsigned* status;     // abort word, zeroed before every launch
     int B, T, H;
 };
 
 __device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
 
-template <int NKSW_MAX>
+// TPW = consumer tiles (32 hidden units each) per wave: ceil(NW / 4)
+template <int TPW>
 __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4][64][20];
-    __shared__ __attribute__((aligned(16))) bf16_t img[8][64][8];
+    __shared__ __attribute__((aligned(16))) bf16_t img[8][64][8];      // this workgroup's dgates of the step, as 8 MFMA B-operand images
     __shared__ int abort_s;
-    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+    typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int H = a.H, T = a.T, nkb = H >> 3, NW = (H + 31) >> 5, nksw = 2 * NW;
+    const int H = a.H, T = a.T, nkb = H >> 3, NW = (H + 31) >> 5;
     const int w = blockIdx.x, d = blockIdx.y, g = blockIdx.z;
     const int b = lane & 31, hh = lane >> 5;
     const int Bg = min(32, a.B - g * 32);
 
-    // ---- W_hh^T slice as MFMA A-operands: lane (row r <-> unit j = 32w + r, k half hh) holds, for k-step ks,
-    //      W_hh[gate*H + 32w' + u][j] at k = 16ks + 8hh + e = 128w' + 32 gate + u
-    const int r = lane & 31, j = 32 * w + r;
-    bf16x8 wt[NKSW_MAX];
+    // ---- W_hh slices as MFMA A-operands.  Tile i of this wave serves consumer wc = wv*TPW + i (hidden units k = 32wc + r):
+    //      lane (row r, k half hh) holds, for k-step ks over this workgroup's OWN 128 gate rows rho = 16ks + 8hh + e
+    //      (gate p = rho >> 5, unit u = rho & 31):  W_hh[p*H + 32w + u][32wc + r]
+    const int r = lane & 31;
+    bf16x8 wt[TPW][8];
 #pragma unroll
-    for (int i = 0; i < NKSW_MAX; ++i) {
-        const int ks = wv * nksw + i;
+    for (int i = 0; i < TPW; ++i) {
+        const int wc = wv * TPW + i, k = 32 * wc + r;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = ks * 16 + 8 * hh + e, wp = k >> 7, kl = k & 127, p = kl >> 5, u = kl & 31, jp = 32 * wp + u;
-            float v = 0.0f;
-            if (i < nksw && jp < H && j < H) v = a.w_hh[((size_t)d * 4 * H + (size_t)p * H + jp) * H + j];
-            wt[i][e] = (short)f32_to_bf16(v);
-        }
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int rho = ks * 16 + 8 * hh + e, p = rho >> 5, u = rho & 31, jo = 32 * w + u;
+                float v = 0.0f;
+                if (wc < NW && k < H && jo < H) v = a.w_hh[((size_t)d * 4 * H + (size_t)p * H + jo) * H + k];
+                wt[i][ks][e] = (short)f32_to_bf16(v);
+            }
     }
 
     // this thread's cells: units u = 8wv + 4hh + e (e = 0..3) of the workgroup, batch row b
@@ -73,18 +78,17 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
     const float* gates_g = a.gates + g * g_blocks * 1024;
     const float* cx_g = a.cx + g * g_blocks * 256;
     const float* dh_g = a.dh + g * g_blocks * 256;
-    const size_t dg_bytes = (size_t)T * 2 * NW * 8 * 1024;
-    char* dgx_g = (char*)a.dgx + g * dg_bytes;
-    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dgx_g, 0, (int)dg_bytes, 0x00020000);
+    char* dgx_g = (char*)a.dgx + g * ((size_t)T * 2 * NW * 8 * 1024);
+    const size_t part_bytes = (size_t)T * 2 * NW * NW * 2048;
+    char* part_g = (char*)a.part + g * part_bytes;
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(part_g, 0, (int)part_bytes, 0x00020000);
     if (tid == 0) abort_s = 0;
     __syncthreads();
 
     float carry[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // dc[t_next] * f[t_next]
     float ccur[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // What the cell math needs from the forward pass (activated gates, c of the forward pass's previous step, dh from
-    // above) does not depend on the recurrence: it is fetched ONE STEP AHEAD, right behind the gather loads of the
-    // current step, so its HBM latency hides under the MFMA chain / publish / next poll (loads return in order: issued
-    // before the gather it would sit in front of it on the critical path).
+    // above) does not depend on the recurrence: it is fetched ONE STEP AHEAD (see the issue point below).
     float gt[4][4], cprev[4], dhin[4];
 #define BPTT_FETCH(S_)                                                                                              \
     do {                                                                                                            \
@@ -107,38 +111,38 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
     for (int s = 0; s < T; ++s) {
         const int t = d ? s : (T - 1 - s);            // reverse of the forward processing order
         const int tn = d ? (t - 1) : (t + 1);         // the step processed just before this one
-        // this step's operands (fetched during the previous step) move out of the prefetch registers
         float g_i[4], g_f[4], g_g[4], g_o[4], c_prev[4], dh_in[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { g_i[e] = gt[0][e]; g_f[e] = gt[1][e]; g_g[e] = gt[2][e]; g_o[e] = gt[3][e]; c_prev[e] = cprev[e]; dh_in[e] = dhin[e]; }
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        float rec[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // (W_hh^T dgates[t_next]) for this thread's 4 units
         if (s > 0) {
-            // No flag wait (as lstm.hip): the gather below polls the poison pattern of the payload itself.  The short
-            // sleep keeps the certain-to-fail first attempt, issued right behind this workgroup's own publish, off the fabric.
+            // ---- reduce-scatter, consumer side: every producer wp left a 32-unit x 32-batch slice of ITS partial product
+            //      for this workgroup; this thread's 4 units x 1 batch row are one 8-B word of each slice.  No flag: the
+            //      loads poll the poison pattern (as lstm.hip); the short sleep keeps the certain-to-fail first attempt,
+            //      issued right behind this workgroup's own publish, off the fabric.
             __builtin_amdgcn_s_sleep(BPTT_POLL_SLEEP);
-            // ---- gather dgates[t_next] and run the MFMA chain: a word still holding the poison pattern has not been
-            //      published (or has not landed) -> redo the loads.
-            const int gbase = ((tn * 2 + d) * NW * 8) * 1024 + lane * 16;
+            const int gbase = (((tn * 2 + d) * NW + w) * NW) * 2048 + ((2 * wv + hh) * 32 + b) * 8;
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
-                u32x4 raw[NKSW_MAX];
+                u32x2 raw[TPW * 4];
 #pragma unroll
-                for (int i = 0; i < NKSW_MAX; ++i)
-                    raw[i] = (i < nksw) ? __builtin_amdgcn_raw_buffer_load_b128(drsrc, gbase + (wv * nksw + i) * 1024, 0, 16 /*sc1*/) : u32x4{0, 0, 0, 0};
-                __builtin_amdgcn_sched_barrier(0);
-                if (it == 0 && s + 1 < T) BPTT_FETCH(s + 1);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < TPW * 4; ++i)
+                    raw[i] = (i < NW) ? __builtin_amdgcn_raw_buffer_load_b64(prsrc, gbase + i * 2048, 0, 16 /*sc1*/) : u32x2{0, 0};
                 unsigned worst = 0;
+                float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int i = 0; i < NKSW_MAX; ++i) {
-                    worst = max(max(worst, max(raw[i][0], raw[i][1])), max(raw[i][2], raw[i][3]));
-                    if (i < nksw) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[i], __builtin_bit_cast(bf16x8, raw[i]), acc, 0, 0, 0);
+                for (int i = 0; i < TPW * 4; ++i) {
+                    worst = max(worst, max(raw[i][0], raw[i][1]));
+                    sum[0] += __uint_as_float(raw[i][0] << 16);
+                    sum[1] += __uint_as_float(raw[i][0] & 0xFFFF0000u);
+                    sum[2] += __uint_as_float(raw[i][1] << 16);
+                    sum[3] += __uint_as_float(raw[i][1] & 0xFFFF0000u);
                 }
-                if (!__any(worst == DG_POISON)) break;
+                if (!__any(worst == DG_POISON)) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                    for (int e = 0; e < 4; ++e) rec[e] = sum[e];
+                    break;
+                }
                 if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
                     break;
@@ -155,22 +159,18 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
                     }
                 }
             }
-        } else if (T > 1) {
-            BPTT_FETCH(1);
         }
-        // ---- sum the four K-slices through LDS; wave wv finishes rows (units) 8wv + 4hh + e
-#pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4)
-            *(f32x4*)(&red[wv][lane][4 * e4]) = f32x4{acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]};
-        __syncthreads();
-        if (abort_s) return;                           // a payload spin gave up (status word says where)
-        const f32x4 r0 = *(const f32x4*)(&red[0][lane][4 * wv]), r1 = *(const f32x4*)(&red[1][lane][4 * wv]);
-        const f32x4 r2 = *(const f32x4*)(&red[2][lane][4 * wv]), r3 = *(const f32x4*)(&red[3][lane][4 * wv]);
+        // next step's operands: issued once the gather has succeeded (behind a retried gather they would sit, with their HBM
+        // latency, in front of the retry in the wave's in-order memory queue); they have the cell math, the MFMA chain, the
+        // publish and the next sleep to land
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < T) BPTT_FETCH(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- cell backward (lane-local)
         bf16_t o4[4][4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float dhv = dh_in[e] + ((r0[e] + r1[e]) + (r2[e] + r3[e]));
+            const float dhv = dh_in[e] + rec[e];
             const float ig = g_i[e], fg = g_f[e], gg = g_g[e], og = g_o[e];
             const float tc = tanh_fast(ccur[e]);
             const float dc = fmaf(dhv * og, 1.0f - tc * tc, carry[e]);
@@ -183,26 +183,46 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
             if (!live) { di = df = dgg = dov = 0.0f; carry[e] = 0.0f; }
             o4[0][e] = f32_to_bf16(di); o4[1][e] = f32_to_bf16(df); o4[2][e] = f32_to_bf16(dgg); o4[3][e] = f32_to_bf16(dov);
         }
-        // ---- assemble the workgroup's 8 B-operand images: (gate p, unit u) -> image 2p + (u >> 4),
+        // ---- the workgroup's dgates as 8 B-operand images: (gate p, unit u) -> image 2p + (u >> 4),
         //      lane ((u >> 3) & 1)*32 + batch, element u & 7;  u = 8wv + 4hh + e
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const unsigned lo = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16), hi = (unsigned)o4[p][2] | ((unsigned)o4[p][3] << 16);
             *(uint2*)(&img[2 * p + (wv >> 1)][(wv & 1) * 32 + b][4 * hh]) = make_uint2(lo, hi);
         }
-        __syncthreads();                                // images assembled; every wave is done with `red`
-        {
-            const int obase = (((t * 2 + d) * NW + w) * 8) * 1024;
+        __syncthreads();                                // images complete (and every wave is past the previous step's reads of img)
+        if (abort_s) return;                            // a payload spin gave up (status word says where)
+        // ---- reduce-scatter, producer side: partial[k][b] = sum over OWN gate rows of W_hh[rho][k] dgates[rho][b] for the
+        //      consumer tiles of this wave, stored as bf16 slices [consumer][producer][unit/4][batch][4]
+        bf16x8 bfr[8];
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int i = tid + 256 * h2;
-                const u32x4 piece = *(const u32x4*)(&img[i >> 6][i & 63][0]);
-                __builtin_amdgcn_raw_buffer_store_b128(piece, drsrc, obase + i * 16, 0, 16 /*sc1: write-through*/);
+        for (int ks = 0; ks < 8; ++ks) bfr[ks] = *(const bf16x8*)(&img[ks][lane][0]);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int wc = wv * TPW + i;
+            if (wc < NW) {
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[i][ks], bfr[ks], acc, 0, 0, 0);
+                const int obase = (((t * 2 + d) * NW + wc) * NW + w) * 2048 + (hh * 32 + b) * 8;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {           // registers 4q..4q+3 = units 8q + 4hh + (0..3): word (unit/4 = 2q + hh, batch b)
+                    const u32x2 v = {pack_bf16x2(acc[4 * q], acc[4 * q + 1]), pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(v, prsrc, obase + q * 512, 0, 16 /*sc1: write-through*/);
+                }
             }
         }
-        // no flag, no drain: consumers poll the payload (see the gather).  `img` is rewritten only after the next step's
-        // LDS-reduce barrier, which every wave reaches after these LDS reads.
+        // ---- dgates for the weight- and input-gradient GEMMs (consumed after the kernel: plain stores)
+        {
+            uint4* dst = (uint4*)(dgx_g + ((((size_t)t * 2 + d) * NW + w) * 8) * 1024);
+            dst[tid] = *(const uint4*)(&img[tid >> 6][tid & 63][0]);
+            dst[tid + 256] = *(const uint4*)(&img[(tid + 256) >> 6][tid & 63][0]);
+        }
+        __syncthreads();                                // every wave is done reading img before the next step rewrites it
     }
+#undef BPTT_FETCH
 }
 
 // dgx images -> dG [(t*B+b)*ldg + d*4H + p*H + j] bf16 (GEMM A rows) and dGT [(d*4H + p*H + j)*ldt + t*B + b] bf16
@@ -326,26 +346,30 @@ extern "C" size_t mt_lstm_dgx_bytes(int B, int T, int H) {
 extern "C" size_t mt_lstm_cx_bytes(int B, int T, int H) { return (size_t)((B + 31) / 32) * T * 2 * (H / 8) * 256 * sizeof(float); }
 
 // sync_ws: >= mt_lstm_sync_bytes(B, H) bytes (word 0 = status, flags from byte 256)
-extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx, void* sync_ws,
-                                 size_t sync_bytes, int B, int T, int H, mt_stream_t stream) {
-    MT_REQUIRE(gates && cx && dh && w_hh && dgx && sync_ws, MT_EINVAL, "mt_lstm_bidir_bwd: null pointer");
+extern "C" size_t mt_lstm_bwd_part_bytes(int B, int T, int H) {
+    const size_t NW = (H + 31) / 32;
+    return (size_t)((B + 31) / 32) * T * 2 * NW * NW * 2048;
+}
+
+// sync_ws: >= mt_lstm_sync_bytes(B, H) bytes (word 0 = status); part_ws: mt_lstm_bwd_part_bytes(B, T, H) bytes of scratch
+extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx, void* part_ws,
+                                 size_t part_bytes, void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream) {
+    MT_REQUIRE(gates && cx && dh && w_hh && dgx && part_ws && sync_ws, MT_EINVAL, "mt_lstm_bidir_bwd: null pointer");
     MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 512, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: H=%d unsupported (16..512, multiple of 16)", H);
     const int NG = (B + 31) / 32, NW = (H + 31) / 32;
-    MT_REQUIRE((size_t)T * 2 * NW * 8 * 1024 < (size_t)1 << 31, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: T=%d too long for one buffer descriptor", T);
-    const size_t need = 256 + (size_t)NG * 2 * BW_FLAG_REPL * NW * 4;
-    MT_REQUIRE(sync_bytes >= need, MT_EWORKSPACE, "mt_lstm_bidir_bwd: sync workspace %zu < %zu", sync_bytes, need);
+    MT_REQUIRE((size_t)T * 2 * NW * NW * 2048 < (size_t)1 << 31, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: T=%d too long for one buffer descriptor", T);
+    MT_REQUIRE(part_bytes >= mt_lstm_bwd_part_bytes(B, T, H), MT_EWORKSPACE, "mt_lstm_bidir_bwd: partial-product workspace %zu < %zu", part_bytes,
+               mt_lstm_bwd_part_bytes(B, T, H));
+    MT_REQUIRE(sync_bytes >= 256, MT_EWORKSPACE, "mt_lstm_bidir_bwd: sync workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, need, st));
-    MT_CHECK_HIP(hipMemsetAsync(dgx, 0xFF, mt_lstm_dgx_bytes(B, T, H), st));     // poison: see the hand-off note
-    LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
+    MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, 256, st));
+    MT_CHECK_HIP(hipMemsetAsync(part_ws, 0xFF, mt_lstm_bwd_part_bytes(B, T, H), st));     // poison: see the hand-off note
+    LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, part_ws, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
     dim3 grid(NW, 2, NG);
     MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);
-    const int nksw = 2 * NW;
-    if (nksw <= 2) hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(256), 0, st, a);
-    else if (nksw <= 4) hipLaunchKernelGGL(lstm_bptt_kernel<4>, grid, dim3(256), 0, st, a);
-    else if (nksw <= 8) hipLaunchKernelGGL(lstm_bptt_kernel<8>, grid, dim3(256), 0, st, a);
-    else if (nksw <= 16) hipLaunchKernelGGL(lstm_bptt_kernel<16>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(lstm_bptt_kernel<32>, grid, dim3(256), 0, st, a);
+    if (NW <= 4) hipLaunchKernelGGL(lstm_bptt_kernel<1>, grid, dim3(256), 0, st, a);
+    else if (NW <= 8) hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(lstm_bptt_kernel<4>, grid, dim3(256), 0, st, a);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

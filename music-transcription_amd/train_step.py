@@ -177,6 +177,7 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         sync = torch.empty(lib.mt_lstm_sync_bytes(B, Hp), device=dev, dtype=torch.uint8)
         dh = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
         dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
+        part = torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
         Hr = _ru(Hp, 128)
         HT = torch.zeros(2 * Hr, Mpad, **bf)
         gb = torch.empty(8 * Hp, **f32)
@@ -185,8 +186,8 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             K = K0 if l == 0 else K1
             p = sv["dropout"] if l < L - 1 else 0.0
             check(lib.mt_lstm_dh_relayout(ptr(dXn), K1, ptr(dh), B, T, Hp, H, float(p), sv["seed"], l, _st()), "mt_lstm_dh_relayout")
-            check(lib.mt_lstm_bidir_bwd(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(sync), sync.numel(),
-                                        B, T, Hp, _st()), "mt_lstm_bidir_bwd")
+            check(lib.mt_lstm_bidir_bwd(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(part), part.numel(),
+                                        ptr(sync), sync.numel(), B, T, Hp, _st()), "mt_lstm_bidir_bwd")
             # dGT is also read as a GEMM A operand from row 4Hp (reverse direction): whole 128-row tiles must stay inside it
             dG, dGT = torch.zeros(Mpad, 8 * Hp, **bf), torch.zeros(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
             check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * Hp, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")

@@ -271,7 +271,8 @@ def test_lstm_bptt_canonical_width(mta):
     dh = torch.empty(lib.mt_lstm_cx_bytes(B, T, H) // 4, device=dev)
     dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, H), dtype=torch.uint8, device=dev)
     check(lib.mt_lstm_dh_relayout(ptr(dX), 2 * H, ptr(dh), B, T, H, H, 0.0, 0, 0, st))
-    check(lib.mt_lstm_bidir_bwd(ptr(gx), ptr(cx), ptr(dh), ptr(whd), ptr(dgx), ptr(sync), sync.numel(), B, T, H, st))
+    part = torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, H), dtype=torch.uint8, device=dev)
+    check(lib.mt_lstm_bidir_bwd(ptr(gx), ptr(cx), ptr(dh), ptr(whd), ptr(dgx), ptr(part), part.numel(), ptr(sync), sync.numel(), B, T, H, st))
     dG = torch.zeros(Mpad, 8 * H, dtype=torch.bfloat16, device=dev)
     dGT = torch.zeros(8 * H, Mpad, dtype=torch.bfloat16, device=dev)
     check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * H, ptr(dGT), Mpad, B, T, H, st))
