@@ -345,6 +345,14 @@ int    mt_lstm_hprev_t(const float* hx, void* HT, long long ld, int rows_per_dir
 int    mt_dlogits_pack(const float* dlogits, void* dL, void* dLT, long long ldt, int B, int P, int T,
                        mt_stream_t stream);
 
+/* ------------------------------------------------------------------ audio decode
+ * PCM frames -> mono float at the target rate, replacing the host side of librosa.load(path, sr=16000, mono=True)
+ * (main.py:76, data/dataset.py:124-130): channel mean + polyphase FIR, y[j] = sum_i x[i] h[(j+n_pre_remove)*down - i*up]
+ * (= scipy.signal.resample_poly with the pre-padded filter h; the host builds h and the offsets, frontend.py).
+ * src: interleaved [n_in][channels], fmt 0 = int16, 1 = int32 (left-aligned), 2 = float32.  soxr-exactness: unpinned. */
+int    mt_resample_poly(const void* src, long long n_in, int channels, int fmt, const float* h, int h_len, int up, int down,
+                        long long n_pre_remove, float* out, long long n_out, mt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,6 +129,7 @@ _SIGS = {
     "mt_lstm_dg_unpack": (i32, [vp, vp, i32, vp, ll, i32, i32, i32, vp]),
     "mt_lstm_hprev_t": (i32, [vp, vp, ll, i32, i32, i32, i32, vp]),
     "mt_dlogits_pack": (i32, [vp, vp, vp, ll, i32, i32, i32, vp]),
+    "mt_resample_poly": (i32, [vp, ll, i32, i32, vp, i32, i32, i32, ll, vp, ll, vp]),
     "mt_cnnrnn_workspace_bytes": (sz, [C.POINTER(CnnRnnWeights), i32, i32]),
     "mt_cnnrnn_status_offset": (sz, [C.POINTER(CnnRnnWeights), i32, i32, i32]),
     "mt_cnnrnn_forward": (i32, [C.POINTER(CnnRnnWeights), vp, vp, i32, i32, vp, vp, sz, vp]),

@@ -8,8 +8,9 @@
     reference runs librosa per chunk on a host thread; labels: midi.chunk_roll (own SMF parser);
   * record = {'mel': (1, n_mels, T), 'roll': (88, T)} trimmed to the common T (dataset.py:159-161), files
     `{cache}/{split}/chunk_%06d.pt`, `{cache}/{split}_metadata.pkl` with the reference's keys.
-Audio decoding is transcribe.load_audio (WAV + polyphase resampling: row f3, not soxr-exact); the whole recording is
-resampled once and sliced, where librosa.load(offset, duration) resamples each slice on its own.
+Audio decoding is transcribe.load_audio_device (WAV, channel mean + polyphase resampling on the GPU: row f3, not
+soxr-exact); the whole recording is resampled once and sliced, where librosa.load(offset, duration) resamples each slice
+on its own.
 """
 from __future__ import annotations
 
@@ -23,7 +24,7 @@ import torch
 from . import data as D
 from .frontend import get_frontend
 from .midi import MidiFile, chunk_roll
-from .transcribe import load_audio
+from .transcribe import load_audio_device
 
 
 def build_chunk_index(durations: Sequence[float], chunk_length: float = 30.0, overlap: float = 0.0, sr: int = 16000) -> List[dict]:
@@ -99,7 +100,7 @@ def preprocess_and_cache(root_dir: str = "maestro-v3.0.0", cache_dir: str = "cac
         if not todo:
             continue
         try:
-            y = load_audio(paths[file_idx], sr)
+            y = load_audio_device(paths[file_idx], sr, device)          # stays on the GPU: decode, resample, mel
             midi = MidiFile(os.path.join(root_dir, rows[file_idx]["midi_filename"]))
             by_len: Dict[int, List[int]] = {}
             for i in todo:
@@ -107,11 +108,11 @@ def preprocess_and_cache(root_dir: str = "maestro-v3.0.0", cache_dir: str = "cac
             for n, group in by_len.items():
                 for g0 in range(0, len(group), max_batch):
                     part = group[g0:g0 + max_batch]
-                    wave = np.zeros((len(part), n), dtype=np.float32)
+                    wave = torch.zeros(len(part), n, dtype=torch.float32, device=y.device)
                     for k, i in enumerate(part):
                         seg = y[chunks[i]["start_sample"]:chunks[i]["end_sample"]]
-                        wave[k, :len(seg)] = seg
-                    mel, _ = fe(torch.from_numpy(wave).to(device), clamp=True)           # (len, 1, n_mels, T) dB, per-chunk top_db
+                        wave[k, :seg.numel()] = seg
+                    mel, _ = fe(wave, clamp=True)                                         # (len, 1, n_mels, T) dB, per-chunk top_db
                     mel = mel.cpu()
                     for k, i in enumerate(part):
                         roll = torch.from_numpy(chunk_roll(midi, chunks[i]["start_time"], chunks[i]["end_time"], sr, hop_length))

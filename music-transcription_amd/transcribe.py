@@ -8,8 +8,8 @@
     (as the reference does) and written by a dependency-free Standard MIDI File writer.
 
 Audio decoding: librosa/soundfile are not available in this image, so only WAV (PCM 16/24/32-bit or
-float) is read, channels are averaged (librosa mono=True) and other sample rates are resampled with
-scipy's polyphase filter -- NOT sample-exact with librosa's soxr_hq.
+float) is read; channel mean, PCM scaling and polyphase resampling run on the GPU (csrc/resample.hip,
+scipy.signal.resample_poly's filter) -- NOT sample-exact with librosa's soxr_hq.
 """
 from __future__ import annotations
 
@@ -29,27 +29,87 @@ MODEL_TYPE, N_MELS, HIDDEN_SIZE, NUM_LAYERS, DROPOUT = "cnn_rnn_large", 320, 512
 SR, HOP_LENGTH, CHUNK_LENGTH, THRESHOLD = 16000, 512, 30.0, 0.5                                # main.py:21-24
 
 
-def load_audio(path: str, sr: int = SR) -> np.ndarray:
-    """Mono float32 at `sr`.  WAV only (see module docstring)."""
+def resample_plan(rate_in: int, rate_out: int, n_in: int):
+    """Polyphase plan with scipy.signal.resample_poly's conventions (Kaiser(5.0) windowed sinc of 2*10*max(up,down)+1
+    taps, scaled by `up`, pre-padded so that output sample j sits at input time j*down/up): returns
+    (up, down, h float32, n_pre_remove, n_out).  up == down == 1 -> a one-tap identity plan."""
+    from math import gcd
+    g = gcd(int(rate_in), int(rate_out))
+    up, down = int(rate_out) // g, int(rate_in) // g
+    if up == down == 1:
+        return 1, 1, np.ones(1, np.float32), 0, n_in
+    from scipy.signal import firwin
+    n_out = (n_in * up + down - 1) // down
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up
+    n_pre_pad = down - half_len % down
+    n_pre_remove = (half_len + n_pre_pad) // down
+
+    def out_len(len_h):
+        nt = (n_in + (len_h + (-len_h % up)) // up - 1) * up
+        return nt // down + (1 if nt % down else 0)
+    n_post_pad = 0
+    while out_len(len(h) + n_pre_pad + n_post_pad) < n_out + n_pre_remove:
+        n_post_pad += 1
+    h = np.concatenate([np.zeros(n_pre_pad), h, np.zeros(n_post_pad)]).astype(np.float32)
+    return up, down, h, n_pre_remove, n_out
+
+
+_PLAN_FILTERS = {}
+
+
+def load_audio_device(path: str, sr: int = SR, device="cuda") -> torch.Tensor:
+    """WAV file -> mono float32 at `sr` ON THE DEVICE (librosa.load(path, sr=sr, mono=True) of main.py:76): the PCM frames
+    go to the GPU as they are (memory-mapped read, one H2D copy) and csrc/resample.hip does the channel mean, the PCM
+    scaling and the polyphase resampling.  WAV only (PCM 16/24/32-bit or float32); not soxr-exact."""
     from scipy.io import wavfile
+    from . import _lib
     try:
-        rate, data = wavfile.read(path)
+        rate, data = wavfile.read(path, mmap=True)
     except ValueError as e:
         raise ValueError(f"{path}: only WAV input is supported in this build ({e})")
-    if data.dtype.kind == "i":
-        data = data.astype(np.float32) / float(2 ** (8 * data.dtype.itemsize - 1))
-    elif data.dtype.kind == "u":
-        data = (data.astype(np.float32) - 128.0) / 128.0
+    if data.ndim == 1:
+        data = data[:, None]
+    if data.dtype == np.int16:
+        fmt = 0
+    elif data.dtype == np.int32:
+        fmt = 1
+    elif data.dtype == np.float32:
+        fmt = 2
+    elif data.dtype == np.uint8:
+        data, fmt = ((data.astype(np.float32) - 128.0) / 128.0), 2
     else:
-        data = data.astype(np.float32)
-    if data.ndim == 2:
-        data = data.mean(axis=1)
-    if rate != sr:
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(rate), int(sr))
-        data = resample_poly(data, sr // g, rate // g).astype(np.float32)
-    return np.ascontiguousarray(data, dtype=np.float32)
+        data, fmt = data.astype(np.float32), 2
+    n_in, ch = data.shape
+    if n_in == 0:
+        return torch.zeros(0, dtype=torch.float32, device=device)
+    up, down, h, n_pre_remove, n_out = resample_plan(int(rate), sr, n_in)
+    dev = torch.device(device)
+    key = (up, down, len(h), str(dev))
+    if key not in _PLAN_FILTERS:
+        _PLAN_FILTERS[key] = torch.from_numpy(h).to(dev)
+    hd = _PLAN_FILTERS[key]
+    src = torch.from_numpy(np.ascontiguousarray(data)).to(dev, non_blocking=True)
+    out = torch.empty(n_out, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib.mt_resample_poly(_lib.ptr(src), n_in, ch, fmt, _lib.ptr(hd), len(h), up, down, n_pre_remove, _lib.ptr(out), n_out,
+                                             _lib.stream_ptr()), "mt_resample_poly")
+    return out
+
+
+def load_audio(path: str, sr: int = SR) -> np.ndarray:
+    """Mono float32 at `sr` as a numpy array (decoded and resampled on the GPU, see load_audio_device)."""
+    return load_audio_device(path, sr, "cuda").cpu().numpy()
+
+
+def split_into_chunks_device(y: torch.Tensor, chunk_length: float = CHUNK_LENGTH, sr: int = SR):
+    """main.py:60-100 on the device: ceil(len / chunk) chunks, the last one zero-padded.  -> ((n, chunk_samples), seconds)."""
+    chunk = int(chunk_length * sr)
+    n = max(1, -(-y.numel() // chunk))
+    out = torch.zeros(n * chunk, dtype=torch.float32, device=y.device)
+    out[:y.numel()] = y[: n * chunk]
+    return out.view(n, chunk), y.numel() / sr
 
 
 def split_into_chunks(y: np.ndarray, chunk_length: float = CHUNK_LENGTH, sr: int = SR) -> Tuple[np.ndarray, float]:
@@ -116,13 +176,16 @@ def load_model(model_path: str, device: str = "cuda", model_type: str = MODEL_TY
 
 
 @torch.no_grad()
-def transcribe_chunks(model: TranscriptionModel, chunks: np.ndarray, threshold: float = THRESHOLD, batch: int = 32,
+def transcribe_chunks(model: TranscriptionModel, chunks, threshold: float = THRESHOLD, batch: int = 32,
                       n_mels: int = N_MELS, device: str = "cuda") -> np.ndarray:
-    """(n, 480000) waveform chunks -> (88, n * T) {0,1} roll; mel + forward + threshold all on the GPU."""
+    """(n, 480000) waveform chunks (device tensor, or numpy) -> (88, n * T) {0,1} roll; mel + forward + threshold all on the GPU."""
     fe = get_frontend(SR, n_mels, HOP_LENGTH, device)
+    if not torch.is_tensor(chunks):
+        chunks = torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32))
+    chunks = chunks.to(device)
     rolls = []
     for i in range(0, len(chunks), batch):
-        wave = torch.from_numpy(chunks[i:i + batch]).to(device)
+        wave = chunks[i:i + batch].contiguous()
         mel, cmax = fe(wave, clamp=False)
         net = model.model
         logits = net(mel, chunk_max_power=cmax)
@@ -137,8 +200,8 @@ def transcribe_audio(audio_path: str, model_path: str, output_path=None, device=
         raise RuntimeError("music_transcription_amd runs on the GPU only (-d cuda)")
     print(f"Using device: {device}")
     model = load_model(model_path, device, **model_kw)
-    y = load_audio(audio_path, SR)
-    chunks, duration = split_into_chunks(y)
+    y = load_audio_device(audio_path, SR, device)       # decode + resample on the GPU; the waveform never visits the host
+    chunks, duration = split_into_chunks_device(y)
     print(f"Audio duration: {duration:.2f} seconds; {len(chunks)} chunks of {CHUNK_LENGTH}s")
     roll = transcribe_chunks(model, chunks, threshold, n_mels=model_kw.get("n_mels", N_MELS), device=device)
     notes = pianoroll_to_notes(roll, SR / HOP_LENGTH)

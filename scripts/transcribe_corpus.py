@@ -101,9 +101,8 @@ def main():
     # chunks are independent (main.py:258-266 keeps no cross-chunk state): batch them ACROSS recordings
     owners, pieces = [], []
     for i in mine:
-        if args.wav_dir:                    # host decode + resample is part of the end-to-end time
-            chunks, _ = tr.split_into_chunks(tr.load_audio(os.path.join(args.wav_dir, names[i] + ".wav"), SR))
-            c = torch.from_numpy(chunks).to(dev, non_blocking=True)
+        if args.wav_dir:                    # file read + H2D + GPU resample are part of the end-to-end time
+            c, _ = tr.split_into_chunks_device(tr.load_audio_device(os.path.join(args.wav_dir, names[i] + ".wav"), SR, dev))
         else:
             c = synth_chunks[i]
         owners += [i] * c.shape[0]

@@ -362,3 +362,32 @@ def test_full_size_batch_independence_and_determinism(mta):
         assert (sub - full[:7]).abs().max().item() < 1e-5
     assert torch.isfinite(full).all() and full.shape == (32, 88, 938)
     model.model.raise_on_handoff_timeout(32, 938)
+
+
+# ------------------------------------------------------------------ audio decode (row f3): GPU resampler vs scipy
+@pytest.mark.parametrize("rate,ch,dtype,n", [(44100, 2, "int16", 200000), (48000, 1, "float32", 150001), (16000, 2, "int16", 50000),
+                                             (44100, 2, "int32", 44100), (22050, 1, "int16", 33333)])
+def test_load_audio_device_matches_scipy_resample_poly(mta, tmp_path, rate, ch, dtype, n):
+    from math import gcd
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+    from music_transcription_amd import transcribe as tr
+    rng = np.random.default_rng(n)
+    t = np.arange(n) / rate
+    sig = np.stack([0.4 * np.sin(2 * np.pi * 440.0 * t + c) + 0.05 * rng.standard_normal(n) for c in range(ch)], 1)
+    if dtype == "int16":
+        data = (sig * 32767).astype(np.int16); mono = data.astype(np.float64).mean(1) / 32768.0
+    elif dtype == "int32":
+        data = (sig * 2147483647).astype(np.int32); mono = data.astype(np.float64).mean(1) / 2147483648.0
+    else:
+        data = sig.astype(np.float32); mono = data.astype(np.float64).mean(1)
+    path = str(tmp_path / "x.wav")
+    wavfile.write(path, rate, data if ch > 1 else data[:, 0])
+    y = tr.load_audio_device(path, 16000, "cuda")
+    g = gcd(rate, 16000)
+    ref = resample_poly(mono, 16000 // g, rate // g) if rate != 16000 else mono
+    assert y.is_cuda and y.dtype == torch.float32 and y.numel() == len(ref)
+    assert np.abs(y.cpu().numpy() - ref).max() < 5e-6
+    chunks, dur = tr.split_into_chunks_device(y)
+    assert chunks.shape == (max(1, -(-len(ref) // 480000)), 480000) and abs(dur - len(ref) / 16000.0) < 1e-9
+    assert torch.equal(chunks.reshape(-1)[:len(ref)], y) and float(chunks.reshape(-1)[len(ref):].abs().sum()) == 0.0

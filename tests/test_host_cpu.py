@@ -192,13 +192,21 @@ def test_chunking_notes_and_midi_writer(mta, tmp_path):
     raw = p.read_bytes()
     assert raw[:4] == b"MThd" and raw[8:14] == bytes([0, 1, 0, 2, 0, 220]) and raw.count(b"MTrk") == 2
     assert raw.count(bytes([0x90, 60, 100])) == 2 and raw.endswith(b"\xFF\x2F\x00")
-    # wav loader: stereo int16 at 32 kHz -> mono float32 at 16 kHz
-    from scipy.io import wavfile
-    t = np.arange(32000) / 32000.0
-    st = np.stack([np.sin(2 * np.pi * 440 * t), np.sin(2 * np.pi * 440 * t)], 1)
-    wavfile.write(str(tmp_path / "a.wav"), 32000, (st * 20000).astype(np.int16))
-    y = tr.load_audio(str(tmp_path / "a.wav"))
-    assert y.dtype == np.float32 and abs(len(y) - 16000) <= 1 and 0.55 < np.abs(y).max() < 0.65
+    # the resampling plan handed to the GPU kernel reproduces scipy.signal.resample_poly (evaluated here in numpy)
+    from scipy.signal import resample_poly
+    rng = np.random.default_rng(0)
+    for rate, n_in in ((44100, 5000), (48000, 3001), (22050, 777), (8000, 500)):
+        x = rng.standard_normal(n_in)
+        up, down, h, npr, n_out = tr.resample_plan(rate, 16000, n_in)
+        ref = resample_poly(x, up, down)
+        assert n_out == len(ref)
+        j = np.arange(n_out)[:, None]
+        i = np.arange(n_in)[None, :]
+        idx = (j + npr) * down - i * up
+        ok = (idx >= 0) & (idx < len(h))
+        y = (np.where(ok, h.astype(np.float64)[np.clip(idx, 0, len(h) - 1)], 0.0) * x[None, :]).sum(1)
+        assert np.abs(y - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    assert tr.resample_plan(16000, 16000, 123)[:2] == (1, 1)
 
 
 def test_cli_errors_like_reference(tmp_path):
