@@ -250,6 +250,8 @@ def main():
     net = model.model
     fe = mta.MelFrontend(SR, N_MELS, HOP, dev)
     NS = max(1, args.streams)
+    # with several batches in flight the projection GEMMs are the shared resource: let layers 1.. project inside the recurrence
+    net.fuse_input_projection = NS >= 2
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
     cmax = [torch.empty(B, device=dev) for _ in range(NS)]
@@ -372,7 +374,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
                                       "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
-                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)", "streams_per_gpu": NS},
+                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)", "streams_per_gpu": NS, "fused_input_projection": bool(net.fuse_input_projection)},
                "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
         print(json.dumps(out))
     if world > 1:

@@ -114,6 +114,12 @@ size_t mt_lstm_hx_bytes(int B, int T, int H);
 size_t mt_lstm_sync_bytes(int B, int H);
 int    mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                          int B, int T, int H, mt_stream_t stream);
+/* A layer fed by the previous LSTM layer, with its input projection fused into the recurrence (no gx buffer, no GEMM, no
+ * re-layout between the layers): gate pre-activations = W_ihx x_t + bias + W_hh h_{t-1}, x_t = the previous layer's h of
+ * step t (both directions) read from ITS hx.  w_ihx [2][4H][2H] f32 (column = dir'*H + unit, zero columns for padded
+ * units), bias [2][4H] = b_ih + b_hh.  H <= 512.                                                                       */
+int    mt_lstm_bidir_fwd_xproj(const float* hx_prev, const float* w_ihx, const float* bias, const float* w_hh, float* hx,
+                               void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream);
 /* mode 0: as above (agent-scope hand-off, correct under any workgroup placement).  mode 1: XCD-local
  * hand-off: each (direction, batch group) runs on workgroups that read their hardware XCC id and share one
  * XCD's L2 (about 2x shorter steps).  It needs the dispatcher to deal the launch's workgroups evenly over the
@@ -148,6 +154,9 @@ typedef struct {
     const float* w_hh[MT_MAX_LSTM_LAYERS];   /* f32 [2][4Hp][Hp]                                  */
     const void*  fc_w;                       /* bf16 [128][roundup(2H,64)], rows >= 88 zero       */
     const float* fc_b;                       /* f32 [88]                                          */
+    const float* w_ihx[MT_MAX_LSTM_LAYERS];  /* layers l > 0 (optional, NULL = project with the GEMM): f32 [2][4Hp][2Hp], */
+                                             /*   column dir'*Hp + k: the input projection fused into the recurrence      */
+                                             /*   (mt_lstm_bidir_fwd_xproj; agent-scope hand-off, Hp <= 512)               */
 } mt_cnnrnn_weights;
 
 size_t mt_cnnrnn_workspace_bytes(const mt_cnnrnn_weights* w, int B, int T);

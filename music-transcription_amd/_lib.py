@@ -52,7 +52,7 @@ class CnnRnnWeights(C.Structure):
     _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("lstm_mode", i32),
                 ("conv1_w", vp), ("conv1_b", vp), ("conv2_w", vp), ("conv2_b", vp),
                 ("w_ih", vp * MAX_LSTM_LAYERS), ("b_gates", vp * MAX_LSTM_LAYERS), ("w_hh", vp * MAX_LSTM_LAYERS),
-                ("fc_w", vp), ("fc_b", vp)]
+                ("fc_w", vp), ("fc_b", vp), ("w_ihx", vp * MAX_LSTM_LAYERS)]
 
 
 class CnnRnnLargeWeights(C.Structure):
@@ -85,6 +85,7 @@ _SIGS = {
     "mt_lstm_hx_bytes": (sz, [i32, i32, i32]),
     "mt_lstm_sync_bytes": (sz, [i32, i32]),
     "mt_lstm_bidir_fwd": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "mt_lstm_bidir_fwd_xproj": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "mt_lstm_bidir_fwd_ex": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
     "mt_xcd_census": (i32, [vp, vp, i32, vp]),
     "mt_lstm_relayout_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),

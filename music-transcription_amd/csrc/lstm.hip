@@ -60,6 +60,11 @@ struct LstmArgs {
     // train mode (lstm_rec_kernel<.., TRAIN = true>): what the backward pass needs (lstm_bwd.hip)
     float* gates_out;     // = gx: the ACTIVATED gates i, f, g, o overwrite the pre-activations in place
     float* cx;            // [NG][T][2][NKB][8][32] cell states
+    // fused input projection (lstm_rec_kernel<.., XP = true>): gx is not read; the gate pre-activations are
+    // W_ihx x_t + bias + W_hh h_{t-1}, with x_t = the previous layer's h of step t (both directions) read from ITS hx
+    const float* w_ihx;   // [2][4H][2H] f32, column = direction' * H + unit of the previous layer (zero columns for padded units)
+    const float* bias;    // [2][4H] = b_ih + b_hh
+    const float* hx_prev; // the previous layer's hx (complete: written by an earlier launch)
 };
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): absolute error ~1e-7, saturate cleanly for |x| large
@@ -92,7 +97,14 @@ __device__ unsigned long long mt_lstm_diag[1024][8];
 // the status word), never a stale read.  The host sizes the grid 8 x S (the dispatcher deals workgroups
 // round-robin over the 8 XCDs) and falls back to the agent-scope variant (XCD = false) if a census launch at
 // start-up shows a different distribution.
-template <int NKSW, bool XCD, bool TRAIN = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
+// XP = true: the layer's INPUT PROJECTION is fused in (layers fed by another LSTM layer): no gx buffer (0.5 GB written by a
+// GEMM and read back here), no projection GEMM, no re-layout pass between the layers.  x_t is read as MFMA B operands
+// straight from the previous layer's hx images (plain loads, issued at the top of the step), and the product W_ihx x_t
+// (2 NKSW MFMAs per wave) runs right behind the issue of the h gather, under its latency.  The recurrence step gets longer
+// (2.35 vs 1.65 us at H = 512: 64 KB more per workgroup per step in front of the gather in the in-order memory queue),
+// the projection GEMM (0.38 ms) and the re-layout disappear: a loss with one batch in flight (-6 %), a gain when
+// several are (+8 % at three: the GEMMs are the serialised resource there).  Opt-in (mt_cnnrnn_weights.w_ihx).
+template <int NKSW, bool XCD, bool TRAIN = false, bool XP = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
 __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][64][20];       // [k-slice wave][lane][16 regs + pad]: 80-B lane stride, conflict-free b128
     __shared__ __attribute__((aligned(16))) f16_t hs[32][8];           // [batch][unit]
@@ -135,14 +147,34 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
         for (int j = 0; j < 8; ++j) w16[i][j] = (ks < nks) ? (f16_t)wsrc[ks * 16 + 8 * hh + j] : (f16_t)0.0f;
     }
 
+    // XP: the W_ih slice of the same 32 gate rows over the 2H input features (2 NKSW k-steps per wave), f16
+    constexpr int NKSX = XP ? 2 * NKSW : 1;
+    f16x8 wx[NKSX];
+    if (XP) {
+        const float* wxsrc = a.w_ihx + ((size_t)d * 4 * H + wrow) * (2 * H);
+#pragma unroll
+        for (int i = 0; i < NKSX; ++i) {
+            const int kx = wv * NKSX + i;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wx[i][j] = (kx < 2 * nks) ? (f16_t)wxsrc[kx * 16 + 8 * hh + j] : (f16_t)0.0f;
+        }
+    }
+
     // this thread's cell: unit jl = 2*wv + hh of the workgroup, batch row b
     const int jl = 2 * wv + hh;
     float c = 0.0f;
+    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (XP) {
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) bias4[pp] = a.bias[(size_t)d * 4 * H + pp * H + kb * 8 + jl];
+    }
     const size_t gd_blocks = (size_t)T * 2 * nkb;                       // (t, d, kb) blocks per batch group: 4 KB of gx, 512 B of hx each
     const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
     char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
     // buffer resource over this group's hx (all t, both d): offsets stay < 2^31
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        XP ? (void*)((const char*)a.hx_prev + (size_t)g * gd_blocks * 512) : (void*)hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
     // step flags are kept in FLAG_REPL replicas on separate cache lines: a producer writes all replicas with one
     // wave instruction, a consumer polls the replica kb % FLAG_REPL, so each flag line has nkb / FLAG_REPL pollers
     // instead of nkb (loads that bypass the caches serialise at the line's home memory channel)
@@ -162,11 +194,27 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
         float gxv[4];
         const float* gxp = gx_g + (((size_t)t * 2 + d) * nkb + kb) * 1024 + jl * 32 + b;
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) gxv[pp] = (b < Bg) ? gxp[pp * 256] : 0.0f;
-
-        f32x16 acc;
+        for (int pp = 0; pp < 4; ++pp) gxv[pp] = XP ? bias4[pp] : ((b < Bg) ? gxp[pp * 256] : 0.0f);
+        // XP: x_t = the previous layer's h of step t, both directions (2H features), as MFMA B operands straight from its
+        // hx images (plain loads: that buffer is complete)
+        typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_;
+        u32x4_ xr[NKSX];
+        if (XP) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            for (int i = 0; i < NKSX; ++i) {
+                const int kx = wv * NKSX + i, dsel = kx >= nks ? 1 : 0, ksx = kx - dsel * nks;
+                xr[i] = (kx < 2 * nks) ? __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((t * 2 + dsel) * nkb) * 512 + ksx * 1024 + lane * 16, 0, 0)
+                                       : u32x4_{0, 0, 0, 0};
+            }
+        }
+        f32x16 acc, accx;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = accx[e] = 0.0f;
+        if (XP && s == 0) {
+#pragma unroll
+            for (int i = 0; i < NKSX; ++i) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wx[i], __builtin_bit_cast(f16x8, xr[i]), accx, 0, 0, 0);
+            acc = accx;
+        }
         if (s > 0) {
             if (XCD) {
             // ---- XCD-local variant: wait until every workgroup of this direction has published step s-1.  One round trip per
@@ -218,6 +266,15 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
                 for (int i = 0; i < NKSW; ++i) {
                     const int ks = wv * NKSW + i;
                     rh[i] = (ks < nks) ? __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 1024, 0, 16 /*sc1*/) : u32x4{0, 0, 0, 0};
+                }
+                if (XP) {
+                    if (it == 0) {                     // the input projection runs under the gather's latency
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < NKSX; ++i) accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(wx[i], __builtin_bit_cast(f16x8, xr[i]), accx, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    acc = accx;
                 }
                 unsigned worst = 0;
 #pragma unroll
@@ -517,7 +574,8 @@ static int launch_rec16(const LstmArgs& a, hipStream_t st) {
 
 template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, bool xcd, hipStream_t st) {
-    if (a.cx) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
+    if (a.w_ihx) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false, false, true>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
+    else if (a.cx) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
     else if (xcd) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, true>), dim3(8 * (a.H >> 3)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
     return 0;
@@ -553,8 +611,9 @@ extern "C" int mt_xcd_census(int* counts_host, void* scratch32, int nwg, mt_stre
 }
 
 static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
-                         int B, int T, int H, int xcd_local, mt_stream_t stream, float* cx = nullptr) {
-    MT_REQUIRE(gx && w_hh && hx && sync_ws, MT_EINVAL, "mt_lstm_bidir_fwd: null pointer");
+                         int B, int T, int H, int xcd_local, mt_stream_t stream, float* cx = nullptr,
+                         const float* w_ihx = nullptr, const float* bias = nullptr, const float* hx_prev = nullptr) {
+    MT_REQUIRE((gx || w_ihx) && w_hh && hx && sync_ws, MT_EINVAL, "mt_lstm_bidir_fwd: null pointer");
     MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 1024, MT_EUNSUPPORTED,
                "mt_lstm_bidir_fwd: hidden size %d unsupported (multiple of 16, <= 1024)", H);
     MT_REQUIRE(sync_bytes >= mt_lstm_sync_bytes(B, H), MT_EWORKSPACE, "mt_lstm_bidir_fwd: sync workspace too small");
@@ -565,7 +624,7 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
     // sync_ws: [0] status word, [32..64) XCD tickets, [256..) flags (own cache lines, away from the polled status word)
     LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, 0, (unsigned*)((char*)sync_ws + 32), 0, 0,
-               cx ? const_cast<float*>(gx) : nullptr, cx};
+               cx ? const_cast<float*>(gx) : nullptr, cx, w_ihx, bias, hx_prev};
     // every workgroup of a launch must be resident (they wait on each other).  Agent-scope variant: at most 256
     // workgroups (one per CU) per launch; XCD-local variant: at most 8 lanes = 4 batch groups per launch, each lane's
     // H/8 workgroups share one XCD (H/8 <= 128 -> at most 4 per CU).  Further groups run as further launches.
@@ -598,6 +657,16 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
 extern "C" int mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                                  int B, int T, int H, mt_stream_t stream) {
     return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, 0, stream);
+}
+
+// A layer whose input is the previous LSTM layer's output, with its input projection fused into the recurrence (see
+// lstm_rec_kernel, XP).  hx_prev: the previous layer's hx (same B, T, H); w_ihx [2][4H][2H] f32 (column = direction' * H +
+// unit, zero for padded units); bias [2][4H] = b_ih + b_hh.
+extern "C" int mt_lstm_bidir_fwd_xproj(const float* hx_prev, const float* w_ihx, const float* bias, const float* w_hh, float* hx,
+                                       void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream) {
+    MT_REQUIRE(hx_prev && w_ihx && bias && hx_prev != hx, MT_EINVAL, "mt_lstm_bidir_fwd_xproj: bad arguments");
+    MT_REQUIRE(H <= 512, MT_EUNSUPPORTED, "mt_lstm_bidir_fwd_xproj: H=%d > 512 (the W_ih slice lives in registers)", H);
+    return lstm_fwd_impl(nullptr, w_hh, hx, sync_ws, sync_bytes, B, T, H, 0, stream, nullptr, w_ihx, bias, hx_prev);
 }
 
 // Train-mode forward: as mt_lstm_bidir_fwd, and additionally the activated gates overwrite gx in place and the cell

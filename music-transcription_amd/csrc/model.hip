@@ -11,6 +11,7 @@ int mt_gemm_lstm_gx(const void*, int, const void*, int, const float*, float*, in
 int mt_gemm_logits(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
 int mt_lstm_relayout_ex(const float*, void*, int, float*, int, int, int, int, int, int, mt_stream_t);
+int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 size_t mt_lstm_gx_bytes(int, int, int);
 size_t mt_lstm_hx_bytes(int, int, int);
 size_t mt_lstm_sync_bytes(int, int);
@@ -19,7 +20,7 @@ size_t mt_lstm_sync_bytes(int, int);
 namespace mt {
 struct CnnRnnPlan {
     int F1, Fo2, K0, K1, M, Mpad, Hp;
-    size_t act1, x0, x1, gx, hx, sync, sync_stride, total;
+    size_t act1, x0, x1, gx, hx, hx2, sync, sync_stride, total;
 };
 static CnnRnnPlan plan(const mt_cnnrnn_weights* w, int B, int T) {
     CnnRnnPlan p;
@@ -34,6 +35,7 @@ static CnnRnnPlan plan(const mt_cnnrnn_weights* w, int B, int T) {
     p.x1 = o;   o += align_up((size_t)p.Mpad * p.K1 * 2, 256);
     p.gx = o;   o += align_up(mt_lstm_gx_bytes(B, T, p.Hp), 256);
     p.hx = o;   o += align_up(mt_lstm_hx_bytes(B, T, p.Hp), 256);
+    p.hx2 = o;  o += align_up(mt_lstm_hx_bytes(B, T, p.Hp), 256);      // ping-pong partner for the fused-projection layers
     p.sync_stride = align_up(mt_lstm_sync_bytes(B, p.Hp), 256);
     p.sync = o; o += p.sync_stride * w->layers;
     p.total = o;
@@ -96,15 +98,30 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
     if ((rc = mt_conv2_bn_relu_pool(ws + p.act1, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, p.F1, T, stream)) != MT_OK) return rc;
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     if (p.K1 != 2 * Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, (hipStream_t)stream));
+    char* hcur = ws + p.hx;                  // the previous layer's output images
+    char* hnext = ws + p.hx2;
     for (int l = 0; l < w->layers; ++l) {
-        const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
-        const int K = l == 0 ? p.K0 : p.K1;
-        if ((rc = mt_gemm_lstm_gx(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, stream)) != MT_OK) return rc;
+        const bool last = l + 1 == w->layers;
+        // layers > 0 with packed W_ihx: input projection fused into the recurrence (reads the previous layer's hx directly)
+        const bool fused = l > 0 && w->w_ihx[l] && w->lstm_mode == 0 && H <= 512;
+        if (fused) {
+            if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;              // (no projection GEMM: empty stage)
+            if ((rc = mt_lstm_bidir_fwd_xproj((const float*)hcur, w->w_ihx[l], w->b_gates[l], w->w_hh[l], (float*)hnext,
+                                              ws + p.sync + p.sync_stride * l, p.sync_stride, B, T, H, stream)) != MT_OK) return rc;
+            char* tmp = hcur; hcur = hnext; hnext = tmp;
+        } else {
+            const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
+            const int K = l == 0 ? p.K0 : p.K1;
+            if ((rc = mt_gemm_lstm_gx(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, stream)) != MT_OK) return rc;
+            if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
+            if ((rc = mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * l,
+                                           p.sync_stride, B, T, H, w->lstm_mode, stream)) != MT_OK) return rc;
+        }
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
-        if ((rc = mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * l,
-                                    p.sync_stride, B, T, H, w->lstm_mode, stream)) != MT_OK) return rc;
-        if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
-        if ((rc = mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.x1, p.K1, nullptr, 0, 0, B, T, H, Hv, stream)) != MT_OK) return rc;
+        // the next consumer of feature ROWS: a GEMM-projected layer, or the final fc
+        const bool next_fused = !last && w->w_ihx[l + 1] && w->lstm_mode == 0 && H <= 512;
+        if (!next_fused)
+            if ((rc = mt_lstm_relayout_ex((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, H, Hv, stream)) != MT_OK) return rc;
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     }
     if ((rc = mt_gemm_logits(ws + p.x1, p.K1, w->fc_w, p.K1, w->fc_b, logits, B, T, MT_N_PITCH, p.K1, stream)) != MT_OK) return rc;

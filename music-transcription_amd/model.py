@@ -13,6 +13,7 @@ not implement yet raises.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -159,6 +160,15 @@ class CNNRNNModel(nn.Module, _HipForward):
         wi, bg, wh = _pack_bilstm(self.rnn, L, H, cols, device)
         for l in range(L):
             t[f"w_ih{l}"], t[f"b_g{l}"], t[f"w_hh{l}"] = wi[l], bg[l], wh[l]
+        # layers > 0: W_ih in the layout of the fused input projection (mt_lstm_bidir_fwd_xproj): f32 [2][4Hp][2Hp],
+        # column dir'*Hp + k of the previous layer's (padded) hidden units
+        Hp = _round_up(H, 16)
+        for l in range(1, L):
+            wx = torch.zeros(2, 4, Hp, 2, Hp, dtype=torch.float32, device=device)
+            for di, suf in enumerate(("", "_reverse")):
+                wsrc = getattr(self.rnn, f"weight_ih_l{l}{suf}").detach().to(device, torch.float32).reshape(4, H, 2, H)
+                wx[di, :, :H, :, :H] = wsrc
+            t[f"w_ihx{l}"] = wx.reshape(2, 4 * Hp, 2 * Hp).contiguous()
         fw = torch.zeros(128, K1)
         fw[:88, :2 * H] = self.fc.weight.detach().float().cpu()
         t["fc_w"] = _bf16(fw).to(**dev)
@@ -168,6 +178,7 @@ class CNNRNNModel(nn.Module, _HipForward):
         w.conv1_w, w.conv1_b, w.conv2_w, w.conv2_b = (ptr(t[k]) for k in ("conv1_w", "conv1_b", "conv2_w", "conv2_b"))
         for l in range(L):
             w.w_ih[l], w.b_gates[l], w.w_hh[l] = ptr(t[f"w_ih{l}"]), ptr(t[f"b_g{l}"]), ptr(t[f"w_hh{l}"])
+            w.w_ihx[l] = None                        # set per call from self.fuse_input_projection (forward)
         w.fc_w, w.fc_b = ptr(t["fc_w"]), ptr(t["fc_b"])
         return {"tensors": t, "struct": w}
 
@@ -207,6 +218,13 @@ class CNNRNNModel(nn.Module, _HipForward):
             n_ev = len(events)
             ev_arr = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in events])
         w.lstm_mode = lstm_mode(x.device)
+        # Layers > 0 can take their input projection inside the recurrence (no GEMM, no gx buffer, no re-layout between LSTM
+        # layers; csrc/lstm.hip, XP).  It lengthens the latency-bound recurrence and removes GEMM work: a loss with one batch in
+        # flight, a gain with several (the GEMMs are the shared resource then) -- so the caller decides.  MT_LSTM_XPROJ=0/1 forces it.
+        env = os.environ.get("MT_LSTM_XPROJ")
+        fuse = (env == "1") if env in ("0", "1") else bool(getattr(self, "fuse_input_projection", False))
+        for l in range(1, self.num_layers):
+            w.w_ihx[l] = ptr(pk["tensors"][f"w_ihx{l}"]) if (fuse and self.hidden_size <= 512) else None
         with torch.cuda.device(x.device):
             check(lib.mt_cnnrnn_forward_ex(w, ptr(x), ptr(chunk_max_power), B, T, ptr(logits), ptr(ws), ws.numel(),
                                            ev_arr, n_ev, _lib.stream_ptr()), "mt_cnnrnn_forward")

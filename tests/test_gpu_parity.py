@@ -391,3 +391,42 @@ def test_load_audio_device_matches_scipy_resample_poly(mta, tmp_path, rate, ch, 
     chunks, dur = tr.split_into_chunks_device(y)
     assert chunks.shape == (max(1, -(-len(ref) // 480000)), 480000) and abs(dur - len(ref) / 16000.0) < 1e-9
     assert torch.equal(chunks.reshape(-1)[:len(ref)], y) and float(chunks.reshape(-1)[len(ref):].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("tag", ["small_a", "small_b"])
+def test_fused_input_projection_matches_goldens(mta, golden_dir, tag):
+    """CNNRNNModel.fuse_input_projection: layers > 0 project their input inside the recurrence (csrc/lstm.hip, XP) -- same
+    tolerances against the reference goldens and the emulating oracle as the GEMM path, and close to it."""
+    z = np.load(os.path.join(golden_dir, "small_models.npz"))
+    nm, hs, nl, B, T, seed_w, seed_x = [int(v) for v in z[f"{tag}_cfg"]]
+    sd = R.make_state_dict("cnn_rnn", nm, hs, nl, seed_w)
+    R.set_bn_flat(sd, z[f"{tag}_bn"])
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = _mel_in(B, nm, T, seed_x)
+    with torch.no_grad():
+        plain = model.model(x.cuda(), check_status=True).cpu()
+        model.model.fuse_input_projection = True
+        fused = model.model(x.cuda(), check_status=True).cpu()
+        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_bf16=True))
+    assert not torch.equal(plain, fused)                                  # a different code path ...
+    assert (fused - plain).abs().max().item() < 2e-3                      # ... with the same answer
+    assert (fused - emu).abs().max().item() < 2e-3
+    assert np.abs(fused.numpy() - z[f"{tag}_logits"]).max() < 3e-2
+
+
+def test_fused_input_projection_full_size(mta):
+    from oracle import frontend_ref as FR
+    sd = R.make_state_dict("cnn_rnn", 320, 512, 3, seed=0)
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=320, hidden_size=512, num_layers=3, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    wave = torch.from_numpy(FR.synth_audio(4, 480000, seed=5)).cuda()
+    mel, _ = mta.MelFrontend(16000, 320, 512, "cuda")(torch.cat([wave, 0.5 * wave, 0.25 * wave, 0.7 * wave]), clamp=True)
+    with torch.no_grad():
+        plain = model(mel).clone()
+        model.model.fuse_input_projection = True
+        fused = model(mel).clone()
+        again = model(mel).clone()
+    model.model.raise_on_handoff_timeout(16, 938)
+    assert torch.equal(fused, again) and (fused - plain).abs().max().item() < 3e-3
