@@ -37,7 +37,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3
 N_SAMPLES, SR, HOP, N_MELS, HIDDEN, LAYERS = 480000, 16000, 512, 320, 512, 3
 
 
-def stage_table(B, T, n_mels, H, L):
+def stage_table(B, T, n_mels, H, L, fused=False):
     """(name, bound, work per launch, unit of work) for each timed stage, in launch order.
     Algorithmic figures: SURVEY 8(d) / DESIGN.md 'Kernels'."""
     F1, Fo2 = n_mels // 2, n_mels // 4
@@ -47,11 +47,14 @@ def stage_table(B, T, n_mels, H, L):
           ("conv2_kernel", "mfma", 2.0 * B * (2 * Fo2) * T * 64 * 288, "FLOP")]
     for l in range(L):
         K = Fo2 * 64 if l == 0 else 2 * H
-        st.append((f"gemm_lstm_gx_l{l}", "mfma", 2.0 * M * 8 * H * K, "FLOP"))
-        # algorithmic FLOPs of W_hh h; the kernel issues 3 bf16 MFMAs per product (split precision) and is
-        # bound by the per-step inter-workgroup hand-off latency, not by the matrix pipe
-        st.append((f"lstm_rec_l{l}", "mfma", 2.0 * M * 8 * H * H, "FLOP"))
-        st.append((f"lstm_relayout_l{l}", "hbm", M * 2 * H * (4 + 2), "B"))
+        proj = 2.0 * M * 8 * H * K
+        in_rec = fused and l > 0                     # layers > 0 project inside the recurrence: their GEMM stage is empty
+        st.append((f"gemm_lstm_gx_l{l}", "mfma", 0.0 if in_rec else proj, "FLOP"))
+        # algorithmic FLOPs of W_hh h (+ W_ih x when fused); f16 MFMA; the kernel is bound by the per-step
+        # inter-workgroup hand-off latency, not by the matrix pipe
+        st.append((f"lstm_rec_l{l}", "mfma_f16", 2.0 * M * 8 * H * H + (proj if in_rec else 0.0), "FLOP"))
+        # (the re-layout pass is skipped when the next layer reads hx directly)
+        st.append((f"lstm_relayout_l{l}", "hbm", 0 if (fused and l + 1 < L) else M * 2 * H * (4 + 2), "B"))
     st.append(("gemm_logits", "mfma", 2.0 * M * 88 * 2 * H, "FLOP"))
     return st
 
@@ -298,21 +301,21 @@ def main():
 
     if rank == 0:
         # ---- per-kernel times from the events recorded inside the timed region
-        table = stage_table(B, T, N_MELS, HIDDEN, LAYERS)
+        table = stage_table(B, T, N_MELS, HIDDEN, LAYERS, fused=bool(net.fuse_input_projection))
         ms = [float(np.mean([ev_mel[i][0].elapsed_time(ev_mel[i][1]) for i in range(K)]))]
         for s in range(nst):
             ms.append(float(np.mean([ev_net[i][s].elapsed_time(ev_net[i][s + 1]) for i in range(K)])))
         stages = []
         for (name, bound, work, unit), t_ms in zip(table, ms):
             if unit == "B":
-                ach, peak, u = work / (t_ms * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+                ach, peak, u = work / (max(t_ms, 1e-6) * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
             else:
-                ach = work / (t_ms * 1e-3) / 1e12
-                peak, u = (PEAK_F32_MATRIX_TFLOPS if bound == "mfma_f32" else PEAK_BF16_TFLOPS), "TFLOP/s"
+                ach = work / (max(t_ms, 1e-6) * 1e-3) / 1e12
+                peak, u = (PEAK_F32_MATRIX_TFLOPS if bound == "mfma_f32" else PEAK_BF16_TFLOPS), "TFLOP/s"    # f16 peak = bf16 peak
             stages.append({"kernel": name, "bound": "hbm" if bound == "hbm" else "mfma", "ms": round(t_ms, 4),
                            "achieved": round(ach, 2), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
                            "work_per_launch": work, "work_unit": unit,
-                           "mfma_dtype": {"mfma": "bf16", "mfma_f32": "f32"}.get(bound)})
+                           "mfma_dtype": {"mfma": "bf16", "mfma_f32": "f32", "mfma_f16": "f16"}.get(bound)})
         # dominant kernel = largest share of the step; the three recurrence launches are one kernel
         groups = {}
         for s in stages:
@@ -369,8 +372,8 @@ def main():
         out = {"metric": "30 s audio chunks/sec (mel+CNNRNN forward)", "value": round(world * B * K / elapsed, 2),
                "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16 MFMA (f32 accumulate) for conv2 / input projections / fc, split-bf16x3 MFMA for the "
-                        "recurrence (f32 state and gates), f32 FFT and conv1",
+               "dtype": "bf16 MFMA (f32 accumulate) for conv2 / layer-0 projection / fc, f16 MFMA for the recurrence and the "
+                        "projections fused into it (f32 state, gates and accumulation), f32 FFT and conv1",
                "data": "synthetic",
                "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
                                       "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
