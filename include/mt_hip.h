@@ -225,6 +225,8 @@ typedef struct {
     const void*  shared_w; const float* shared_b; /* bf16 [roundup(hidden,128)][Cp]                    */
     const void*  heads_w;  const float* heads_b;  /* bf16 [384][roundup(hidden,64)]: frame, onset, offset */
     const void*  fc_w;     const float* fc_b;     /* no-heads variant: bf16 [128][Cp]                  */
+    const float* main_w_ihx[MT_MAX_LSTM_LAYERS];  /* main layers l > 0, optional: f32 [2][4Hp][2Hp] for the input projection */
+                                                  /*   fused into the recurrence (as mt_cnnrnn_weights.w_ihx)                 */
 } mt_cnnrnn_large_weights;
 size_t mt_cnnrnn_large_workspace_bytes(const mt_cnnrnn_large_weights* w, int B, int T);
 size_t mt_cnnrnn_large_status_offset(const mt_cnnrnn_large_weights* w, int B, int T, int idx);

@@ -63,7 +63,8 @@ class CnnRnnLargeWeights(C.Structure):
                                      "rb2c2_w", "rb2c2_b", "fa_w", "fa_b")]
                 + [("main_w_ih", vp * MAX_LSTM_LAYERS), ("main_b", vp * MAX_LSTM_LAYERS), ("main_w_hh", vp * MAX_LSTM_LAYERS)]
                 + [(n, vp) for n in ("local_w_ih", "local_b", "local_w_hh", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln_g", "ln_b",
-                                     "shared_w", "shared_b", "heads_w", "heads_b", "fc_w", "fc_b")])
+                                     "shared_w", "shared_b", "heads_w", "heads_b", "fc_w", "fc_b")]
+                + [("main_w_ihx", vp * MAX_LSTM_LAYERS)])
 
 
 ll = C.c_longlong

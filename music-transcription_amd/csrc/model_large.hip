@@ -17,6 +17,7 @@ int mt_gemm_batched_bf16out(const void*, int, long long, long long, const void*,
                             long long, long long, int, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
 int mt_lstm_relayout_ex(const float*, void*, int, float*, int, int, int, int, int, int, mt_stream_t);
+int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 int mt_attn_softmax_clamped(const float*, int, void*, int, int, long long, float, float, mt_stream_t);
 int mt_attn_transpose_v(const void*, int, int, void*, int, int, int, int, int, mt_stream_t);
 int mt_layernorm_residual(const float*, int, const float*, int, const float*, const float*, void*, int, long long, int, float, mt_stream_t);
@@ -28,7 +29,7 @@ size_t mt_lstm_sync_bytes(int, int);
 namespace mt {
 struct LargePlan {
     int F1, F2, F3, K0, K1, M, Mpad, Tr, Tp, Hp, Hlp, comb, Cp, Hs, dp, ld3, Ca;
-    size_t act1, r1a, r1, r2a, r2, x0, x1, gx, hx, gx2, hx2, sync, sync_stride, rb, r32, qkv, S, P, VT, ao, proj, ln, sh, total;
+    size_t act1, r1a, r1, r2a, r2, x0, x1, gx, hx, gx2, hx2, hx3, sync, sync_stride, rb, r32, qkv, S, P, VT, ao, proj, ln, sh, total;
 };
 static LargePlan lplan(const mt_cnnrnn_large_weights* w, int B, int T) {
     LargePlan p;
@@ -56,6 +57,7 @@ static LargePlan lplan(const mt_cnnrnn_large_weights* w, int B, int T) {
     p.hx = take(mt_lstm_hx_bytes(B, T, Hmax));
     p.gx2 = take(mt_lstm_gx_bytes(B, T, p.Hlp));          // the local LSTM's own buffers: it may run beside the main stack
     p.hx2 = take(mt_lstm_hx_bytes(B, T, p.Hlp));
+    p.hx3 = take(mt_lstm_hx_bytes(B, T, Hmax));            // ping-pong partner of hx for layers with the fused input projection
     p.sync_stride = align_up(mt_lstm_sync_bytes(B, Hmax), 256);
     p.sync = take(p.sync_stride * (w->layers + 1));
     p.rb = take((size_t)p.Mpad * p.Cp * 2);
@@ -131,15 +133,26 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
     RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode, ls));
     RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx2), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, ls));
     if (fork) MT_CHECK_HIP(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)side_stream));
-    // main LSTM
+    // main LSTM; layers > 0 with a packed W_ihx take their input projection inside the recurrence (no GEMM, no re-layout)
+    char* hcur = ws + p.hx;
+    char* hnext = ws + p.hx3;
     for (int l = 0; l < w->layers; ++l) {
-        const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
-        const int K = l == 0 ? p.K0 : p.K1;
-        RUN(mt_gemm_lstm_gx(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, stream));
-        RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)(ws + p.hx), ws + p.sync + p.sync_stride * (l + 1),
-                              p.sync_stride, B, T, p.Hp, w->lstm_mode, stream));
-        if (l + 1 < w->layers) RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, stream));
-        else RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, stream));
+        const bool last = l + 1 == w->layers;
+        const bool fused = l > 0 && w->main_w_ihx[l] && w->lstm_mode == 0 && p.Hp <= 512;
+        if (fused) {
+            RUN(mt_lstm_bidir_fwd_xproj((const float*)hcur, w->main_w_ihx[l], w->main_b[l], w->main_w_hh[l], (float*)hnext,
+                                        ws + p.sync + p.sync_stride * (l + 1), p.sync_stride, B, T, p.Hp, stream));
+            char* tmp = hcur; hcur = hnext; hnext = tmp;
+        } else {
+            const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
+            const int K = l == 0 ? p.K0 : p.K1;
+            RUN(mt_gemm_lstm_gx(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, stream));
+            RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * (l + 1),
+                                  p.sync_stride, B, T, p.Hp, w->lstm_mode, stream));
+        }
+        const bool next_fused = !last && w->main_w_ihx[l + 1] && w->lstm_mode == 0 && p.Hp <= 512;
+        if (last) RUN(mt_lstm_relayout_ex((const float*)hcur, ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, stream));
+        else if (!next_fused) RUN(mt_lstm_relayout_ex((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, stream));
     }
     if (fork) MT_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0));      // both column ranges of rb / r32 are complete
     const void* feat = ws + p.rb;            // [Mpad][Cp] bf16

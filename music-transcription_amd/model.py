@@ -334,9 +334,16 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
         # reference feature index c*F3+f (cnn_rnn_model.py:292-294) -> kernel column f*256+c
         cols = (torch.arange(256)[None, :] * F3 + torch.arange(F3)[:, None]).reshape(-1)
         wi, bg, wh = _pack_bilstm(self.rnn_main, L, H, cols, device)
+        Hp = _round_up(H, 16)
         for l in range(L):
             t[f"m_wi{l}"], t[f"m_b{l}"], t[f"m_wh{l}"] = wi[l], bg[l], wh[l]
             w.main_w_ih[l], w.main_b[l], w.main_w_hh[l] = ptr(wi[l]), ptr(bg[l]), ptr(wh[l])
+            w.main_w_ihx[l] = None                   # set per call from self.fuse_input_projection (forward)
+            if l > 0:                                # W_ih in the layout of the fused input projection (see CNNRNNModel._pack)
+                wx = torch.zeros(2, 4, Hp, 2, Hp, dtype=torch.float32, device=device)
+                for di, suf in enumerate(("", "_reverse")):
+                    wx[di, :, :H, :, :H] = getattr(self.rnn_main, f"weight_ih_l{l}{suf}").detach().to(device, torch.float32).reshape(4, H, 2, H)
+                t[f"m_wix{l}"] = wx.reshape(2, 4 * Hp, 2 * Hp).contiguous()
         wi, bg, wh = _pack_bilstm(self.rnn_local, 1, Hl, cols, device)
         t["l_wi"], t["l_b"], t["l_wh"] = wi[0], bg[0], wh[0]
         w.local_w_ih, w.local_b, w.local_w_hh = ptr(wi[0]), ptr(bg[0]), ptr(wh[0])
@@ -406,6 +413,10 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
                     e.record()                       # creates the underlying hipEvent_t
             self._side[key[2]] = (side, evs)
         side, evs = self._side[key[2]]
+        env = os.environ.get("MT_LSTM_XPROJ")
+        fuse = (env == "1") if env in ("0", "1") else bool(getattr(self, "fuse_input_projection", False))
+        for l in range(1, self.num_layers):
+            w.main_w_ihx[l] = ptr(pk["tensors"][f"m_wix{l}"]) if (fuse and self.hidden_size <= 512) else None
         with torch.cuda.device(x.device):
             check(lib.mt_cnnrnn_large_forward_ex(w, ptr(x), ptr(chunk_max_power), B, T, ptr(out), ptr(ws), ws.numel(),
                                                  _lib.stream_ptr(), side.cuda_stream, evs[0].cuda_event, evs[1].cuda_event),
