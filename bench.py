@@ -335,8 +335,8 @@ def main():
             hit = [v for k, v in prof.items() if dom_key.replace("_l", "").split("_gx")[0] in k.replace("::", "_")]
             if dom_key == "lstm_rec":
                 hit = [v for k, v in prof.items() if "lstm_rec_kernel" in k]
-            if hit and B == 32:
-                traffic = round(hit[0]["hbm_bytes_per_launch_corrected"])
+            if hit and B == 32:      # launch-weighted mean over the kernel's variants (plain / fused-projection recurrence)
+                traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
         except Exception:
             traffic = None
         roofline = {"kernel": dom_key, "bound": ref["bound"], "achieved": round(ach, 2), "peak": ref["peak"],
