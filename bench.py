@@ -253,8 +253,15 @@ def main():
     net = model.model
     fe = mta.MelFrontend(SR, N_MELS, HOP, dev)
     NS = max(1, args.streams)
+    # Persistent recurrence launches wait on their own workgroups, so every launch in flight must eventually be fully
+    # resident.  A plain recurrence workgroup needs a third of a CU's registers (768 slots per GPU = 6 launches of 128),
+    # one with the fused projection a whole CU's (256 slots = 2 launches): with at most 3 launches in flight the third
+    # always gets the slots the first frees (deficits sum to 128 = one launch); 4+ fused launches could starve each other
+    # until the 2 s spin bound trips.  Hence: fusion only for 2-3 streams, never more than 6 streams.
+    if NS > 6:
+        raise SystemExit("--streams: at most 6 forwards in flight per GPU (co-residency of the persistent recurrence launches)")
     # with several batches in flight the projection GEMMs are the shared resource: let layers 1.. project inside the recurrence
-    net.fuse_input_projection = NS >= 2
+    net.fuse_input_projection = 2 <= NS <= 3
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
     cmax = [torch.empty(B, device=dev) for _ in range(NS)]

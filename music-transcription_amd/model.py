@@ -221,6 +221,8 @@ class CNNRNNModel(nn.Module, _HipForward):
         # Layers > 0 can take their input projection inside the recurrence (no GEMM, no gx buffer, no re-layout between LSTM
         # layers; csrc/lstm.hip, XP).  It lengthens the latency-bound recurrence and removes GEMM work: a loss with one batch in
         # flight, a gain with several (the GEMMs are the shared resource then) -- so the caller decides.  MT_LSTM_XPROJ=0/1 forces it.
+        # A fused recurrence workgroup fills a CU's register file (one per CU, 256 per GPU = two launches): keep at most THREE
+        # forwards of this model in flight per GPU with it (see bench.py), at most six without.
         env = os.environ.get("MT_LSTM_XPROJ")
         fuse = (env == "1") if env in ("0", "1") else bool(getattr(self, "fuse_input_projection", False))
         for l in range(1, self.num_layers):
