@@ -72,6 +72,16 @@ def pack_train(model, dev) -> Dict[str, object]:
     return t
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 def _gemm(A, lda, W, ldw, C, ldc, M, N, K, bias=None):
     # the kernel reads whole 128-row tiles of both operands: the views handed in must cover them
     assert A.numel() >= (_ru(M, 128) - 1) * lda + K and W.numel() >= (_ru(N, 128) - 1) * ldw + K, "GEMM operand smaller than its tiles"
@@ -162,15 +172,20 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         # ---- fc: dW = dL^T X_L, db = sum dL, dX_L = dL W
         dL, dLT = torch.zeros(Mpad, 128, **bf), torch.zeros(128, Mpad, **bf)
         check(lib.mt_dlogits_pack(ptr(dlogits), ptr(dL), ptr(dLT), Mpad, B, 88, T, _st()), "mt_dlogits_pack")
-        Kmax = max(K0, K1)
-        XT = torch.empty(_ru(Kmax, 128) * Mpad, **bf)
-        check(lib.mt_transpose_bf16(ptr(Xs[L]), K1, M, K1, ptr(XT), Mpad, K1, _st()), "mt_transpose_bf16")
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        XT = torch.empty(_ru(K1, 128) * Mpad, **bf)
         gfc = torch.empty(128, K1, **f32)
-        _gemm(dLT, Mpad, XT, Mpad, gfc, K1, 88, K1, Mpad)
-        g["fc.weight"] = torch.empty(88, 2 * H, **f32)
-        _gather4(gfc, 0, g["fc.weight"], (1, 1, 88, 2 * H), (0, 0, K1, 1))
-        g["fc.bias"] = torch.empty(88, **f32)
-        check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(g["fc.bias"]), 88, _st()), "mt_rowsum_bf16")
+        g["fc.weight"], g["fc.bias"] = torch.empty(88, 2 * H, **f32), torch.empty(88, **f32)
+        keep = [dL, dLT, XT, gfc]                    # side-stream operands stay referenced until the streams have joined
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        with torch.cuda.stream(side):                # weight gradients never gate the layers below: side stream
+            side.wait_event(ev0)
+            check(lib.mt_transpose_bf16(ptr(Xs[L]), K1, M, K1, ptr(XT), Mpad, K1, _st()), "mt_transpose_bf16")
+            _gemm(dLT, Mpad, XT, Mpad, gfc, K1, 88, K1, Mpad)
+            _gather4(gfc, 0, g["fc.weight"], (1, 1, 88, 2 * H), (0, 0, K1, 1))
+            check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(g["fc.bias"]), 88, _st()), "mt_rowsum_bf16")
         dXn = torch.empty(M, K1, **f32)
         _gemm(dL, 128, pk["fc_wT"], 128, dXn, K1, M, K1, 128)
         # ---- LSTM layers, top to bottom
@@ -179,9 +194,9 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
         part = torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
         Hr = _ru(Hp, 128)
-        HT = torch.zeros(2 * Hr, Mpad, **bf)
-        gb = torch.empty(8 * Hp, **f32)
         dX0 = None
+        # The weight gradients of a layer (dW_ih, dW_hh, db: transposes + GEMMs with K = T*B) are not needed by the layers
+        # below it: they run on a side stream under the next layer's backward recurrence, which is latency-bound on 32 CUs.
         for l in range(L - 1, -1, -1):
             K = K0 if l == 0 else K1
             p = sv["dropout"] if l < L - 1 else 0.0
@@ -191,31 +206,42 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             # dGT is also read as a GEMM A operand from row 4Hp (reverse direction): whole 128-row tiles must stay inside it
             dG, dGT = torch.zeros(Mpad, 8 * Hp, **bf), torch.zeros(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
             check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * Hp, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
-            check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
-            check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XT), Mpad, K, _st()), "mt_transpose_bf16")
-            gwi = torch.empty(8 * Hp, K, **f32)
-            _gemm(dGT, Mpad, XT, Mpad, gwi, K, 8 * Hp, K, Mpad)
-            check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HT), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
-            gwh = torch.empty(2, 4 * Hp, Hp, **f32)
+            # buffers of the side-stream work are allocated here, on the main stream (stream-ordered allocator)
+            XTl = torch.empty(_ru(K, 128) * Mpad, **bf)
+            HT = torch.zeros(2 * Hr, Mpad, **bf)
+            gb, gwi, gwh = torch.empty(8 * Hp, **f32), torch.empty(8 * Hp, K, **f32), torch.empty(2, 4 * Hp, Hp, **f32)
+            outs = []
             for di in range(2):
-                _gemm(dGT[di * 4 * Hp:], Mpad, HT[di * Hr:], Mpad, gwh[di], Hp, 4 * Hp, Hp, Mpad)
+                outs.append((torch.empty(4 * H, 64 * Fo2 if l == 0 else 2 * H, **f32), torch.empty(4 * H, H, **f32), torch.empty(4 * H, **f32),
+                             torch.empty(4 * H, **f32)))
+            keep += [dG, dGT, XTl, HT, gb, gwi, gwh]
+            ev = torch.cuda.Event()
+            ev.record(main)
+            # ---- input gradient: the only product the next layer down waits for
             if l > 0:
                 _gemm(dG, 8 * Hp, pk["w_ihT"][l], 8 * Hp, dXn, K1, M, K1, 8 * Hp)
             else:
                 dX0 = torch.empty(M, K0, **f32)
                 _gemm(dG, 8 * Hp, pk["w_ihT"][0], 8 * Hp, dX0, K0, M, K0, 8 * Hp)
-            for di, suf in enumerate(("", "_reverse")):
-                wi = torch.empty(4 * H, 64 * Fo2 if l == 0 else 2 * H, **f32)
-                if l == 0:
-                    _gather4(gwi, di * 4 * Hp * K, wi, (4, H, 64, Fo2), (Hp * K, K, 1, 64))
-                else:
-                    _gather4(gwi, di * 4 * Hp * K, wi, (4, H, 1, 2 * H), (Hp * K, K, 0, 1))
-                wh = torch.empty(4 * H, H, **f32)
-                _gather4(gwh, di * 4 * Hp * Hp, wh, (4, H, 1, H), (Hp * Hp, Hp, 0, 1))
-                bb = torch.empty(4 * H, **f32)
-                _gather4(gb, di * 4 * Hp, bb, (1, 1, 4, H), (0, 0, Hp, 1))
-                g[f"rnn.weight_ih_l{l}{suf}"], g[f"rnn.weight_hh_l{l}{suf}"] = wi, wh
-                g[f"rnn.bias_ih_l{l}{suf}"], g[f"rnn.bias_hh_l{l}{suf}"] = bb, bb.clone()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
+                check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XTl), Mpad, K, _st()), "mt_transpose_bf16")
+                _gemm(dGT, Mpad, XTl, Mpad, gwi, K, 8 * Hp, K, Mpad)
+                check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HT), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
+                for di in range(2):
+                    _gemm(dGT[di * 4 * Hp:], Mpad, HT[di * Hr:], Mpad, gwh[di], Hp, 4 * Hp, Hp, Mpad)
+                for di, suf in enumerate(("", "_reverse")):
+                    wi, wh, bb, bb2 = outs[di]
+                    if l == 0:
+                        _gather4(gwi, di * 4 * Hp * K, wi, (4, H, 64, Fo2), (Hp * K, K, 1, 64))
+                    else:
+                        _gather4(gwi, di * 4 * Hp * K, wi, (4, H, 1, 2 * H), (Hp * K, K, 0, 1))
+                    _gather4(gwh, di * 4 * Hp * Hp, wh, (4, H, 1, H), (Hp * Hp, Hp, 0, 1))
+                    _gather4(gb, di * 4 * Hp, bb, (1, 1, 4, H), (0, 0, Hp, 1))
+                    _gather4(gb, di * 4 * Hp, bb2, (1, 1, 4, H), (0, 0, Hp, 1))
+                    g[f"rnn.weight_ih_l{l}{suf}"], g[f"rnn.weight_hh_l{l}{suf}"] = wi, wh
+                    g[f"rnn.bias_ih_l{l}{suf}"], g[f"rnn.bias_hh_l{l}{suf}"] = bb, bb2
         # ---- conv2: BN + ReLU + pool backward, dgrad (flipped-weight conv), wgrad (split-K GEMM over positions)
         sums = torch.zeros(512, device=dev, dtype=torch.float64)
         Npos = B * F1 * T
@@ -231,19 +257,25 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         Ks = 64 * ((n64 + S - 1) // S)
         S = (n64 * 64 + Ks - 1) // Ks
         Np = S * Ks
-        dz2T, colT = torch.zeros(2, 128, Np, **bf), torch.zeros(384, Np, **bf)      # dz2T[0] = hi piece, [1] = lo piece
-        check(lib.mt_transpose_bf16(ptr(dz2), 64, Npos, 64, ptr(dz2T[0]), Np, 64, _st()), "mt_transpose_bf16")
-        check(lib.mt_transpose_bf16(ptr(dz2lo), 64, Npos, 64, ptr(dz2T[1]), Np, 64, _st()), "mt_transpose_bf16")
-        check(lib.mt_im2col_t_3x3_c32(ptr(sv["a1"]), ptr(colT), Np, B, F1, T, _st()), "mt_im2col_t_3x3_c32")
+        dz2T, colT = torch.empty(2, 128, Np, **bf), torch.empty(384, Np, **bf)      # dz2T[0] = hi piece, [1] = lo piece (zeroed on the side stream)
         P = torch.empty(2 * S, 64, 288, **f32)          # batch z = piece * S + slice
-        check(lib.mt_gemm_batched_f32(ptr(dz2T), Np, 128 * Np, Ks, ptr(colT), Np, 0, Ks, None, ptr(P), 288, S * 64 * 288, 64 * 288,
-                                      64, 288, Ks, 2 * S, S, _st()), "mt_gemm_batched_f32 (wgrad)")
         gw2 = torch.empty(64, 288, **f32)
-        check(lib.mt_sum_slices_f32(ptr(P), 64 * 288, 288, 2 * S, ptr(gw2), 288, 64, 288, _st()), "mt_sum_slices_f32")
-        g["cnn.4.weight"] = torch.empty(64, 32, 3, 3, **f32)
-        _gather4(gw2, 0, g["cnn.4.weight"], (1, 64, 32, 9), (0, 288, 1, 32))
-        g["cnn.4.bias"] = torch.empty(64, **f32)
-        check(lib.mt_rowsum_bf16(ptr(dz2T[0]), Np, Npos, ptr(g["cnn.4.bias"]), 64, _st()), "mt_rowsum_bf16")
+        g["cnn.4.weight"], g["cnn.4.bias"] = torch.empty(64, 32, 3, 3, **f32), torch.empty(64, **f32)
+        keep += [dz2, dz2lo, dz2T, colT, P, gw2]
+        ev2 = torch.cuda.Event()
+        ev2.record(main)
+        with torch.cuda.stream(side):                    # conv2 weight gradient beside the conv1 backward
+            side.wait_event(ev2)
+            dz2T.zero_()                                 # K-padding columns / unused rows must be finite zeros
+            colT.zero_()
+            check(lib.mt_transpose_bf16(ptr(dz2), 64, Npos, 64, ptr(dz2T[0]), Np, 64, _st()), "mt_transpose_bf16")
+            check(lib.mt_transpose_bf16(ptr(dz2lo), 64, Npos, 64, ptr(dz2T[1]), Np, 64, _st()), "mt_transpose_bf16")
+            check(lib.mt_im2col_t_3x3_c32(ptr(sv["a1"]), ptr(colT), Np, B, F1, T, _st()), "mt_im2col_t_3x3_c32")
+            check(lib.mt_gemm_batched_f32(ptr(dz2T), Np, 128 * Np, Ks, ptr(colT), Np, 0, Ks, None, ptr(P), 288, S * 64 * 288, 64 * 288,
+                                          64, 288, Ks, 2 * S, S, _st()), "mt_gemm_batched_f32 (wgrad)")
+            check(lib.mt_sum_slices_f32(ptr(P), 64 * 288, 288, 2 * S, ptr(gw2), 288, 64, 288, _st()), "mt_sum_slices_f32")
+            _gather4(gw2, 0, g["cnn.4.weight"], (1, 64, 32, 9), (0, 288, 1, 32))
+            check(lib.mt_rowsum_bf16(ptr(dz2T[0]), Np, Npos, ptr(g["cnn.4.bias"]), 64, _st()), "mt_rowsum_bf16")
         if debug is not None:
             debug.update(dX0=dX0, dz2=dz2, dz2lo=dz2lo, da1=da1, gw2=gw2, P=P)
         # ---- conv1 (z1 recomputed from the input)
@@ -252,6 +284,8 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         check(lib.mt_conv1_bwd(ptr(x), ptr(pk["w1"]), ptr(pk["b1"]), ptr(sv["mean1"]), ptr(sv["rstd1"]), ptr(pk["g1"]), ptr(pk["be1"]),
                                ptr(da1), 64, ptr(sums[128:]), ptr(g["cnn.0.weight"]), ptr(g["cnn.0.bias"]), ptr(g["cnn.1.weight"]),
                                ptr(g["cnn.1.bias"]), B, F, T, _st()), "mt_conv1_bwd")
+        main.wait_stream(side)                       # every gradient is complete in the caller's stream order
+    del keep
     return g
 
 
