@@ -72,6 +72,38 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MT_BENCH_CPU_THREADS", "16"))))
 
 
+def synth_audio(batch, n_samples=480000, seed=1234, sr=16000):
+    """SURVEY 8(d) synthetic input: 0.1*N(0,1) noise + 1-6 decaying sinusoids at piano fundamentals, clipped to [-1, 1]."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_samples, dtype=np.float64) / sr
+    out = np.empty((batch, n_samples), dtype=np.float32)
+    for b in range(batch):
+        y = 0.1 * rng.standard_normal(n_samples)
+        for _ in range(int(rng.integers(1, 7))):
+            f0 = 27.5 * 2.0 ** (int(rng.integers(0, 88)) / 12.0)
+            onset = float(rng.uniform(0.0, 0.8)) * n_samples / sr
+            amp = float(rng.uniform(0.1, 0.6))
+            env = np.where(t >= onset, np.exp(-(t - onset) * float(rng.uniform(0.3, 3.0))), 0.0)
+            y += amp * env * np.sin(2 * np.pi * f0 * (t - onset))
+        out[b] = np.clip(y, -1.0, 1.0).astype(np.float32)
+    return out
+
+
+def seeded_model(mta, model_type, device, seed=0, **kw):
+    """Random-init weights of the architecture (there is no checkpoint): torch's default initialisation under a fixed seed,
+    BatchNorm running statistics drawn around (0, 1) so that folding them is exercised."""
+    import torch
+    torch.manual_seed(seed)
+    model = mta.TranscriptionModel(model_type, n_mels=N_MELS, hidden_size=HIDDEN, num_layers=LAYERS, device="cpu", **kw)
+    g = torch.Generator().manual_seed(seed + 1)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+            m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+    return model.to(device)
+
+
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
@@ -81,15 +113,12 @@ def bench_large(args):
     import numpy as np
     import torch
     import music_transcription_amd as mta
-    from oracle import frontend_ref, model_ref
     dev = torch.device("cuda", 0)
     B, K, W, NS = args.batch, args.steps, args.warmup, max(1, args.streams)
     T = mta.num_frames(N_SAMPLES, HOP)
-    base = frontend_ref.synth_audio(min(B, 4), N_SAMPLES, seed=1234)
+    base = synth_audio(min(B, 4), N_SAMPLES, seed=1234)
     wave = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B].copy()).to(dev)
-    sd = model_ref.make_state_dict("cnn_rnn_large", N_MELS, HIDDEN, LAYERS, seed=0)
-    model = mta.TranscriptionModel("cnn_rnn_large", n_mels=N_MELS, hidden_size=HIDDEN, num_layers=LAYERS, device=str(dev)).eval()
-    model.load_state_dict(sd, strict=True)
+    model = seeded_model(mta, "cnn_rnn_large", str(dev)).eval()
     fe = mta.MelFrontend(SR, N_MELS, HOP, dev)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
@@ -137,12 +166,9 @@ def bench_train(args):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     import music_transcription_amd as mta
-    from oracle import model_ref
     B, K, W, T = args.batch, args.steps, args.warmup, 937
     g = torch.Generator().manual_seed(1234 + rank)
-    sd = model_ref.make_state_dict("cnn_rnn", N_MELS, HIDDEN, LAYERS, seed=0)
-    model = mta.TranscriptionModel("cnn_rnn", n_mels=N_MELS, hidden_size=HIDDEN, num_layers=LAYERS, dropout=0.3, device=str(dev))
-    model.load_state_dict(sd, strict=True)
+    model = seeded_model(mta, "cnn_rnn", str(dev), dropout=0.3)      # the same initial weights on every rank
     opt = mta.make_optimizer(model, lr=1e-4)
     batches = []
     for _ in range(2):
@@ -238,17 +264,14 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import music_transcription_amd as mta
-    from oracle import frontend_ref, model_ref
 
     B, K, W = args.batch, args.steps, args.warmup
     T = mta.num_frames(N_SAMPLES, HOP)
     # seeded synthetic input: noise + decaying piano-range sinusoids; seed = 1234 + rank.
     # Four distinct chunks tiled to the batch keep host-side synthesis short; the kernels see B chunks.
-    base = frontend_ref.synth_audio(min(B, 4), N_SAMPLES, seed=1234 + rank)
+    base = synth_audio(min(B, 4), N_SAMPLES, seed=1234 + rank)
     wave = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B].copy()).to(dev)
-    sd = model_ref.make_state_dict("cnn_rnn", N_MELS, HIDDEN, LAYERS, seed=0)
-    model = mta.TranscriptionModel("cnn_rnn", n_mels=N_MELS, hidden_size=HIDDEN, num_layers=LAYERS, device=str(dev))
-    model.load_state_dict(sd, strict=True)
+    model = seeded_model(mta, "cnn_rnn", str(dev))
     model.eval()
     net = model.model
     fe = mta.MelFrontend(SR, N_MELS, HOP, dev)
@@ -354,10 +377,12 @@ def main():
         # ---- CPU baseline: the oracle (port of the reference path) on this node's host cores
         cpu = None
         if not args.no_cpu_baseline and world == 1:
+            from oracle import frontend_ref, model_ref      # the CPU port of the reference path: used ONLY in this leg
             cores = host_cores()
             log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
             torch.set_num_threads(cores)
             w_np = wave[:1].cpu().numpy()
+            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
             def cpu_chunk():
                 m = frontend_ref.audio_to_mel_batch(w_np, SR, N_MELS, HOP)          # main.py:117-125
                 with torch.no_grad():

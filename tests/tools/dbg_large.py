@@ -1,5 +1,5 @@
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import music_transcription_amd as mta
 from oracle import model_ref as R
 def mel(B, nm, T, seed):

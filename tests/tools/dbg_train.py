@@ -1,6 +1,6 @@
 """Debug: intermediates of the HIP training step vs torch (CPU, f64) on the same tensors."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, torch.nn.functional as F
 import music_transcription_amd as mta
 from music_transcription_amd import train_step as TS

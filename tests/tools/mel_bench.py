@@ -1,7 +1,7 @@
 """Time mt_mel_db_f32 alone (B = 32 chunks of 30 s) and check it against the oracle on two chunks."""
 import sys, os, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import music_transcription_amd as mta
 from oracle import frontend_ref as FR
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
