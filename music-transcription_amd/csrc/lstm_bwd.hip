@@ -10,14 +10,15 @@
 // Decomposition: a (direction, batch group) is sliced over NW = ceil(H/32) persistent workgroups; workgroup w owns hidden
 // units 32w..32w+31, i.e. 128 gate rows of W_hh, and the product W_hh^T dgates is a REDUCE-SCATTER instead of the forward
 // kernel's all-gather: from its OWN dgates (which never leave the CU: LDS -> MFMA B operand) a workgroup computes its
-// partial of dh for ALL H units (its 128 x H slice of W_hh sits in registers as bf16 MFMA A-operands, 4 waves x 4 consumer
+// partial of dh for ALL H units (its 128 x H slice of W_hh sits in registers as bf16 MFMA A-operands, 8 waves x 2 consumer
 // tiles x 8 k-steps) and stores one 2-KB bf16 slice per consumer; a consumer then reads the NW slices addressed to it
 // (32 KB per workgroup per step at H = 512, where all-gathering the 4H x 32 dgates took 128 KB) and sums them in fp32.
 // Cell math is lane-local with dc carried in registers.  The dgates of all steps are kept (bf16 MFMA-operand images,
 // re-laid out by lstm_dg_unpack_kernel) for the weight-gradient and input-gradient GEMMs.
 // Hand-off as in lstm.hip: sc1 stores and nothing else on the producer side; the slice buffer is poisoned (0xFF) before the
 // launch and the consumers' loads poll the poison pattern (no flags, one round trip per step).  Bounded spins.
-// 4.07 us/step at H = 512 (4.3 with the all-gather formulation, 10.2 before the prefetch pipeline and the flagless hand-off).
+// 3.6 us/step at H = 512 (4.07 with 4-wave workgroups, 4.3 with the all-gather formulation, 10.2 before the prefetch
+// pipeline and the flagless hand-off).
 #include "mt_common.h"
 
 namespace mt {
@@ -40,9 +41,10 @@ struct LstmBwdArgs {
 
 __device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
 
-// TPW = consumer tiles (32 hidden units each) per wave: ceil(NW / 4)
+// TPW = consumer tiles (32 hidden units each) per wave: ceil(NW / 8).  Eight waves: the cell math (2 cells per thread) and the
+// partial-product MFMAs (TPW x 8 per wave) are both on the step's critical path and halve against a 4-wave workgroup.
 template <int TPW>
-__global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
+__global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
     __shared__ __attribute__((aligned(16))) bf16_t img[8][64][8];      // this workgroup's dgates of the step, as 8 MFMA B-operand images
     __shared__ int abort_s;
     typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2;
@@ -71,8 +73,8 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
             }
     }
 
-    // this thread's cells: units u = 8wv + 4hh + e (e = 0..3) of the workgroup, batch row b
-    const int kb = 4 * w + wv;
+    // this thread's cells: units u = 4wv + 2hh + e (e = 0, 1) of the workgroup, batch row b
+    const int kb = 4 * w + (wv >> 1), jl0 = 4 * (wv & 1) + 2 * hh;
     const bool live = (kb < nkb) && (b < Bg);
     const size_t g_blocks = (size_t)T * 2 * nkb;
     const float* gates_g = a.gates + g * g_blocks * 1024;
@@ -85,18 +87,18 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
     if (tid == 0) abort_s = 0;
     __syncthreads();
 
-    float carry[4] = {0.0f, 0.0f, 0.0f, 0.0f};       // dc[t_next] * f[t_next]
-    float ccur[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float carry[2] = {0.0f, 0.0f};                   // dc[t_next] * f[t_next]
+    float ccur[2] = {0.0f, 0.0f};
     // What the cell math needs from the forward pass (activated gates, c of the forward pass's previous step, dh from
     // above) does not depend on the recurrence: it is fetched ONE STEP AHEAD (see the issue point below).
-    float gt[4][4], cprev[4], dhin[4];
+    float gt[4][2], cprev[2], dhin[2];
 #define BPTT_FETCH(S_)                                                                                              \
     do {                                                                                                            \
         const int t_ = d ? (S_) : (T - 1 - (S_));                                                                   \
         const int tp_ = d ? (t_ + 1) : (t_ - 1);                                                                    \
         const size_t blk_ = ((size_t)t_ * 2 + d) * nkb + kb, blkp_ = ((size_t)tp_ * 2 + d) * nkb + kb;             \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                             \
-            const int off_ = (4 * hh + e) * 32 + b;                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                             \
+            const int off_ = (jl0 + e) * 32 + b;                                                                    \
             _Pragma("unroll") for (int p = 0; p < 4; ++p) gt[p][e] = live ? gates_g[blk_ * 1024 + p * 256 + off_] : 0.0f; \
             dhin[e] = live ? dh_g[blk_ * 256 + off_] : 0.0f;                                                        \
             cprev[e] = (live && tp_ >= 0 && tp_ < T) ? cx_g[blkp_ * 256 + off_] : 0.0f;                             \
@@ -105,42 +107,39 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
     {
         const size_t blk0 = ((size_t)(d ? 0 : T - 1) * 2 + d) * nkb + kb;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ccur[e] = live ? cx_g[blk0 * 256 + (4 * hh + e) * 32 + b] : 0.0f;
+        for (int e = 0; e < 2; ++e) ccur[e] = live ? cx_g[blk0 * 256 + (jl0 + e) * 32 + b] : 0.0f;
     }
     BPTT_FETCH(0);
     for (int s = 0; s < T; ++s) {
         const int t = d ? s : (T - 1 - s);            // reverse of the forward processing order
         const int tn = d ? (t - 1) : (t + 1);         // the step processed just before this one
-        float g_i[4], g_f[4], g_g[4], g_o[4], c_prev[4], dh_in[4];
+        float g_i[2], g_f[2], g_g[2], g_o[2], c_prev[2], dh_in[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { g_i[e] = gt[0][e]; g_f[e] = gt[1][e]; g_g[e] = gt[2][e]; g_o[e] = gt[3][e]; c_prev[e] = cprev[e]; dh_in[e] = dhin[e]; }
-        float rec[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // (W_hh^T dgates[t_next]) for this thread's 4 units
+        for (int e = 0; e < 2; ++e) { g_i[e] = gt[0][e]; g_f[e] = gt[1][e]; g_g[e] = gt[2][e]; g_o[e] = gt[3][e]; c_prev[e] = cprev[e]; dh_in[e] = dhin[e]; }
+        float rec[2] = {0.0f, 0.0f};                  // (W_hh^T dgates[t_next]) for this thread's 2 units
         if (s > 0) {
             // ---- reduce-scatter, consumer side: every producer wp left a 32-unit x 32-batch slice of ITS partial product
-            //      for this workgroup; this thread's 4 units x 1 batch row are one 8-B word of each slice.  No flag: the
+            //      for this workgroup; this thread's 2 units x 1 batch row are half an 8-B word of each slice.  No flag: the
             //      loads poll the poison pattern (as lstm.hip); the short sleep keeps the certain-to-fail first attempt,
             //      issued right behind this workgroup's own publish, off the fabric.
             __builtin_amdgcn_s_sleep(BPTT_POLL_SLEEP);
-            const int gbase = (((tn * 2 + d) * NW + w) * NW) * 2048 + ((2 * wv + hh) * 32 + b) * 8;
+            const int gbase = (((tn * 2 + d) * NW + w) * NW) * 2048 + (wv * 32 + b) * 8 + hh * 4;
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
-                u32x2 raw[TPW * 4];
+                unsigned raw[TPW * 8];
 #pragma unroll
-                for (int i = 0; i < TPW * 4; ++i)
-                    raw[i] = (i < NW) ? __builtin_amdgcn_raw_buffer_load_b64(prsrc, gbase + i * 2048, 0, 16 /*sc1*/) : u32x2{0, 0};
+                for (int i = 0; i < TPW * 8; ++i)
+                    raw[i] = (i < NW) ? __builtin_amdgcn_raw_buffer_load_b32(prsrc, gbase + i * 2048, 0, 16 /*sc1*/) : 0u;
                 unsigned worst = 0;
-                float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                float sum[2] = {0.0f, 0.0f};
 #pragma unroll
-                for (int i = 0; i < TPW * 4; ++i) {
-                    worst = max(worst, max(raw[i][0], raw[i][1]));
-                    sum[0] += __uint_as_float(raw[i][0] << 16);
-                    sum[1] += __uint_as_float(raw[i][0] & 0xFFFF0000u);
-                    sum[2] += __uint_as_float(raw[i][1] << 16);
-                    sum[3] += __uint_as_float(raw[i][1] & 0xFFFF0000u);
+                for (int i = 0; i < TPW * 8; ++i) {
+                    worst = max(worst, raw[i]);
+                    sum[0] += __uint_as_float(raw[i] << 16);
+                    sum[1] += __uint_as_float(raw[i] & 0xFFFF0000u);
                 }
                 if (!__any(worst == DG_POISON)) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rec[e] = sum[e];
+                    rec[0] = sum[0]; rec[1] = sum[1];
                     break;
                 }
                 if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
@@ -167,9 +166,9 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
         if (s + 1 < T) BPTT_FETCH(s + 1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- cell backward (lane-local)
-        bf16_t o4[4][4];
+        bf16_t o4[4][2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 2; ++e) {
             const float dhv = dh_in[e] + rec[e];
             const float ig = g_i[e], fg = g_f[e], gg = g_g[e], og = g_o[e];
             const float tc = tanh_fast(ccur[e]);
@@ -184,12 +183,10 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
             o4[0][e] = f32_to_bf16(di); o4[1][e] = f32_to_bf16(df); o4[2][e] = f32_to_bf16(dgg); o4[3][e] = f32_to_bf16(dov);
         }
         // ---- the workgroup's dgates as 8 B-operand images: (gate p, unit u) -> image 2p + (u >> 4),
-        //      lane ((u >> 3) & 1)*32 + batch, element u & 7;  u = 8wv + 4hh + e
+        //      lane ((u >> 3) & 1)*32 + batch, element u & 7;  u = 4wv + 2hh + e
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const unsigned lo = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16), hi = (unsigned)o4[p][2] | ((unsigned)o4[p][3] << 16);
-            *(uint2*)(&img[2 * p + (wv >> 1)][(wv & 1) * 32 + b][4 * hh]) = make_uint2(lo, hi);
-        }
+        for (int p = 0; p < 4; ++p)
+            *(unsigned*)(&img[2 * p + (wv >> 2)][((wv >> 1) & 1) * 32 + b][jl0]) = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16);
         __syncthreads();                                // images complete (and every wave is past the previous step's reads of img)
         if (abort_s) return;                            // a payload spin gave up (status word says where)
         // ---- reduce-scatter, producer side: partial[k][b] = sum over OWN gate rows of W_hh[rho][k] dgates[rho][b] for the
@@ -218,7 +215,6 @@ __global__ __launch_bounds__(256) void lstm_bptt_kernel(LstmBwdArgs a) {
         {
             uint4* dst = (uint4*)(dgx_g + ((((size_t)t * 2 + d) * NW + w) * 8) * 1024);
             dst[tid] = *(const uint4*)(&img[tid >> 6][tid & 63][0]);
-            dst[tid + 256] = *(const uint4*)(&img[(tid + 256) >> 6][tid & 63][0]);
         }
         __syncthreads();                                // every wave is done reading img before the next step rewrites it
     }
@@ -367,9 +363,8 @@ extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const floa
     LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, part_ws, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
     dim3 grid(NW, 2, NG);
     MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);
-    if (NW <= 4) hipLaunchKernelGGL(lstm_bptt_kernel<1>, grid, dim3(256), 0, st, a);
-    else if (NW <= 8) hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(lstm_bptt_kernel<4>, grid, dim3(256), 0, st, a);
+    if (NW <= 8) hipLaunchKernelGGL(lstm_bptt_kernel<1>, grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(512), 0, st, a);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
