@@ -127,7 +127,8 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
         check(lib.mt_bn_stats_cl(ptr(z2), B * F1 * T, 64, ptr(sums2), _st()), "mt_bn_stats_cl")
         check(lib.mt_bn_finalize(ptr(sums2), float(B * F1 * T), ptr(pk["g2"]), ptr(pk["be2"]), ptr(bn2.running_mean), ptr(bn2.running_var),
                                  BN_MOMENTUM, BN_EPS, ptr(mean2), ptr(rstd2), 64, None, None, None, None, 0, _st()), "mt_bn_finalize")
-        X0 = torch.zeros(Mpad, K0, **bf)
+        X0 = torch.empty(Mpad, K0, **bf)               # every column of the M valid rows is written below; pad rows only feed
+        X0[M:].zero_()                                 # discarded GEMM outputs but must be finite for the transposed (K = rows) use
         check(lib.mt_bn_relu_pool_apply(ptr(z2), ptr(mean2), ptr(rstd2), ptr(pk["g2"]), ptr(pk["be2"]), ptr(X0), K0, B, F1, T, _st()),
               "mt_bn_relu_pool_apply")
         sv.update(mean1=mean1, rstd1=rstd1, a1=a1, z2=z2, mean2=mean2, rstd2=rstd2)
@@ -143,7 +144,11 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
             check(lib.mt_gemm_lstm_gx(ptr(Xs[l]), K, ptr(pk["w_ih"][l]), K, ptr(pk["b_g"][l]), ptr(gx), B, T, Hp, K, _st()), "mt_gemm_lstm_gx")
             check(lib.mt_lstm_bidir_fwd_train(ptr(gx), ptr(pk["w_hh"][l]), ptr(hx), ptr(cx), ptr(sync), sync.numel(), B, T, Hp, _st()),
                   "mt_lstm_bidir_fwd_train")
-            Xn = torch.zeros(Mpad, K1, **bf)
+            if K1 == 2 * H:
+                Xn = torch.empty(Mpad, K1, **bf)
+                Xn[M:].zero_()
+            else:
+                Xn = torch.zeros(Mpad, K1, **bf)       # padding columns stay zero
             p = dropout if l < L - 1 else 0.0
             check(lib.mt_lstm_relayout_train(ptr(hx), ptr(Xn), K1, B, T, Hp, H, float(p), seed, l, _st()), "mt_lstm_relayout_train")
             gates.append(gx); cxs.append(cx); hxs.append(hx); Xs.append(Xn)
@@ -204,7 +209,10 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             check(lib.mt_lstm_bidir_bwd(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(part), part.numel(),
                                         ptr(sync), sync.numel(), B, T, Hp, _st()), "mt_lstm_bidir_bwd")
             # dGT is also read as a GEMM A operand from row 4Hp (reverse direction): whole 128-row tiles must stay inside it
-            dG, dGT = torch.zeros(Mpad, 8 * Hp, **bf), torch.zeros(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
+            dG, dGT = torch.empty(Mpad, 8 * Hp, **bf), torch.empty(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
+            dG[M:].zero_()                           # the unpack writes every column of the M valid rows / every row's M valid columns;
+            dGT[:, M:].zero_()                       # the K-padding (rows M.. of dG, columns M.. of dGT) must be zero
+            dGT[8 * Hp:].zero_()
             check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * Hp, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
             # buffers of the side-stream work are allocated here, on the main stream (stream-ordered allocator)
             XTl = torch.empty(_ru(K, 128) * Mpad, **bf)
