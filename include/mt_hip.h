@@ -344,6 +344,12 @@ size_t mt_lstm_bwd_part_bytes(int B, int T, int H);
 int    mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx,
                          void* part_ws, size_t part_bytes, void* sync_ws, size_t sync_bytes, int B, int T, int H,
                          mt_stream_t stream);
+/* The poison fill of part_ws alone (any stream), and the launch with flags bit 0 = "part_ws is already poisoned": lets the
+ * caller hide the 1-GB fill of the next layer's workspace under the current layer's recurrence.                       */
+int    mt_lstm_bwd_poison(void* part_ws, size_t part_bytes, int B, int T, int H, mt_stream_t stream);
+int    mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx,
+                            void* part_ws, size_t part_bytes, void* sync_ws, size_t sync_bytes, int B, int T, int H,
+                            int flags, mt_stream_t stream);
 /* dgx -> dG [(t*B+b)*ldg + d*4H + gate*H + j] bf16 and dGT [(d*4H + gate*H + j)*ldt + t*B + b] bf16
  * (pre-zeroed by the caller: padded rows / columns are not written).                                       */
 int    mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, long long ldt, int B, int T, int H,

@@ -128,6 +128,8 @@ _SIGS = {
     "mt_lstm_dgx_bytes": (sz, [i32, i32, i32]),
     "mt_lstm_bwd_part_bytes": (sz, [i32, i32, i32]),
     "mt_lstm_bidir_bwd": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, i32, i32, vp]),
+    "mt_lstm_bidir_bwd_ex": (i32, [vp, vp, vp, vp, vp, vp, sz, vp, sz, i32, i32, i32, i32, vp]),
+    "mt_lstm_bwd_poison": (i32, [vp, sz, i32, i32, i32, vp]),
     "mt_lstm_dg_unpack": (i32, [vp, vp, i32, vp, ll, i32, i32, i32, vp]),
     "mt_lstm_hprev_t": (i32, [vp, vp, ll, i32, i32, i32, i32, vp]),
     "mt_dlogits_pack": (i32, [vp, vp, vp, ll, i32, i32, i32, vp]),

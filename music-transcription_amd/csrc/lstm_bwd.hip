@@ -347,9 +347,18 @@ extern "C" size_t mt_lstm_bwd_part_bytes(int B, int T, int H) {
     return (size_t)((B + 31) / 32) * T * 2 * NW * NW * 2048;
 }
 
-// sync_ws: >= mt_lstm_sync_bytes(B, H) bytes (word 0 = status); part_ws: mt_lstm_bwd_part_bytes(B, T, H) bytes of scratch
-extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx, void* part_ws,
-                                 size_t part_bytes, void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream) {
+// Fill a partial-product workspace with the poison pattern the hand-off polls (mt_lstm_bidir_bwd does it itself unless told
+// that the caller already has, e.g. on another stream under the previous layer's recurrence: 1 GB at H = 512, T = 938).
+extern "C" int mt_lstm_bwd_poison(void* part_ws, size_t part_bytes, int B, int T, int H, mt_stream_t stream) {
+    MT_REQUIRE(part_ws && part_bytes >= mt_lstm_bwd_part_bytes(B, T, H), MT_EWORKSPACE, "mt_lstm_bwd_poison: workspace too small");
+    MT_CHECK_HIP(hipMemsetAsync(part_ws, 0xFF, mt_lstm_bwd_part_bytes(B, T, H), (hipStream_t)stream));
+    return MT_OK;
+}
+
+// sync_ws: >= mt_lstm_sync_bytes(B, H) bytes (word 0 = status); part_ws: mt_lstm_bwd_part_bytes(B, T, H) bytes of scratch;
+// flags bit 0: part_ws is already poisoned (mt_lstm_bwd_poison, ordered before this call)
+extern "C" int mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx, void* part_ws,
+                                    size_t part_bytes, void* sync_ws, size_t sync_bytes, int B, int T, int H, int flags, mt_stream_t stream) {
     MT_REQUIRE(gates && cx && dh && w_hh && dgx && part_ws && sync_ws, MT_EINVAL, "mt_lstm_bidir_bwd: null pointer");
     MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 512, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: H=%d unsupported (16..512, multiple of 16)", H);
     const int NG = (B + 31) / 32, NW = (H + 31) / 32;
@@ -359,7 +368,7 @@ extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const floa
     MT_REQUIRE(sync_bytes >= 256, MT_EWORKSPACE, "mt_lstm_bidir_bwd: sync workspace too small");
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, 256, st));
-    MT_CHECK_HIP(hipMemsetAsync(part_ws, 0xFF, mt_lstm_bwd_part_bytes(B, T, H), st));     // poison: see the hand-off note
+    if (!(flags & 1)) MT_CHECK_HIP(hipMemsetAsync(part_ws, 0xFF, mt_lstm_bwd_part_bytes(B, T, H), st));     // poison: see the hand-off note
     LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, part_ws, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
     dim3 grid(NW, 2, NG);
     MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);
@@ -367,6 +376,11 @@ extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const floa
     else hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(512), 0, st, a);
     MT_CHECK_LAUNCH();
     return MT_OK;
+}
+
+extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx, void* part_ws,
+                                 size_t part_bytes, void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream) {
+    return mt_lstm_bidir_bwd_ex(gates, cx, dh, w_hh, dgx, part_ws, part_bytes, sync_ws, sync_bytes, B, T, H, 0, stream);
 }
 
 extern "C" int mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, long long ldt, int B, int T, int H, mt_stream_t stream) {

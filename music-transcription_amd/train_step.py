@@ -197,7 +197,11 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         sync = torch.empty(lib.mt_lstm_sync_bytes(B, Hp), device=dev, dtype=torch.uint8)
         dh = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
         dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
-        part = torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
+        # two partial-product workspaces: the poison fill of the next layer's (1 GB at H = 512) runs on the side stream under
+        # the current layer's recurrence
+        parts = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8) for _ in range(min(2, L))]
+        check(lib.mt_lstm_bwd_poison(ptr(parts[0]), parts[0].numel(), B, T, Hp, _st()), "mt_lstm_bwd_poison")
+        ev_part = [None, None]
         Hr = _ru(Hp, 128)
         dX0 = None
         # The weight gradients of a layer (dW_ih, dW_hh, db: transposes + GEMMs with K = T*B) are not needed by the layers
@@ -206,8 +210,20 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             K = K0 if l == 0 else K1
             p = sv["dropout"] if l < L - 1 else 0.0
             check(lib.mt_lstm_dh_relayout(ptr(dXn), K1, ptr(dh), B, T, Hp, H, float(p), sv["seed"], l, _st()), "mt_lstm_dh_relayout")
-            check(lib.mt_lstm_bidir_bwd(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(part), part.numel(),
-                                        ptr(sync), sync.numel(), B, T, Hp, _st()), "mt_lstm_bidir_bwd")
+            it = (L - 1 - l) % 2
+            part = parts[it % len(parts)]
+            if ev_part[it] is not None:
+                main.wait_event(ev_part[it])             # this workspace's poison fill (issued on the side stream) is done
+            if l > 0 and len(parts) == 2:                # fill the other workspace for the next layer down, beside this recurrence
+                evp = torch.cuda.Event()
+                evp.record(main)                         # (its previous user, two layers up, has finished in main-stream order)
+                with torch.cuda.stream(side):
+                    side.wait_event(evp)
+                    check(lib.mt_lstm_bwd_poison(ptr(parts[1 - it]), parts[1 - it].numel(), B, T, Hp, _st()), "mt_lstm_bwd_poison")
+                    ev_part[1 - it] = torch.cuda.Event()
+                    ev_part[1 - it].record(side)
+            check(lib.mt_lstm_bidir_bwd_ex(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(part), part.numel(),
+                                           ptr(sync), sync.numel(), B, T, Hp, 1, _st()), "mt_lstm_bidir_bwd")
             # dGT is also read as a GEMM A operand from row 4Hp (reverse direction): whole 128-row tiles must stay inside it
             dG, dGT = torch.empty(Mpad, 8 * Hp, **bf), torch.empty(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
             dG[M:].zero_()                           # the unpack writes every column of the M valid rows / every row's M valid columns;
