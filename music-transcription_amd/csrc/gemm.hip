@@ -365,15 +365,238 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
         for (int j = 0; j < 2; ++j) epilogue_tile<EPI>(acc[i][j], m0 + wm * 128 + i * 32, n0 + wn * 64 + j * 32, r, h, M, N, ep, outp);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same 256 x 256 x 64 tile on v_mfma_f32_16x16x32_bf16 with a ping-pong schedule.  Two things bound gemm256_kernel:
+// every wave's LDS latency sits in front of its own MFMAs, and under MFMA load on real data the chip holds a lower
+// clock for the 32x32x16 shape than for 16x16x32 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back 7).
+// Here a K-tile is 4 phases of [fragment reads (+ DMA issue)] barrier [16 MFMAs] barrier; the waves of the lower M half
+// run one barrier ahead of the upper half's and a SIMD holds one wave of each half, so while one is in its MFMA block
+// the other fetches its fragments.  The next tile's DMA is issued in phases 0-1 (two phases old when phase 3 waits for
+// it); each phase retires its own fragment reads before its first barrier, so a buffer is never restaged while a
+// lagging wave still reads it.  A wave's 128 x 64 outputs are 8 x 4 tiles of 16 x 16 (C: column = lane & 15,
+// rows 4 (lane >> 4) + j); fragment reads stay conflict-free under the same swizzle (lane = row & 15, 16-B chunk
+// 4 ks + (lane >> 4)).
+// One 16 x 16 accumulator tile.  The operands are ordered so that a lane's 4 registers run along the output's
+// contiguous axis (one 16-byte store per lane and tile): for the gx layout that is the chunk index b (rows = m, lane
+// column = n), for the row-major outputs it is n (operands swapped: rows = n, lane column = m).
+template <int EPI>
+__device__ __forceinline__ void epilogue_tile16(const f32x4& acc, int mb, int nb, int c16, int q, int M, int N, const GemmEpi& ep, float* outp) {
+    if (EPI == EPI_LSTM_GX) {
+        const int n = nb + c16, m4 = mb + 4 * q;
+        if (n < N && m4 < M) {
+            const int H = ep.H, nkb = H >> 3;
+            const int d = n / (4 * H), rem = n - d * 4 * H, p = rem / H, jj = rem - p * H;
+            const size_t nofs = ((size_t)(d * nkb + (jj >> 3)) * 4 + p) * 256 + (jj & 7) * 32;
+            const float bv = ep.bias[n];
+            const int t = m4 / ep.B, b = m4 - t * ep.B;
+            if ((ep.B & 3) == 0 && m4 + 4 <= M) {           // 4 | B: the 4 rows are 4 consecutive chunks of one (t, group)
+                float* o = outp + ((size_t)((b >> 5) * ep.T + t) * 2) * nkb * 1024 + nofs + (b & 31);
+                *(f32x4*)o = f32x4{acc[0] + bv, acc[1] + bv, acc[2] + bv, acc[3] + bv};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m4 + j;
+                    if (m < M) {
+                        const int t1 = m / ep.B, b1 = m - t1 * ep.B;
+                        outp[((size_t)((b1 >> 5) * ep.T + t1) * 2) * nkb * 1024 + nofs + (b1 & 31)] = acc[j] + bv;
+                    }
+                }
+            }
+        }
+    } else {
+        const int m = mb + c16, n4 = nb + 4 * q;
+        if (m < M && n4 < N) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[j] + ((ep.bias && n4 + j < N) ? ep.bias[n4 + j] : 0.0f);
+                if (EPI == EPI_ROWMAJOR_BF16 && ep.relu) v[j] = fmaxf(v[j], 0.0f);
+            }
+            if (EPI == EPI_ROWMAJOR_BF16) {
+                bf16_t* o = (bf16_t*)outp + (size_t)m * ep.ldc + n4;
+                if (n4 + 4 <= N && ((uintptr_t)o & 7) == 0) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *(uint2*)o = pk;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (n4 + j < N) o[j] = f32_to_bf16(v[j]);
+                }
+            } else {
+                float* o = outp + (size_t)m * ep.ldc + n4;
+                if (n4 + 4 <= N && ((uintptr_t)o & 15) == 0) {
+                    *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (n4 + j < N) o[j] = v[j];
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+                                                       int M, int N, int K, GemmEpi ep) {
+    constexpr bool SWAP = (EPI != EPI_LSTM_GX);      // see epilogue_tile16
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int m0, n0;
+    {
+        const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = (N + BN2 - 1) / BN2, total = tiles_m * tiles_n;
+        const int bid = blockIdx.x, xcd = bid & 7, qq = total >> 3, rmd = total & 7;
+        const int pid = (xcd < rmd ? xcd * (qq + 1) : rmd * (qq + 1) + (xcd - rmd) * qq) + (bid >> 3);
+        constexpr int GM = 4;
+        const int per_group = GM * tiles_n, grp = pid / per_group, first_m = grp * GM;
+        const int gm = min(GM, tiles_m - first_m), in_grp = pid - grp * per_group;
+        m0 = (first_m + in_grp % gm) * BM2;
+        n0 = (in_grp / gm) * BN2;
+    }
+    float* outp;
+    {
+        const int z1 = blockIdx.z / ep.zdiv, z2 = blockIdx.z - z1 * ep.zdiv;
+        A += (size_t)(z1 * ep.sA + z2 * ep.sA2);
+        W += (size_t)(z1 * ep.sW + z2 * ep.sW2);
+        const long long oc = z1 * ep.sC + z2 * ep.sC2;
+        outp = ep.out + (EPI == EPI_ROWMAJOR_BF16 ? oc / 2 : oc);
+    }
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wm = wv >> 2, wn = wv & 3;
+    const int a_last = ((M + 127) & ~127) - 1, w_last = ((N + 127) & ~127) - 1;
+
+    typedef __attribute__((address_space(1))) const void gvoid_t;
+    typedef __attribute__((address_space(3))) void lvoid_t;
+    const int drow = lane >> 3, dslot = lane & 7;
+#define GX_DMA1(kt, buf, J)                                                                                   \
+    {                                                                                                         \
+        const int row_ = wv * 32 + (J) * 8 + drow;                                                            \
+        const int chunk_ = dslot ^ ((row_ >> 1) & 7);                                                         \
+        const bf16_t* ga_ = A + (size_t)min(m0 + row_, a_last) * lda + (size_t)(kt) * BK + chunk_ * 8;        \
+        const bf16_t* gw_ = W + (size_t)min(n0 + row_, w_last) * ldw + (size_t)(kt) * BK + chunk_ * 8;        \
+        char* la_ = smem2 + (buf) * (BM2 + BN2) * BK * 2 + (wv * 32 + (J) * 8) * 128;                         \
+        __builtin_amdgcn_global_load_lds((gvoid_t*)ga_, (lvoid_t*)la_, 16, 0, 0);                             \
+        __builtin_amdgcn_global_load_lds((gvoid_t*)gw_, (lvoid_t*)(la_ + BM2 * BK * 2), 16, 0, 0);            \
+    }
+#define GX_READ_A(I0, ks)                                                                                      \
+    _Pragma("unroll") for (int i_ = (I0); i_ < (I0) + 4; ++i_) {                                               \
+        const int ra_ = wm * 128 + i_ * 16 + c16;                                                              \
+        fa[i_] = *(const bf16x8*)(as + ra_ * 128 + (swz(ra_, (ks) * 4 + q) << 4));                             \
+    }
+#define GX_READ_B(ks)                                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                         \
+        const int rw_ = wn * 64 + j_ * 16 + c16;                                                               \
+        fb[j_] = *(const bf16x8*)(ws + rw_ * 128 + (swz(rw_, (ks) * 4 + q) << 4));                             \
+    }
+#define GX_MFMA(I0)                                                                                            \
+    _Pragma("unroll") for (int i_ = (I0); i_ < (I0) + 4; ++i_)                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                       \
+            acc[i_][j_] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j_], fa[i_], acc[i_][j_], 0, 0, 0) \
+                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i_], fb[j_], acc[i_][j_], 0, 0, 0);
+#define GX_MID(I0)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    GX_MFMA(I0)                                                                                                \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 fa[8], fb[4];
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0f;
+
+    const int nk = K / BK;
+    GX_DMA1(0, 0, 0) GX_DMA1(0, 0, 1) GX_DMA1(0, 0, 2) GX_DMA1(0, 0, 3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // the stagger; balanced after the loop
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const char* as = smem2 + buf * (BM2 + BN2) * BK * 2;
+        const char* ws = as + BM2 * BK * 2;
+        const bool more = kt + 1 < nk;
+        GX_READ_B(0) GX_READ_A(0, 0)
+        if (more) { GX_DMA1(kt + 1, buf ^ 1, 0) GX_DMA1(kt + 1, buf ^ 1, 1) }
+        GX_MID(0)
+        GX_READ_A(4, 0)
+        if (more) { GX_DMA1(kt + 1, buf ^ 1, 2) GX_DMA1(kt + 1, buf ^ 1, 3) }
+        GX_MID(4)
+        GX_READ_B(1) GX_READ_A(0, 1)
+        GX_MID(0)
+        GX_READ_A(4, 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GX_MID(4)
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef GX_DMA1
+#undef GX_READ_A
+#undef GX_READ_B
+#undef GX_MFMA
+#undef GX_MID
+    if (EPI == EPI_LSTM_GX && (ep.B & 3) == 0) {
+        // gx epilogue with the index arithmetic hoisted: 4 column decompositions and 8 row decompositions per lane
+        // instead of one of each per tile (the integer divisions otherwise cost as much as a short K loop)
+        const int H = ep.H, nkb = H >> 3;
+        size_t nofs[4];
+        float bv[4];
+        bool nok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + c16;
+            nok[j] = n < N;
+            const int nn = nok[j] ? n : 0;
+            const int d = nn / (4 * H), rem = nn - d * 4 * H, p = rem / H, jj = rem - p * H;
+            nofs[j] = ((size_t)(d * nkb + (jj >> 3)) * 4 + p) * 256 + (jj & 7) * 32;
+            bv[j] = ep.bias[nn];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m4 = m0 + wm * 128 + i * 16 + 4 * q;
+            if (m4 >= M) continue;
+            const int t = m4 / ep.B, b = m4 - t * ep.B;
+            float* o = outp + ((size_t)((b >> 5) * ep.T + t) * 2) * nkb * 1024 + (b & 31);
+            if (m4 + 4 <= M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (nok[j]) *(f32x4*)(o + nofs[j]) = f32x4{acc[i][j][0] + bv[j], acc[i][j][1] + bv[j], acc[i][j][2] + bv[j], acc[i][j][3] + bv[j]};
+            } else {                                        // 4 | B, so the rows below M still share (t, group)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (nok[j] && m4 + e < M) o[nofs[j] + e] = acc[i][j][e] + bv[j];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            epilogue_tile16<EPI>(acc[i][j], m0 + wm * 128 + i * 16, n0 + wn * 64 + j * 16, c16, q, M, N, ep, outp);
+}
+
 template <int EPI>
 static int launch256(const bf16_t* a, int lda, const bf16_t* w, int ldw, int M, int N, int K, const GemmEpi& ep, hipStream_t st, int batch) {
     static bool attr_set = false;
+    // MT_GEMM_TILE=256 keeps the 32x32x16 kernel (A/B runs); the default is the 16x16x32 ping-pong kernel
+    static const bool old256 = getenv("MT_GEMM_TILE") && atoi(getenv("MT_GEMM_TILE")) == 256;
     if (!attr_set) {
         MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256x_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
         attr_set = true;
     }
     dim3 grid(cdiv(N, BN2) * cdiv(M, BM2), 1, batch);
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), G256_LDS, st, a, lda, w, ldw, M, N, K, ep);
+    if (old256) hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), G256_LDS, st, a, lda, w, ldw, M, N, K, ep);
+    else hipLaunchKernelGGL(gemm256x_kernel<EPI>, grid, dim3(512), G256_LDS, st, a, lda, w, ldw, M, N, K, ep);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
