@@ -32,43 +32,46 @@ def _st():
     return _lib.stream_ptr()
 
 
-def pack_train(model, dev) -> Dict[str, object]:
-    """Device-side operand layouts of the CURRENT parameters (re-done every step: the optimizer moves them)."""
+def pack_train(model, dev, part: str = "all") -> Dict[str, object]:
+    """Device-side operand layouts of the CURRENT parameters (re-done every step: the optimizer moves them).
+    part = "conv" (what the step needs first), "rnn" (LSTM + fc, packed on the side stream beside the convolutions) or "all"."""
     from .model import _pack_bilstm
     H, L, F = model.hidden_size, model.num_layers, model.n_mels
     Hp, K1, Fo2 = _ru(H, 16), _ru(2 * H, 64), (F // 2) // 2
     K0 = Fo2 * 64
     f32 = dict(device=dev, dtype=torch.float32)
     t: Dict[str, object] = {}
-    c1, bn1, c2, bn2 = model.cnn[0], model.cnn[1], model.cnn[4], model.cnn[5]
-    t["w1"] = c1.weight.detach().to(**f32).reshape(32, 9).contiguous()
-    t["b1"] = c1.bias.detach().to(**f32).contiguous()
-    w2 = c2.weight.detach().to(**f32)
-    t["w2"] = w2.permute(0, 2, 3, 1).reshape(64, 288).to(torch.bfloat16).contiguous()           # [co][tap*32 + ci]
-    t["b2"] = c2.bias.detach().to(**f32).contiguous()
-    wd = torch.zeros(64, 576, **f32)                                                             # dgrad: [ci (pad 64)][tap'*64 + co]
-    wd[:32] = w2.flip(2, 3).permute(1, 2, 3, 0).reshape(32, 576)
-    t["w2d"] = wd.to(torch.bfloat16)
-    t["zero64"] = torch.zeros(64, **f32)
-    for i, bn in ((1, bn1), (2, bn2)):
-        t[f"g{i}"] = bn.weight.detach().to(**f32).contiguous()
-        t[f"be{i}"] = bn.bias.detach().to(**f32).contiguous()
-    cols = (torch.arange(64)[None, :] * Fo2 + torch.arange(Fo2)[:, None]).reshape(-1)             # kernel col f*64+c -> ref col c*Fo2+f
-    t["w_ih"], t["b_g"], t["w_hh"] = _pack_bilstm(model.rnn, L, H, cols, dev)
-    t["w_ihT"] = []
-    for l in range(L):
-        K = K0 if l == 0 else K1
-        wT = torch.zeros(_ru(K, 128), 8 * Hp, device=dev, dtype=torch.bfloat16)
-        wT[:K] = t["w_ih"][l][:8 * Hp].t()
-        t["w_ihT"].append(wT)
-    fw = torch.zeros(128, K1, **f32)
-    fw[:88, :2 * H] = model.fc.weight.detach().to(**f32)
-    t["fc_w"] = fw.to(torch.bfloat16)
-    fwT = torch.zeros(_ru(K1, 128), 128, device=dev, dtype=torch.bfloat16)
-    fwT[:K1] = t["fc_w"].t()
-    t["fc_wT"] = fwT
-    t["fc_b"] = model.fc.bias.detach().to(**f32).contiguous()
     t["dims"] = dict(H=H, Hp=Hp, L=L, F=F, F1=F // 2, Fo2=Fo2, K0=K0, K1=K1)
+    if part in ("all", "conv"):
+        c1, bn1, c2, bn2 = model.cnn[0], model.cnn[1], model.cnn[4], model.cnn[5]
+        t["w1"] = c1.weight.detach().to(**f32).reshape(32, 9).contiguous()
+        t["b1"] = c1.bias.detach().to(**f32).contiguous()
+        w2 = c2.weight.detach().to(**f32)
+        t["w2"] = w2.permute(0, 2, 3, 1).reshape(64, 288).to(torch.bfloat16).contiguous()           # [co][tap*32 + ci]
+        t["b2"] = c2.bias.detach().to(**f32).contiguous()
+        wd = torch.zeros(64, 576, **f32)                                                             # dgrad: [ci (pad 64)][tap'*64 + co]
+        wd[:32] = w2.flip(2, 3).permute(1, 2, 3, 0).reshape(32, 576)
+        t["w2d"] = wd.to(torch.bfloat16)
+        t["zero64"] = torch.zeros(64, **f32)
+        for i, bn in ((1, bn1), (2, bn2)):
+            t[f"g{i}"] = bn.weight.detach().to(**f32).contiguous()
+            t[f"be{i}"] = bn.bias.detach().to(**f32).contiguous()
+    if part in ("all", "rnn"):
+        cols = (torch.arange(64)[None, :] * Fo2 + torch.arange(Fo2)[:, None]).reshape(-1)             # kernel col f*64+c -> ref col c*Fo2+f
+        t["w_ih"], t["b_g"], t["w_hh"] = _pack_bilstm(model.rnn, L, H, cols, dev)
+        t["w_ihT"] = []
+        for l in range(L):
+            K = K0 if l == 0 else K1
+            wT = torch.zeros(_ru(K, 128), 8 * Hp, device=dev, dtype=torch.bfloat16)
+            wT[:K] = t["w_ih"][l][:8 * Hp].t()
+            t["w_ihT"].append(wT)
+        fw = torch.zeros(128, K1, **f32)
+        fw[:88, :2 * H] = model.fc.weight.detach().to(**f32)
+        t["fc_w"] = fw.to(torch.bfloat16)
+        fwT = torch.zeros(_ru(K1, 128), 128, device=dev, dtype=torch.bfloat16)
+        fwT[:K1] = t["fc_w"].t()
+        t["fc_wT"] = fwT
+        t["fc_b"] = model.fc.bias.detach().to(**f32).contiguous()
     return t
 
 
@@ -99,8 +102,25 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
     """Returns (logits (B,88,T) f32, saved state for backward_train).  Updates the BatchNorm running statistics."""
     dev = x.device
     B, _, F, T = x.shape
-    pk = pack_train(model, dev)
-    d = pk["dims"]
+    # The LSTM / fc operands are packed on the side stream while the main stream runs the convolutions, and the first
+    # BPTT workspace gets its poison fill there as well (the side stream first waits for everything already queued on
+    # the main stream: the previous step's optimizer update, and the last users of whatever the allocator hands back).
+    with torch.cuda.device(dev):
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        ev_start = torch.cuda.Event()
+        ev_start.record(main)
+        pk = pack_train(model, dev, "conv")
+        d = pk["dims"]
+        Hp_, L_ = d["Hp"], d["L"]
+        parts = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp_), device=dev, dtype=torch.uint8) for _ in range(min(2, L_))]
+        with torch.cuda.stream(side):
+            side.wait_event(ev_start)
+            pk.update(pack_train(model, dev, "rnn"))
+            ev_pack = torch.cuda.Event()
+            ev_pack.record(side)
+            check(lib.mt_lstm_bwd_poison(ptr(parts[0]), parts[0].numel(), B, T, Hp_, _st()), "mt_lstm_bwd_poison")
+            ev_part0 = torch.cuda.Event()
+            ev_part0.record(side)
     H, Hp, L, F1, K0, K1 = d["H"], d["Hp"], d["L"], d["F1"], d["K0"], d["K1"]
     M, Mpad = T * B, _ru(T * B, 128)
     x = x.contiguous().float()
@@ -131,7 +151,8 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
         X0[M:].zero_()                                 # discarded GEMM outputs but must be finite for the transposed (K = rows) use
         check(lib.mt_bn_relu_pool_apply(ptr(z2), ptr(mean2), ptr(rstd2), ptr(pk["g2"]), ptr(pk["be2"]), ptr(X0), K0, B, F1, T, _st()),
               "mt_bn_relu_pool_apply")
-        sv.update(mean1=mean1, rstd1=rstd1, a1=a1, z2=z2, mean2=mean2, rstd2=rstd2)
+        sv.update(mean1=mean1, rstd1=rstd1, a1=a1, z2=z2, mean2=mean2, rstd2=rstd2, parts=parts, ev_part0=ev_part0)
+        main.wait_event(ev_pack)                       # LSTM / fc operands are packed
         # ---- LSTM layers
         Xs: List[torch.Tensor] = [X0]
         gates, cxs, hxs = [], [], []
@@ -197,13 +218,36 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         sync = torch.empty(lib.mt_lstm_sync_bytes(B, Hp), device=dev, dtype=torch.uint8)
         dh = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
         dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
-        # two partial-product workspaces: the poison fill of the next layer's (1 GB at H = 512) runs on the side stream under
-        # the current layer's recurrence
-        parts = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8) for _ in range(min(2, L))]
-        check(lib.mt_lstm_bwd_poison(ptr(parts[0]), parts[0].numel(), B, T, Hp, _st()), "mt_lstm_bwd_poison")
-        ev_part = [None, None]
+        # two partial-product workspaces: the first was filled with the poison pattern during the forward pass, the fill of
+        # the next layer's (1 GB at H = 512) runs on the side stream under the current layer's recurrence
+        parts = sv["parts"]
+        ev_part = [sv["ev_part0"], None]
         Hr = _ru(Hp, 128)
         dX0 = None
+        # Every weight-gradient GEMM contracts over positions, so it wants the forward activations transposed (X_l^T,
+        # h_{t-1}^T, im2col(a1)^T).  None of that depends on the backward pass: it is all produced now, on the side stream,
+        # under the top layer's backward recurrence, instead of after the bottom layer's where nothing is left to hide it.
+        Npos = B * F1 * T
+        n64 = (Npos + 63) // 64
+        S = max(1, min(256, n64 // 8))
+        Ks = 64 * ((n64 + S - 1) // S)
+        S = (n64 * 64 + Ks - 1) // Ks
+        Np = S * Ks
+        XTs = [torch.empty(_ru(K0 if l == 0 else K1, 128) * Mpad, **bf) for l in range(L)]
+        HTs = [torch.zeros(2 * Hr, Mpad, **bf) for l in range(L)]
+        colT = torch.empty(384, Np, **bf)               # rows 288.. only feed output columns that are never stored
+        keep += XTs + HTs + [colT]
+        with torch.cuda.stream(side):
+            for l in range(L - 1, -1, -1):
+                K = K0 if l == 0 else K1
+                check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XTs[l]), Mpad, K, _st()), "mt_transpose_bf16")
+                check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HTs[l]), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
+            if Np > Npos:
+                colT[:288, Npos:].zero_()               # K-padding columns must be finite zeros
+            check(lib.mt_im2col_t_3x3_c32(ptr(sv["a1"]), ptr(colT), Np, B, F1, T, _st()), "mt_im2col_t_3x3_c32")
+        # dW_hh of both directions as one split-K launch when T*B splits evenly (4 Hp x Hp outputs are only 64 tiles)
+        nkt = Mpad // 64
+        Sh = next((c for c in (8, 7, 6, 5, 4, 3, 2) if nkt % c == 0), 1)
         # The weight gradients of a layer (dW_ih, dW_hh, db: transposes + GEMMs with K = T*B) are not needed by the layers
         # below it: they run on a side stream under the next layer's backward recurrence, which is latency-bound on 32 CUs.
         for l in range(L - 1, -1, -1):
@@ -231,14 +275,14 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             dGT[8 * Hp:].zero_()
             check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * Hp, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
             # buffers of the side-stream work are allocated here, on the main stream (stream-ordered allocator)
-            XTl = torch.empty(_ru(K, 128) * Mpad, **bf)
-            HT = torch.zeros(2 * Hr, Mpad, **bf)
+            XTl, HT = XTs[l], HTs[l]
             gb, gwi, gwh = torch.empty(8 * Hp, **f32), torch.empty(8 * Hp, K, **f32), torch.empty(2, 4 * Hp, Hp, **f32)
+            Ph = torch.empty(2, Sh, 4 * Hp, Hp, **f32) if Sh > 1 else None
             outs = []
             for di in range(2):
                 outs.append((torch.empty(4 * H, 64 * Fo2 if l == 0 else 2 * H, **f32), torch.empty(4 * H, H, **f32), torch.empty(4 * H, **f32),
                              torch.empty(4 * H, **f32)))
-            keep += [dG, dGT, XTl, HT, gb, gwi, gwh]
+            keep += [dG, dGT, gb, gwi, gwh, Ph]
             ev = torch.cuda.Event()
             ev.record(main)
             # ---- input gradient: the only product the next layer down waits for
@@ -250,11 +294,16 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             with torch.cuda.stream(side):
                 side.wait_event(ev)
                 check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
-                check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XTl), Mpad, K, _st()), "mt_transpose_bf16")
                 _gemm(dGT, Mpad, XTl, Mpad, gwi, K, 8 * Hp, K, Mpad)
-                check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HT), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
-                for di in range(2):
-                    _gemm(dGT[di * 4 * Hp:], Mpad, HT[di * Hr:], Mpad, gwh[di], Hp, 4 * Hp, Hp, Mpad)
+                if Sh > 1:                               # batch z = direction * Sh + K-slice
+                    Kh = Mpad // Sh
+                    check(lib.mt_gemm_batched_f32(ptr(dGT), Mpad, 4 * Hp * Mpad, Kh, ptr(HT), Mpad, Hr * Mpad, Kh, None, ptr(Ph), Hp,
+                                                  Sh * 4 * Hp * Hp, 4 * Hp * Hp, 4 * Hp, Hp, Kh, 2 * Sh, Sh, _st()), "mt_gemm_batched_f32 (dW_hh)")
+                    for di in range(2):
+                        check(lib.mt_sum_slices_f32(ptr(Ph[di]), 4 * Hp * Hp, Hp, Sh, ptr(gwh[di]), Hp, 4 * Hp, Hp, _st()), "mt_sum_slices_f32")
+                else:
+                    for di in range(2):
+                        _gemm(dGT[di * 4 * Hp:], Mpad, HT[di * Hr:], Mpad, gwh[di], Hp, 4 * Hp, Hp, Mpad)
                 for di, suf in enumerate(("", "_reverse")):
                     wi, wh, bb, bb2 = outs[di]
                     if l == 0:
@@ -268,7 +317,6 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
                     g[f"rnn.bias_ih_l{l}{suf}"], g[f"rnn.bias_hh_l{l}{suf}"] = bb, bb2
         # ---- conv2: BN + ReLU + pool backward, dgrad (flipped-weight conv), wgrad (split-K GEMM over positions)
         sums = torch.zeros(512, device=dev, dtype=torch.float64)
-        Npos = B * F1 * T
         dz2, dz2lo = torch.empty(Npos, 64, **bf), torch.empty(Npos, 64, **bf)
         g["cnn.5.weight"], g["cnn.5.bias"] = torch.empty(64, **f32), torch.empty(64, **f32)
         check(lib.mt_bn_pool_bwd(ptr(dX0), K0, ptr(sv["z2"]), ptr(sv["mean2"]), ptr(sv["rstd2"]), ptr(pk["g2"]), ptr(pk["be2"]), ptr(sums),
@@ -276,27 +324,20 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         da1 = torch.empty(B, F1, T, 64, **bf)
         check(lib.mt_conv_cl_bf16(ptr(dz2), None, ptr(pk["w2d"]), ptr(pk["zero64"]), ptr(da1), B, F1, T, 64, 0, 64, 3, 0, 0, 0, 0, _st()),
               "mt_conv_cl_bf16 (dgrad)")
-        n64 = (Npos + 63) // 64
-        S = max(1, min(256, n64 // 8))
-        Ks = 64 * ((n64 + S - 1) // S)
-        S = (n64 * 64 + Ks - 1) // Ks
-        Np = S * Ks
-        dz2T, colT = torch.empty(2, 128, Np, **bf), torch.empty(384, Np, **bf)      # dz2T[0] = hi piece, [1] = lo piece (zeroed on the side stream)
-        P = torch.empty(2 * S, 64, 288, **f32)          # batch z = piece * S + slice
+        dz2T = torch.empty(128, Np, **bf)               # rows 0..63 = hi piece, 64..127 = lo piece: one full 128-row operand tile
+        P = torch.empty(S, 128, 288, **f32)             # batch z = K-slice; read back as 2 S slices of 64 x 288
         gw2 = torch.empty(64, 288, **f32)
         g["cnn.4.weight"], g["cnn.4.bias"] = torch.empty(64, 32, 3, 3, **f32), torch.empty(64, **f32)
-        keep += [dz2, dz2lo, dz2T, colT, P, gw2]
+        keep += [dz2, dz2lo, dz2T, P, gw2]
         ev2 = torch.cuda.Event()
         ev2.record(main)
         with torch.cuda.stream(side):                    # conv2 weight gradient beside the conv1 backward
             side.wait_event(ev2)
-            dz2T.zero_()                                 # K-padding columns / unused rows must be finite zeros
-            colT.zero_()
+            # (the transposes write zeros into the K-padding columns themselves)
             check(lib.mt_transpose_bf16(ptr(dz2), 64, Npos, 64, ptr(dz2T[0]), Np, 64, _st()), "mt_transpose_bf16")
-            check(lib.mt_transpose_bf16(ptr(dz2lo), 64, Npos, 64, ptr(dz2T[1]), Np, 64, _st()), "mt_transpose_bf16")
-            check(lib.mt_im2col_t_3x3_c32(ptr(sv["a1"]), ptr(colT), Np, B, F1, T, _st()), "mt_im2col_t_3x3_c32")
-            check(lib.mt_gemm_batched_f32(ptr(dz2T), Np, 128 * Np, Ks, ptr(colT), Np, 0, Ks, None, ptr(P), 288, S * 64 * 288, 64 * 288,
-                                          64, 288, Ks, 2 * S, S, _st()), "mt_gemm_batched_f32 (wgrad)")
+            check(lib.mt_transpose_bf16(ptr(dz2lo), 64, Npos, 64, ptr(dz2T[64]), Np, 64, _st()), "mt_transpose_bf16")
+            check(lib.mt_gemm_batched_f32(ptr(dz2T), Np, 0, Ks, ptr(colT), Np, 0, Ks, None, ptr(P), 288, 0, 128 * 288,
+                                          128, 288, Ks, S, S, _st()), "mt_gemm_batched_f32 (wgrad)")
             check(lib.mt_sum_slices_f32(ptr(P), 64 * 288, 288, 2 * S, ptr(gw2), 288, 64, 288, _st()), "mt_sum_slices_f32")
             _gather4(gw2, 0, g["cnn.4.weight"], (1, 64, 32, 9), (0, 288, 1, 32))
             check(lib.mt_rowsum_bf16(ptr(dz2T[0]), Np, Npos, ptr(g["cnn.4.bias"]), 64, _st()), "mt_rowsum_bf16")
