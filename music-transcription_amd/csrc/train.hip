@@ -239,6 +239,71 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
 }
 
+// The same transpose with 16-byte global accesses (lds, ldd multiples of 8 elements, 16-byte aligned bases): a block moves
+// 128 rows x 64 columns.  A thread loads the same 8-column chunk of two adjacent rows and stores the 8 (r, r+1) pairs as
+// dwords tile[c][r/2] (row stride 65 dwords: conflict-free for the 8 chunks x 8 row pairs of a wave); the store phase reads
+// 4 consecutive dwords = 8 rows of one column and writes them as one 16-byte piece, 256 contiguous bytes per 16 lanes.
+__global__ __launch_bounds__(256) void transpose_bf16_v_kernel(const bf16_t* __restrict__ src, long long lds, long long R, int C,
+                                                               bf16_t* __restrict__ dst, long long ldd, int Cd) {
+    __shared__ unsigned tile[64 * 65];
+    const long long r0 = (long long)blockIdx.x * 128;
+    const int c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int q = i >> 3, ch = i & 7, c = c0 + ch * 8;
+        const long long ra = r0 + 2 * q;
+        uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+        if (c + 8 <= C) {
+            if (ra < R) va = *(const uint4*)(src + ra * lds + c);
+            if (ra + 1 < R) vb = *(const uint4*)(src + (ra + 1) * lds + c);
+        } else if (c < C) {                             // ragged last chunk
+            bf16_t ta[8], tb[8];
+            for (int j = 0; j < 8; ++j) {
+                ta[j] = (c + j < C && ra < R) ? src[ra * lds + c + j] : (bf16_t)0;
+                tb[j] = (c + j < C && ra + 1 < R) ? src[(ra + 1) * lds + c + j] : (bf16_t)0;
+            }
+            va = *(const uint4*)ta; vb = *(const uint4*)tb;
+        }
+        const unsigned a4[4] = {va.x, va.y, va.z, va.w}, b4[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[(ch * 8 + 2 * j) * 65 + q] = (a4[j] & 0xFFFFu) | (b4[j] << 16);
+            tile[(ch * 8 + 2 * j + 1) * 65 + q] = (a4[j] >> 16) | (b4[j] & 0xFFFF0000u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) {
+        const int c = i >> 4, rq = i & 15;
+        const long long r = r0 + rq * 8;
+        if (c0 + c >= Cd || r >= ldd) continue;
+        const unsigned* t4 = &tile[c * 65 + rq * 4];
+        bf16_t* o = dst + (size_t)(c0 + c) * ldd + r;
+        if (r + 8 <= ldd) {
+            *(uint4*)o = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+        } else {
+            for (int j = 0; j < 8 && r + j < ldd; ++j) o[j] = (bf16_t)(t4[j >> 1] >> (16 * (j & 1)));
+        }
+    }
+}
+
+// dst[i0][i1][i2][i3] = alpha * src[i0*s0 + i1*s1 + i2 + i3*n2]: the last two axes swap places (a transpose of the n3 x n2
+// block behind every (i0, i1)), through LDS so that both sides stay coalesced
+__global__ __launch_bounds__(256) void gather_t2_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int n2, int n3,
+                                                            long long s0, long long s1, int n1, float alpha) {
+    extern __shared__ float gt_tile[];                  // [n3][n2 + 1]
+    const int i1 = blockIdx.x, i0 = blockIdx.y, n = n2 * n3;
+    const float* sp = src + i0 * s0 + i1 * s1;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int i3 = e / n2, i2 = e - i3 * n2;
+        gt_tile[i3 * (n2 + 1) + i2] = sp[e];
+    }
+    __syncthreads();
+    float* dp = dst + ((size_t)i0 * n1 + i1) * n;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int i2 = e / n3, i3 = e - i2 * n3;
+        dp[e] = alpha * gt_tile[i3 * (n2 + 1) + i2];
+    }
+}
+
 // dst[i0][i1][i2][i3] (contiguous f32) = alpha * src[i0*s0 + i1*s1 + i2*s2 + i3*s3]
 __global__ void gather4_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int n0, int n1, int n2, int n3,
                                    long long s0, long long s1, long long s2, long long s3, float alpha) {
@@ -464,8 +529,12 @@ extern "C" int mt_im2col_t_3x3_c32(const void* a, void* colT, long long ld, int 
 
 extern "C" int mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd, mt_stream_t stream) {
     MT_REQUIRE(src && dst && R > 0 && C > 0 && lds >= C && ldd >= R && Cd >= C, MT_EINVAL, "mt_transpose_bf16: bad arguments");
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((ldd + 63) / 64), cdiv(Cd, 64)), dim3(256), 0, ST(stream),
-                       (const bf16_t*)src, lds, R, C, (bf16_t*)dst, ldd, Cd);
+    if (lds % 8 == 0 && ldd % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0)
+        hipLaunchKernelGGL(transpose_bf16_v_kernel, dim3((unsigned)((ldd + 127) / 128), cdiv(Cd, 64)), dim3(256), 0, ST(stream),
+                           (const bf16_t*)src, lds, R, C, (bf16_t*)dst, ldd, Cd);
+    else
+        hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((ldd + 63) / 64), cdiv(Cd, 64)), dim3(256), 0, ST(stream),
+                           (const bf16_t*)src, lds, R, C, (bf16_t*)dst, ldd, Cd);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
@@ -474,6 +543,11 @@ extern "C" int mt_gather4_f32(const float* src, float* dst, int n0, int n1, int 
                               long long s3, float alpha, mt_stream_t stream) {
     MT_REQUIRE(src && dst && n0 > 0 && n1 > 0 && n2 > 0 && n3 > 0, MT_EINVAL, "mt_gather4_f32: bad arguments");
     const long long n = (long long)n0 * n1 * n2 * n3;
+    if (s2 == 1 && s3 == n2 && n2 > 1 && n3 > 1 && (long long)n3 * (n2 + 1) * 4 <= 48 * 1024 && n0 < 65536) {
+        hipLaunchKernelGGL(gather_t2_f32_kernel, dim3(n1, n0), dim3(256), (size_t)n3 * (n2 + 1) * 4, ST(stream), src, dst, n2, n3, s0, s1, n1, alpha);
+        MT_CHECK_LAUNCH();
+        return MT_OK;
+    }
     long long g = (n + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(gather4_f32_kernel, dim3((unsigned)g), dim3(256), 0, ST(stream), src, dst, n0, n1, n2, n3, s0, s1, s2, s3, alpha);

@@ -113,14 +113,6 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
         d = pk["dims"]
         Hp_, L_ = d["Hp"], d["L"]
         parts = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp_), device=dev, dtype=torch.uint8) for _ in range(min(2, L_))]
-        with torch.cuda.stream(side):
-            side.wait_event(ev_start)
-            pk.update(pack_train(model, dev, "rnn"))
-            ev_pack = torch.cuda.Event()
-            ev_pack.record(side)
-            check(lib.mt_lstm_bwd_poison(ptr(parts[0]), parts[0].numel(), B, T, Hp_, _st()), "mt_lstm_bwd_poison")
-            ev_part0 = torch.cuda.Event()
-            ev_part0.record(side)
     H, Hp, L, F1, K0, K1 = d["H"], d["Hp"], d["L"], d["F1"], d["K0"], d["K1"]
     M, Mpad = T * B, _ru(T * B, 128)
     x = x.contiguous().float()
@@ -151,6 +143,15 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
         X0[M:].zero_()                                 # discarded GEMM outputs but must be finite for the transposed (K = rows) use
         check(lib.mt_bn_relu_pool_apply(ptr(z2), ptr(mean2), ptr(rstd2), ptr(pk["g2"]), ptr(pk["be2"]), ptr(X0), K0, B, F1, T, _st()),
               "mt_bn_relu_pool_apply")
+        # (issued only now, so that the host has the convolutions queued before it spends its time on the packing launches)
+        with torch.cuda.stream(side):
+            side.wait_event(ev_start)
+            pk.update(pack_train(model, dev, "rnn"))
+            ev_pack = torch.cuda.Event()
+            ev_pack.record(side)
+            check(lib.mt_lstm_bwd_poison(ptr(parts[0]), parts[0].numel(), B, T, Hp_, _st()), "mt_lstm_bwd_poison")
+            ev_part0 = torch.cuda.Event()
+            ev_part0.record(side)
         sv.update(mean1=mean1, rstd1=rstd1, a1=a1, z2=z2, mean2=mean2, rstd2=rstd2, parts=parts, ev_part0=ev_part0)
         main.wait_event(ev_pack)                       # LSTM / fc operands are packed
         # ---- LSTM layers

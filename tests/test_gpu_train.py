@@ -404,3 +404,35 @@ def test_data_parallel_training_two_ranks(mta):
     out = json.loads(line)
     assert out["world"] == 2 and out["identical_parameters"], out
     assert all(np.isfinite(out["losses_rank0"])) and len(out["losses_rank0"]) == 3
+
+
+@pytest.mark.parametrize("R,C,lds,ldd,Cd,off", [(300, 64, 64, 320, 64, 0), (1000, 72, 72, 1024, 128, 0), (257, 50, 56, 264, 50, 0),
+                                              (130, 64, 64, 136, 64, 3), (64, 24, 30, 70, 24, 0)])
+def test_transpose_bf16_helper(mta, R, C, lds, ldd, Cd, off):
+    """mt_transpose_bf16 (train.hip): dst[c*ldd + r] = src[r*lds + c], zeros in the padding; the 16-byte path, its ragged
+    chunks, and the scalar kernel it falls back to for unaligned operands (off / lds / ldd not multiples of 8)."""
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    torch.manual_seed(R + C)
+    buf = torch.randn(R * lds + 8, device="cuda").bfloat16()
+    src = buf[off:off + R * lds]
+    dst = torch.full((Cd * ldd,), 7.0, device="cuda").bfloat16()
+    check(lib.mt_transpose_bf16(ptr(src), lds, R, C, ptr(dst), ldd, Cd, stream_ptr()), "mt_transpose_bf16")
+    torch.cuda.synchronize()
+    want = torch.zeros(Cd, ldd, device="cuda").bfloat16()
+    want[:C, :R] = src.view(R, lds)[:, :C].t()
+    assert torch.equal(dst.view(Cd, ldd), want)
+
+
+@pytest.mark.parametrize("n,s", [((4, 24, 64, 80), (24 * 5120, 5120, 1, 64)), ((2, 5, 7, 3), (200, 30, 1, 7)),
+                                 ((3, 4, 1, 16), (100, 20, 0, 1)), ((1, 1, 8, 9), (0, 0, 9, 1))])
+def test_gather4_helper(mta, n, s):
+    """mt_gather4_f32: dst[i0][i1][i2][i3] = alpha * src[sum i_k s_k]; the LDS-transposing kernel (s2 = 1, s3 = n2) and the
+    generic one."""
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    need = sum((nk - 1) * sk for nk, sk in zip(n, s)) + 1
+    src = torch.randn(need, device="cuda")
+    dst = torch.empty(n, device="cuda")
+    check(lib.mt_gather4_f32(ptr(src), ptr(dst), n[0], n[1], n[2], n[3], s[0], s[1], s[2], s[3], 0.5, stream_ptr()), "mt_gather4_f32")
+    torch.cuda.synchronize()
+    want = 0.5 * torch.as_strided(src, n, s)
+    assert torch.equal(dst, want)
