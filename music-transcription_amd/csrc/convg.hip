@@ -84,24 +84,26 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     constexpr int WCH = BN_ * KC / 8;                  // 16-B pieces per chunk
     constexpr int WPT = (WCH + 511) / 512;             // per thread (1 or 2; half the threads idle when WCH = 256)
     constexpr int CPR = KC / 8;                        // pieces per weight row (4 or 8)
-    uint4 wreg[WPT];
+    constexpr bool WFULL = (WCH % 512 == 0);
+    constexpr int KS = KC / 16;
     const int nchunks = Ktot / KC;
+    uint4 wreg0 = make_uint4(0, 0, 0, 0), wreg1 = wreg0;
+    // weight rows are KC*2 bytes (64 or 128): swizzle the piece index so that 16 rows distinct mod 16 do not collide
+#define CG_WSWZ(row) (KC == 64 ? (((row) >> 1) & 7) : (((row) >> 2) & 3))
+    const int wl_row0 = tid / CPR, wl_pc0 = tid % CPR, wl_row1 = (tid + 512) / CPR, wl_pc1 = (tid + 512) % CPR;
+    const bf16_t* wl_g0 = a.W + (size_t)(n0 + wl_row0) * Ktot + wl_pc0 * 8;
+    const bf16_t* wl_g1 = a.W + (size_t)(n0 + wl_row1) * Ktot + wl_pc1 * 8;
+    const int wl_l0 = wl_row0 * (KC * 2) + ((wl_pc0 ^ CG_WSWZ(wl_row0)) << 4);
+    const int wl_l1 = wl_row1 * (KC * 2) + ((wl_pc1 ^ CG_WSWZ(wl_row1)) << 4);
 #define CG_WLOAD(q)                                                                                   \
     do {                                                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                          \
-            const int id_ = tid + 512 * i_, row_ = id_ / CPR, pc_ = id_ % CPR;                        \
-            if (id_ < WCH) wreg[i_] = *(const uint4*)(a.W + (size_t)(n0 + row_) * Ktot + (size_t)(q) * KC + pc_ * 8); \
-        }                                                                                             \
+        if (WFULL || tid < WCH) wreg0 = *(const uint4*)(wl_g0 + (size_t)(q) * KC);                    \
+        if (WPT > 1) wreg1 = *(const uint4*)(wl_g1 + (size_t)(q) * KC);                               \
     } while (0)
-    // weight rows are KC*2 bytes (64 or 128): swizzle the piece index so that 16 rows distinct mod 16 do not collide
-#define CG_WADDR(buf, row, pc) \
-    (wbuf + (buf) * WB + (row) * (KC * 2) + ((KC == 64 ? ((pc) ^ (((row) >> 1) & 7)) : ((pc) ^ (((row) >> 2) & 3))) << 4))
 #define CG_WSTORE(buf)                                                                                \
     do {                                                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < WPT; ++i_) {                                          \
-            const int id_ = tid + 512 * i_, row_ = id_ / CPR, pc_ = id_ % CPR;                        \
-            if (id_ < WCH) *(uint4*)CG_WADDR(buf, row_, pc_) = wreg[i_];                              \
-        }                                                                                             \
+        if (WFULL || tid < WCH) *(uint4*)(wbuf + (buf) * WB + wl_l0) = wreg0;                         \
+        if (WPT > 1) *(uint4*)(wbuf + (buf) * WB + wl_l1) = wreg1;                                    \
     } while (0)
 
     f32x16 acc[2][NT];
@@ -112,45 +114,68 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    // per-lane fragment addressing, hoisted: the weight rows of this lane's N tiles, and the 16-B piece index of its two
+    // M tiles' positions in the staged input tiles (tap (0, 0), channel piece 0)
+    int wf_off[NT], wf_sw[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int row = wn * (BN_ / 2) + j * 32 + r;
+        wf_off[j] = row * (KC * 2);
+        wf_sw[j] = CG_WSWZ(row);
+    }
+    int a1_base[2], a2_base[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int frow = 4 * wm + 2 * i + fbit;        // frequency row inside the tile
+        a1_base[i] = (frow * pitch1 + t_l) * nc1;
+        a2_base[i] = (frow * CG_TT + t_l) * nc2;
+    }
+    const int sw2 = cg_swz(t_l, nc2_l2);
+
+    // One chunk: the fragments of k-step ks+1 are fetched before the MFMAs of k-step ks are issued (two register sets),
+    // the next chunk's weights travel global -> registers under the whole chunk and go to the other LDS buffer after it.
+    bf16x8 fb[2][NT], fa[2][2];
+#define CG_READ(S, ks, inp, abase, tapoff, cb, sw)                                                                \
+    _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                             \
+        fb[S][j_] = *(const bf16x8*)(wb_ + wf_off[j_] + ((((ks) * 2 + h) ^ wf_sw[j_]) << 4));                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                              \
+        fa[S][i_] = *(const bf16x8*)((inp) + (((abase)[i_] + (tapoff)) << 4) + ((((cb) + (ks) * 2 + h) ^ (sw)) << 4));
+#define CG_MFMA(S)                                                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                         \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i_], fb[S][j_], acc[i_][j_], 0, 0, 0);
+#define CG_CHUNK(inp, abase, tapoff, cb, sw)                                                                      \
+    do {                                                                                                          \
+        const char* wb_ = wbuf + (q & 1) * WB;                                                                    \
+        if (q + 1 < nchunks) CG_WLOAD(q + 1);                                                                     \
+        CG_READ(0, 0, inp, abase, tapoff, cb, sw)                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                       \
+            if (ks + 1 < KS) {                                                                                    \
+                if (ks & 1) { CG_READ(0, ks + 1, inp, abase, tapoff, cb, sw) } else { CG_READ(1, ks + 1, inp, abase, tapoff, cb, sw) } \
+            }                                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if (ks & 1) { CG_MFMA(1) } else { CG_MFMA(0) }                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+        if (q + 1 < nchunks) CG_WSTORE((q & 1) ^ 1);                                                              \
+        __syncthreads();                                                                                          \
+    } while (0)
+
     CG_WLOAD(0);
     CG_WSTORE(0);
     __syncthreads();
     const int cpt = C1 / KC;                            // chunks per main tap
-    const int main_chunks = KH * 3 * cpt;
-    for (int q = 0; q < nchunks; ++q) {
-        const int buf = q & 1;
-        if (q + 1 < nchunks) CG_WLOAD(q + 1);
-        // where does this chunk's A operand come from?
-        const bool is_main = q < main_chunks;
-        int kh = 0, kw = 0, cbase = 0;                  // cbase: first channel of the chunk
-        if (is_main) { const int tap = q / cpt; kh = tap / 3; kw = tap % 3; cbase = (q % cpt) * KC; }
-        else cbase = (q - main_chunks) * KC;
-#pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-            bf16x8 fb[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int row = wn * (BN_ / 2) + j * 32 + r;
-                fb[j] = *(const bf16x8*)CG_WADDR(buf, row, ks * 2 + h);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int frow = 4 * wm + 2 * i + fbit;            // frequency row inside the tile
-                const int cch = (cbase >> 3) + ks * 2 + h;         // 16-B piece of the channel vector
-                bf16x8 fa;
-                if (is_main) {
-                    const int col = t_l + kw;
-                    fa = *(const bf16x8*)(in1 + (((frow + kh) * pitch1 + col) * nc1 + (cch ^ cg_swz(col, nc1_l2))) * 16);
-                } else {
-                    fa = *(const bf16x8*)(in2 + ((frow * CG_TT + t_l) * nc2 + (cch ^ cg_swz(t_l, nc2_l2))) * 16);
-                }
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
-            }
+    int q = 0;
+    for (int kh = 0; kh < KH; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+            const int tapoff = (kh * pitch1 + kw) * nc1;
+            const int sw1 = cg_swz(t_l + kw, nc1_l2);
+            for (int cc = 0; cc < cpt; ++cc, ++q) CG_CHUNK(in1, a1_base, tapoff, cc * CPR, sw1);
         }
-        if (q + 1 < nchunks) CG_WSTORE(buf ^ 1);
-        __syncthreads();
-    }
+    for (int cc = 0; q < nchunks; ++cc, ++q) CG_CHUNK(in2, a2_base, 0, cc * CPR, sw2);
+#undef CG_CHUNK
+#undef CG_READ
+#undef CG_MFMA
 
     // ---- epilogue: + bias, (pool), (ReLU), bf16 store
     const int Fo = POOL ? a.F / 2 : a.F;
@@ -191,7 +216,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     }
 #undef CG_WLOAD
 #undef CG_WSTORE
-#undef CG_WADDR
+#undef CG_WSWZ
 }
 
 template <int KC, int BN_, bool POOL, int OUT>
