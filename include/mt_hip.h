@@ -335,6 +335,13 @@ int    mt_lstm_relayout_train(const float* hx, void* X, int ldx, int B, int T, i
 /* dX f32 [(t*B+b)*ld + d*Hv + j] (gradient of the layer output) -> dh [B/32][T][2][H/8][8][32] f32.        */
 int    mt_lstm_dh_relayout(const float* dX, int ld, float* dh, int B, int T, int H, int Hv, float p,
                            unsigned seed, unsigned layer, mt_stream_t stream);
+/* The same dh, straight from the GEMM that produces the gradient of a layer's output (dX = dY . W^T with
+ * rows m = t*B+b, N = 2*Hv columns d*Hv + j, W [roundup(2 Hv, 128) rows][K] bf16): the layer above's input
+ * gradient dG_{l+1} . W_ih_{l+1} (train/train_transcriber.py:104-131 loss.backward() through nn.LSTM,
+ * cnn_rnn_model.py:45-52) or the fc layer's dL . W_fc (:54, :73) -- no f32 dX round trip, no re-layout pass.
+ * Entries of padded units (j >= Hv) and chunks (b >= B) are NOT written: dh must be zero there already.       */
+int    mt_gemm_lstm_dh(const void* dY, int ldy, const void* W, int ldw, float* dh, int B, int T, int H, int Hv,
+                       int K, float p, unsigned seed, unsigned layer, mt_stream_t stream);
 /* Backward through time (both directions of one layer; persistent kernel, lstm_bwd.hip): gates/cx from
  * mt_lstm_bidir_fwd_train, dh from mt_lstm_dh_relayout, w_hh [2][4H][H] f32 -> dgx: d(gate pre-activations)
  * as bf16 MFMA-operand images (mt_lstm_dgx_bytes).  H % 16 == 0, H <= 512.  part_ws: scratch for the per-step

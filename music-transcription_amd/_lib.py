@@ -81,6 +81,7 @@ _SIGS = {
     "mt_conv2_bn_relu_pool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_bf16_f32acc": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_lstm_gx": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_gemm_lstm_dh": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),
     "mt_gemm_logits": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_lstm_gx_bytes": (sz, [i32, i32, i32]),
     "mt_lstm_hx_bytes": (sz, [i32, i32, i32]),

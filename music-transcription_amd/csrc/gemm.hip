@@ -21,13 +21,16 @@
 //                  operands swapped (acc rows = n, cols = m) so a store instruction
 //                  writes 32 consecutive batch entries (128 B).
 //   EPI_LOGITS   : out[b][n][t] (the reference's logits.transpose(1,2)), m = t*B + b.
+//   EPI_LSTM_DH  : gradient of a layer's output in the layout the backward recurrence streams (lstm_bwd.hip):
+//                  row m = t*B + b, column n = d*Hv + j -> dh[g][t][d][j/8][j%8][b%32], with the layer's inverted-dropout
+//                  mask applied (training only; no bias).  Entries of padded units / chunks are never written.
 #include "mt_common.h"
 #include <stdlib.h>
 
 namespace mt {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-enum { EPI_ROWMAJOR = 0, EPI_LSTM_GX = 1, EPI_LOGITS = 2, EPI_ROWMAJOR_BF16 = 3 };
+enum { EPI_ROWMAJOR = 0, EPI_LSTM_GX = 1, EPI_LOGITS = 2, EPI_ROWMAJOR_BF16 = 3, EPI_LSTM_DH = 4 };
 
 struct GemmEpi {
     float* out;            // f32 output (bf16_t* for EPI_ROWMAJOR_BF16)
@@ -38,7 +41,18 @@ struct GemmEpi {
     // batch (blockIdx.z = z): offsets z1*s?1 + z2*s?2 in elements with z1 = z / zdiv, z2 = z % zdiv
     long long sA, sW, sC, sA2, sW2, sC2;
     int zdiv;
+    int Hv;                // EPI_LSTM_DH: valid units per direction (H = padded), dropout of the layer whose output this is
+    float drop_p;
+    unsigned seed, layer;
 };
+
+// one element of the EPI_LSTM_DH output
+__device__ __forceinline__ void dh_store(const GemmEpi& ep, float* outp, int m, int n, float v) {
+    const int d = n / ep.Hv, jj = n - d * ep.Hv, t = m / ep.B, b = m - t * ep.B;
+    if (ep.drop_p > 0.0f)
+        v = dropout_keep(ep.seed, ep.layer, (unsigned long long)m * (2 * ep.Hv) + n, ep.drop_p) ? v * (1.0f / (1.0f - ep.drop_p)) : 0.0f;
+    outp[((((size_t)(b >> 5) * ep.T + t) * 2 + d) * (ep.H >> 3) + (jj >> 3)) * 256 + (jj & 7) * 32 + (b & 31)] = v;
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
@@ -64,6 +78,13 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, int mb, int nb,
             float v = acc[e] + bv;
             if (ep.relu) v = fmaxf(v, 0.0f);
             if (m < M && n < N) o[(size_t)m * ep.ldc + n] = f32_to_bf16(v);
+        }
+    } else if (EPI == EPI_LSTM_DH) {
+        const int n = nb + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m < M && n < N) dh_store(ep, outp, m, n, acc[e]);
         }
     } else if (EPI == EPI_LOGITS) {
         // column n = head*88 + pitch (one head when N = 88): out[head][b][pitch][t]
@@ -403,6 +424,11 @@ __device__ __forceinline__ void epilogue_tile16(const f32x4& acc, int mb, int nb
                 }
             }
         }
+    } else if (EPI == EPI_LSTM_DH) {                        // unswapped like gx: lane column = n, rows m = 4 q + j
+        const int n = nb + c16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (mb + 4 * q + j < M && n < N) dh_store(ep, outp, mb + 4 * q + j, n, acc[j]);
     } else {
         const int m = mb + c16, n4 = nb + 4 * q;
         if (m < M && n4 < N) {
@@ -439,7 +465,7 @@ __device__ __forceinline__ void epilogue_tile16(const f32x4& acc, int mb, int nb
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                        int M, int N, int K, GemmEpi ep) {
-    constexpr bool SWAP = (EPI != EPI_LSTM_GX);      // see epilogue_tile16
+    constexpr bool SWAP = (EPI != EPI_LSTM_GX && EPI != EPI_LSTM_DH);      // see epilogue_tile16
     extern __shared__ __attribute__((aligned(16))) char smem2[];
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     int m0, n0;
@@ -577,6 +603,40 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict_
         }
         return;
     }
+    if (EPI == EPI_LSTM_DH && (ep.B & 3) == 0) {
+        // the same hoisting for the dh layout: 4 consecutive rows are 4 consecutive chunks of one (t, group) -> one 16-byte store
+        const int nkb = ep.H >> 3;
+        const float scale = ep.drop_p > 0.0f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+        size_t nofs[4];
+        int ncol[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + c16;
+            ncol[j] = n < N ? n : -1;
+            const int nn = n < N ? n : 0;
+            const int d = nn / ep.Hv, jj = nn - d * ep.Hv;
+            nofs[j] = ((size_t)d * nkb + (jj >> 3)) * 256 + (jj & 7) * 32;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m4 = m0 + wm * 128 + i * 16 + 4 * q;
+            if (m4 >= M) continue;                       // 4 | B and 4 | M: the 4 rows are valid together
+            const int t = m4 / ep.B, b = m4 - t * ep.B;
+            float* o = outp + (((size_t)(b >> 5) * ep.T + t) * 2) * nkb * 256 + (b & 31);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ncol[j] < 0) continue;
+                f32x4 v = acc[i][j];
+                if (ep.drop_p > 0.0f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = dropout_keep(ep.seed, ep.layer, (unsigned long long)(m4 + e) * (2 * ep.Hv) + ncol[j], ep.drop_p) ? v[e] * scale : 0.0f;
+                }
+                *(f32x4*)(o + nofs[j]) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -613,10 +673,12 @@ static int launch(int epi, const void* A, int lda, const void* W, int ldw, int M
         if (epi == EPI_ROWMAJOR) return launch256<EPI_ROWMAJOR>(a, lda, w, ldw, M, N, K, ep, st, batch);
         if (epi == EPI_LSTM_GX) return launch256<EPI_LSTM_GX>(a, lda, w, ldw, M, N, K, ep, st, batch);
         if (epi == EPI_ROWMAJOR_BF16) return launch256<EPI_ROWMAJOR_BF16>(a, lda, w, ldw, M, N, K, ep, st, batch);
+        if (epi == EPI_LSTM_DH) return launch256<EPI_LSTM_DH>(a, lda, w, ldw, M, N, K, ep, st, batch);
     }
     if (epi == EPI_ROWMAJOR) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     else if (epi == EPI_LSTM_GX) hipLaunchKernelGGL(gemm_kernel<EPI_LSTM_GX>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     else if (epi == EPI_ROWMAJOR_BF16) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR_BF16>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
+    else if (epi == EPI_LSTM_DH) hipLaunchKernelGGL(gemm_kernel<EPI_LSTM_DH>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     else hipLaunchKernelGGL(gemm_kernel<EPI_LOGITS>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     MT_CHECK_LAUNCH();
     return MT_OK;
@@ -639,6 +701,14 @@ extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx: bad dims B=%d T=%d H=%d", B, T, H);
     GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1};
     return launch(EPI_LSTM_GX, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream);
+}
+
+extern "C" int mt_gemm_lstm_dh(const void* dY, int ldy, const void* W, int ldw, float* dh, int B, int T, int H, int Hv, int K,
+                               float p, unsigned seed, unsigned layer, mt_stream_t stream) {
+    MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0 && Hv > 0 && Hv <= H && p >= 0.0f && p < 1.0f, MT_EINVAL,
+               "mt_gemm_lstm_dh: bad dims B=%d T=%d H=%d Hv=%d p=%g", B, T, H, Hv, (double)p);
+    GemmEpi ep{dh, nullptr, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1, Hv, p, seed, layer};
+    return launch(EPI_LSTM_DH, dY, ldy, W, ldw, T * B, 2 * Hv, K, ep, (hipStream_t)stream);
 }
 
 extern "C" int mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,

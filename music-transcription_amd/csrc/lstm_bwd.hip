@@ -268,14 +268,6 @@ __global__ __launch_bounds__(256) void lstm_hprevT_kernel(const f16_t* __restric
     }
 }
 
-__device__ __forceinline__ bool dropout_keep(unsigned seed, unsigned layer, unsigned long long idx, float p) {
-    unsigned long long z = idx + ((((unsigned long long)seed) << 8) ^ layer) * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
-}
-
 // hx (f16 h) -> X[(t*B+b)*ldx + d*Hv + j] bf16 with inverted dropout (nn.LSTM's
 // inter-layer dropout; the mask is a counter-based hash of (seed, layer, element), regenerated in the backward pass)
 __global__ void lstm_relayout_train_kernel(const f16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, int B, int T, int H, int Hv,

@@ -31,6 +31,16 @@ typedef unsigned short bf16_t;   // raw bf16 bits
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 
 // round-to-nearest-even; finite inputs only on every path that uses it
+// Inter-layer dropout mask of the training path: counter-based hash of (seed, layer, element index), regenerated wherever
+// the mask is needed (forward re-layout, backward dh) instead of being stored.
+__device__ __forceinline__ bool dropout_keep(unsigned seed, unsigned layer, unsigned long long idx, float p) {
+    unsigned long long z = idx + ((((unsigned long long)seed) << 8) ^ layer) * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;
+}
+
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     unsigned u = __float_as_uint(f);
     u += 0x7FFFu + ((u >> 16) & 1u);

@@ -207,17 +207,21 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         keep = [dL, dLT, XT, gfc]                    # side-stream operands stay referenced until the streams have joined
         ev0 = torch.cuda.Event()
         ev0.record(main)
-        with torch.cuda.stream(side):                # weight gradients never gate the layers below: side stream
-            side.wait_event(ev0)
-            check(lib.mt_transpose_bf16(ptr(Xs[L]), K1, M, K1, ptr(XT), Mpad, K1, _st()), "mt_transpose_bf16")
-            _gemm(dLT, Mpad, XT, Mpad, gfc, K1, 88, K1, Mpad)
-            _gather4(gfc, 0, g["fc.weight"], (1, 1, 88, 2 * H), (0, 0, K1, 1))
-            check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(g["fc.bias"]), 88, _st()), "mt_rowsum_bf16")
-        dXn = torch.empty(M, K1, **f32)
-        _gemm(dL, 128, pk["fc_wT"], 128, dXn, K1, M, K1, 128)
-        # ---- LSTM layers, top to bottom
+
+        def enqueue_fc_wgrad():                      # weight gradients never gate the layers below: side stream
+            with torch.cuda.stream(side):
+                side.wait_event(ev0)
+                check(lib.mt_transpose_bf16(ptr(Xs[L]), K1, M, K1, ptr(XT), Mpad, K1, _st()), "mt_transpose_bf16")
+                _gemm(dLT, Mpad, XT, Mpad, gfc, K1, 88, K1, Mpad)
+                _gather4(gfc, 0, g["fc.weight"], (1, 1, 88, 2 * H), (0, 0, K1, 1))
+                check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(g["fc.bias"]), 88, _st()), "mt_rowsum_bf16")
+        # ---- LSTM layers, top to bottom.  dh (gradient of a layer's output in the backward recurrence's layout, with the
+        #      layer's dropout mask) is written by the GEMM that produces it: the fc layer's dL W here, the layer above's
+        #      dG W_ih below.  Padded units / chunks are never written and stay zero.
         sync = torch.empty(lib.mt_lstm_sync_bytes(B, Hp), device=dev, dtype=torch.uint8)
-        dh = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
+        dh = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
+        check(lib.mt_gemm_lstm_dh(ptr(dL), 128, ptr(pk["fc_wT"]), 128, ptr(dh), B, T, Hp, H, 128, 0.0, sv["seed"], L - 1, _st()),
+              "mt_gemm_lstm_dh (fc)")
         dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
         # two partial-product workspaces: the first was filled with the poison pattern during the forward pass, the fill of
         # the next layer's (1 GB at H = 512) runs on the side stream under the current layer's recurrence
@@ -238,14 +242,16 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         HTs = [torch.zeros(2 * Hr, Mpad, **bf) for l in range(L)]
         colT = torch.empty(384, Np, **bf)               # rows 288.. only feed output columns that are never stored
         keep += XTs + HTs + [colT]
-        with torch.cuda.stream(side):
-            for l in range(L - 1, -1, -1):
-                K = K0 if l == 0 else K1
-                check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XTs[l]), Mpad, K, _st()), "mt_transpose_bf16")
-                check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HTs[l]), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
-            if Np > Npos:
-                colT[:288, Npos:].zero_()               # K-padding columns must be finite zeros
-            check(lib.mt_im2col_t_3x3_c32(ptr(sv["a1"]), ptr(colT), Np, B, F1, T, _st()), "mt_im2col_t_3x3_c32")
+
+        def enqueue_precompute():
+            with torch.cuda.stream(side):
+                for l in range(L - 1, -1, -1):
+                    K = K0 if l == 0 else K1
+                    check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XTs[l]), Mpad, K, _st()), "mt_transpose_bf16")
+                    check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HTs[l]), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
+                if Np > Npos:
+                    colT[:288, Npos:].zero_()           # K-padding columns must be finite zeros
+                check(lib.mt_im2col_t_3x3_c32(ptr(sv["a1"]), ptr(colT), Np, B, F1, T, _st()), "mt_im2col_t_3x3_c32")
         # dW_hh of both directions as one split-K launch when T*B splits evenly (4 Hp x Hp outputs are only 64 tiles)
         nkt = Mpad // 64
         Sh = next((c for c in (8, 7, 6, 5, 4, 3, 2) if nkt % c == 0), 1)
@@ -253,8 +259,6 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         # below it: they run on a side stream under the next layer's backward recurrence, which is latency-bound on 32 CUs.
         for l in range(L - 1, -1, -1):
             K = K0 if l == 0 else K1
-            p = sv["dropout"] if l < L - 1 else 0.0
-            check(lib.mt_lstm_dh_relayout(ptr(dXn), K1, ptr(dh), B, T, Hp, H, float(p), sv["seed"], l, _st()), "mt_lstm_dh_relayout")
             it = (L - 1 - l) % 2
             part = parts[it % len(parts)]
             if ev_part[it] is not None:
@@ -269,6 +273,9 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
                     ev_part[1 - it].record(side)
             check(lib.mt_lstm_bidir_bwd_ex(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(part), part.numel(),
                                            ptr(sync), sync.numel(), B, T, Hp, 1, _st()), "mt_lstm_bidir_bwd")
+            if l == L - 1:                           # the host queues the side-stream work only once the top recurrence is running
+                enqueue_fc_wgrad()
+                enqueue_precompute()
             # dGT is also read as a GEMM A operand from row 4Hp (reverse direction): whole 128-row tiles must stay inside it
             dG, dGT = torch.empty(Mpad, 8 * Hp, **bf), torch.empty(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
             dG[M:].zero_()                           # the unpack writes every column of the M valid rows / every row's M valid columns;
@@ -287,8 +294,9 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             ev = torch.cuda.Event()
             ev.record(main)
             # ---- input gradient: the only product the next layer down waits for
-            if l > 0:
-                _gemm(dG, 8 * Hp, pk["w_ihT"][l], 8 * Hp, dXn, K1, M, K1, 8 * Hp)
+            if l > 0:                                # -> dh of layer l-1, whose output went through dropout in the forward pass
+                check(lib.mt_gemm_lstm_dh(ptr(dG), 8 * Hp, ptr(pk["w_ihT"][l]), 8 * Hp, ptr(dh), B, T, Hp, H, 8 * Hp,
+                                          float(sv["dropout"]), sv["seed"], l - 1, _st()), "mt_gemm_lstm_dh")
             else:
                 dX0 = torch.empty(M, K0, **f32)
                 _gemm(dG, 8 * Hp, pk["w_ihT"][0], 8 * Hp, dX0, K0, M, K0, 8 * Hp)

@@ -436,3 +436,29 @@ def test_gather4_helper(mta, n, s):
     torch.cuda.synchronize()
     want = 0.5 * torch.as_strided(src, n, s)
     assert torch.equal(dst, want)
+
+
+@pytest.mark.parametrize("B,T,H,Hv,K,p", [(16, 60, 512, 512, 256, 0.0), (16, 512, 512, 512, 256, 0.25), (6, 2800, 256, 256, 128, 0.25),
+                                        (5, 37, 48, 40, 64, 0.5), (40, 33, 64, 64, 128, 0.0)])
+def test_gemm_lstm_dh_matches_gemm_plus_relayout(mta, B, T, H, Hv, K, p):
+    """mt_gemm_lstm_dh (the dh layout + dropout mask as a GEMM epilogue) against the two-pass path it replaces,
+    mt_gemm_bf16_f32acc + mt_lstm_dh_relayout: bit-identical, on the 128-tile kernel, the 256-tile kernel's hoisted path
+    (4 | B) and its generic one, with padded units (Hv < H) and a ragged last batch group."""
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    torch.manual_seed(B * T + H)
+    M, N = T * B, 2 * Hv
+    Mp, Np = (M + 127) // 128 * 128, (N + 127) // 128 * 128
+    A = torch.randn(Mp, K, device="cuda").bfloat16()
+    W = (torch.randn(Np, K, device="cuda") * 0.1).bfloat16()
+    n_dh = lib.mt_lstm_cx_bytes(B, T, H) // 4
+    dX = torch.empty(M, N, device="cuda")
+    check(lib.mt_gemm_bf16_f32acc(ptr(A), K, ptr(W), K, None, ptr(dX), N, M, N, K, stream_ptr()), "gemm")
+    want = torch.empty(n_dh, device="cuda")
+    check(lib.mt_lstm_dh_relayout(ptr(dX), N, ptr(want), B, T, H, Hv, p, 77, 1, stream_ptr()), "relayout")
+    got = torch.zeros(n_dh, device="cuda")
+    check(lib.mt_gemm_lstm_dh(ptr(A), K, ptr(W), K, ptr(got), B, T, H, Hv, K, p, 77, 1, stream_ptr()), "mt_gemm_lstm_dh")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    if p > 0:
+        frac = (got == 0).float().mean().item()
+        assert frac > 0.5 * p                      # the mask is really applied
