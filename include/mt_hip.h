@@ -305,6 +305,14 @@ int    mt_bn_pool_bwd(const float* dX, int ldd, const void* z, const float* mean
 /* a [B][F][T][32] bf16 -> colT[(tap*32+ci)*ld + (b*F+f)*T + t] = a[b][f+kh-1][t+kw-1][ci] (zero outside),
  * tap = kh*3+kw: the W operand of the conv2 weight-gradient GEMM (contraction over positions).             */
 int    mt_im2col_t_3x3_c32(const void* a, void* colT, long long ld, int B, int F, int T, mt_stream_t stream);
+/* Weight and bias gradient of the second conv (Conv2d(32, 64, 3, padding=1), cnn_rnn_model.py:35) from the
+ * channels-last activation a1 [B][F][T][32] and the two bf16 pieces of dz [B][F][T][64] (mt_bn_pool_bwd), with the
+ * POSITION as the MFMA contraction index: no im2col, no transposed copy.  n_wg persistent workgroups
+ * (mt_conv2_wgrad_workgroups()) each leave a partial P[wg][64][288] (column = tap*32 + ci) and Pb[wg][64]
+ * (bias: hi piece only); mt_sum_slices_f32 adds them in a fixed order.                                          */
+int    mt_conv2_wgrad_workgroups(void);
+int    mt_conv2_wgrad(const void* a1, const void* dz_hi, const void* dz_lo, float* P, float* Pb, int n_wg,
+                      int B, int F, int T, mt_stream_t stream);
 /* dst[c*ldd + r] = src[r*lds + c] (bf16), r < R, c < C; every dst element with c < Cd, r < ldd is written
  * (zero outside the source).                                                                               */
 int    mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd,

@@ -221,6 +221,127 @@ __global__ __launch_bounds__(256) void im2colT_kernel(const bf16_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ conv2 weight gradient, direct
+// dW[co][tap][ci] = sum_pos (dz_hi + dz_lo)[pos][co] * a1[pos + tap][ci],  db[co] = sum_pos dz_hi[pos][co]
+// (Conv2d 32 -> 64, 3x3, pad 1; dz [B][F][T][64], a1 [B][F][T][32] channels-last bf16) without materialising im2col or a
+// transposed dz: the contraction index of the MFMAs is the POSITION.  A persistent workgroup of 9 waves -- wave = tap
+// (kh, kw) -- walks tiles of 16 frequency rows x 16 frames; a tile's dz (both pieces) and a1 (with halo) are staged into
+// LDS TRANSPOSED ([channel][position], built from pairs of adjacent frames packed into dwords on the way in), a1 in three
+// copies pre-shifted by kw so that every fragment read is an aligned 16-byte read; one k-step = one frequency row:
+// 4 dz fragments (2 co tiles x hi/lo) + 1 a1 fragment feed 4 MFMAs 32x32x16 into the wave's 2 accumulator tiles, which
+// live in registers across all of the workgroup's tiles.  Per-workgroup partials go to P[wg][64][288] / Pb[wg][64]
+// (fixed-order sums; mt_sum_slices_f32 adds the workgroups).
+constexpr int CW_DZ_ROW = 132;                        // dwords per [co] row of the dz image: 128 (256 positions) + 4 pad
+constexpr int CW_A_ROW = 148;                         // dwords per [ci] row of an a1 copy: 18 rows x 8 + 4 pad
+constexpr int CW_LDS = (2 * 64 * CW_DZ_ROW + 3 * 32 * CW_A_ROW) * 4;
+constexpr int CW_THREADS = 576;
+
+__global__ __launch_bounds__(CW_THREADS) void conv2_wgrad_kernel(const bf16_t* __restrict__ a1, const bf16_t* __restrict__ dzh,
+                                                                 const bf16_t* __restrict__ dzl, float* __restrict__ P,
+                                                                 float* __restrict__ Pb, int B, int F, int T) {
+    extern __shared__ __attribute__((aligned(16))) unsigned cw_smem[];
+    unsigned* dzT = cw_smem;                           // [piece][co][CW_DZ_ROW], 4-dword group index XOR-ed with co >> 3
+    unsigned* a1T = cw_smem + 2 * 64 * CW_DZ_ROW;      // [kw][ci][CW_A_ROW]
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int kh = wv / 3, kw = wv - 3 * kh;
+    const int tiles_t = (T + 15) / 16, tiles_f = (F + 15) / 16, ntiles = B * tiles_f * tiles_t;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // this thread's share of db for co = (tid & 7) * 8 + j
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tt = tile % tiles_t, tf = (tile / tiles_t) % tiles_f, b = tile / (tiles_t * tiles_f);
+        const int t0 = tt * 16, f0 = tf * 16;
+        // ---- stage dz: item = (piece, row, frame pair, 8-channel chunk); 576 % 8 == 0, so a thread's chunk is fixed
+        for (int id = tid; id < 2 * 16 * 8 * 8; id += CW_THREADS) {
+            const int ch = id & 7, tp = (id >> 3) & 7, row = (id >> 6) & 15, piece = id >> 10;
+            const int f = f0 + row, t = t0 + 2 * tp;
+            const bf16_t* src = (piece ? dzl : dzh) + (((size_t)b * F + f) * T + t) * 64 + ch * 8;
+            uint4 va = make_uint4(0, 0, 0, 0), vb = va;
+            if (f < F && t < T) va = *(const uint4*)src;
+            if (f < F && t + 1 < T) vb = *(const uint4*)(src + 64);
+            const unsigned a4[4] = {va.x, va.y, va.z, va.w}, b4[4] = {vb.x, vb.y, vb.z, vb.w};
+            const int d = row * 8 + tp, dsw = (((d >> 2) ^ ch) << 2) | (d & 3);
+            unsigned* dst = dzT + (piece * 64 + ch * 8) * CW_DZ_ROW + dsw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dst[(2 * j) * CW_DZ_ROW] = (a4[j] & 0xFFFFu) | (b4[j] << 16);
+                dst[(2 * j + 1) * CW_DZ_ROW] = (a4[j] >> 16) | (b4[j] & 0xFFFF0000u);
+                if (piece == 0) {
+                    bsum[2 * j] += bf16_to_f32((bf16_t)(a4[j] & 0xFFFFu)) + bf16_to_f32((bf16_t)(b4[j] & 0xFFFFu));
+                    bsum[2 * j + 1] += bf16_to_f32((bf16_t)(a4[j] >> 16)) + bf16_to_f32((bf16_t)(b4[j] >> 16));
+                }
+            }
+        }
+        // ---- stage a1 with halo: item = (halo row 0..17, column pair p 0..8, 8-channel chunk); columns hc = 2p, 2p+1, 2p+2
+        //      of the halo (frame t0 - 1 + hc) give copy 0 pair p, copy 1 pair p (odd-aligned) and copy 2 pair p - 1
+        for (int id = tid; id < 18 * 9 * 4; id += CW_THREADS) {
+            const int ch = id & 3, p = (id >> 2) % 9, hr = id / 36;
+            const int f = f0 - 1 + hr;
+            uint4 v[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int t = t0 - 1 + 2 * p + c;
+                v[c] = make_uint4(0, 0, 0, 0);
+                if (f >= 0 && f < F && t >= 0 && t < T && 2 * p + c < 18) v[c] = *(const uint4*)(a1 + (((size_t)b * F + f) * T + t) * 32 + ch * 8);
+            }
+            const unsigned x0[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, x1[4] = {v[1].x, v[1].y, v[1].z, v[1].w}, x2[4] = {v[2].x, v[2].y, v[2].z, v[2].w};
+            unsigned* base = a1T + (ch * 8) * CW_A_ROW + hr * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned e01 = (x0[j] & 0xFFFFu) | (x1[j] << 16), o01 = (x0[j] >> 16) | (x1[j] & 0xFFFF0000u);
+                const unsigned e12 = (x1[j] & 0xFFFFu) | (x2[j] << 16), o12 = (x1[j] >> 16) | (x2[j] & 0xFFFF0000u);
+                if (p < 8) {
+                    base[(0 * 32 + 2 * j) * CW_A_ROW + p] = e01;     base[(0 * 32 + 2 * j + 1) * CW_A_ROW + p] = o01;
+                    base[(1 * 32 + 2 * j) * CW_A_ROW + p] = e12;     base[(1 * 32 + 2 * j + 1) * CW_A_ROW + p] = o12;
+                }
+                if (p > 0) {
+                    base[(2 * 32 + 2 * j) * CW_A_ROW + p - 1] = e01; base[(2 * 32 + 2 * j + 1) * CW_A_ROW + p - 1] = o01;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 16 k-steps (frequency rows) x 4 MFMAs; wave = tap
+        if (wv < 9) {
+            const unsigned* bsrc = a1T + (kw * 32 + r) * CW_A_ROW + kh * 8 + 4 * h;
+#pragma unroll 4
+            for (int row = 0; row < 16; ++row) {
+                const bf16x8 fb = *(const bf16x8*)(bsrc + row * 8);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int co = 32 * i + r, grp = (2 * row + h) ^ (co >> 3);
+                    const bf16x8 fh = *(const bf16x8*)(dzT + co * CW_DZ_ROW + grp * 4);
+                    const bf16x8 fl = *(const bf16x8*)(dzT + (64 + co) * CW_DZ_ROW + grp * 4);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, fb, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, fb, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partials: P[wg][co][tap*32 + ci]; db through LDS in a fixed order
+    float* Pw = P + (size_t)blockIdx.x * 64 * 288;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+            Pw[co * 288 + wv * 32 + r] = acc[i][e];
+        }
+    float* red = (float*)cw_smem;                      // [72][64]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(tid >> 3) * 64 + (tid & 7) * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 64) {
+        float sacc = 0.0f;
+        for (int k = 0; k < CW_THREADS / 8; ++k) sacc += red[k * 64 + tid];
+        Pb[(size_t)blockIdx.x * 64 + tid] = sacc;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ generic bf16 transpose
 // dst[c*ldd + r] = src[r*lds + c] for r < R, c < C; dst rows c < Cd, columns r < ldd are all written (zero outside)
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, long long lds, long long R, int C,
@@ -316,14 +437,26 @@ __global__ void gather4_f32_kernel(const float* __restrict__ src, float* __restr
 }
 
 // out[r*ldo + c] = sum_z P[z*stride + r*ldp + c]   (split-K partial sums, fixed order)
-__global__ void sum_slices_kernel(const float* __restrict__ P, long long stride, int ldp, int S, float* __restrict__ out, int ldo,
-                                  int rows, int cols) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int r = i / cols, c = i - r * cols;
+// 32 outputs x 8 slice lanes per block: lane g adds slices g, g+8, ... in order, the 8 partial sums are then added in order
+// (a fixed summation tree: deterministic; one thread per output walking all S slices was latency-bound for S in the hundreds)
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ P, long long stride, int ldp, int S,
+                                                         float* __restrict__ out, int ldo, int rows, int cols) {
+    __shared__ float part[8][33];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + o;
+    const bool ok = i < rows * cols;
+    const int r = ok ? i / cols : 0, c = ok ? i - r * cols : 0;
     float acc = 0.0f;
-    for (int z = 0; z < S; ++z) acc += P[(size_t)z * stride + (size_t)r * ldp + c];
-    out[(size_t)r * ldo + c] = acc;
+    if (ok)
+        for (int z = g; z < S; z += 8) acc += P[(size_t)z * stride + (size_t)r * ldp + c];
+    part[g][o] = acc;
+    __syncthreads();
+    if (g == 0 && ok) {
+        float t = part[0][o];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += part[k][o];
+        out[(size_t)r * ldo + c] = t;
+    }
 }
 
 // out[r] += sum_{c < n} A[r*ld + c]  (bf16 rows; out zeroed by the host wrapper).  One wave per (row, 16K-column chunk),
@@ -527,6 +660,22 @@ extern "C" int mt_im2col_t_3x3_c32(const void* a, void* colT, long long ld, int 
     return MT_OK;
 }
 
+extern "C" int mt_conv2_wgrad_workgroups(void) { return 256; }
+
+extern "C" int mt_conv2_wgrad(const void* a1, const void* dz_hi, const void* dz_lo, float* P, float* Pb, int n_wg, int B, int F, int T,
+                              mt_stream_t stream) {
+    MT_REQUIRE(a1 && dz_hi && dz_lo && P && Pb && n_wg > 0 && B > 0 && F > 0 && T > 0, MT_EINVAL, "mt_conv2_wgrad: bad arguments");
+    static bool attr_set = false;
+    if (!attr_set) {
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv2_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(n_wg), dim3(CW_THREADS), CW_LDS, ST(stream), (const bf16_t*)a1, (const bf16_t*)dz_hi,
+                       (const bf16_t*)dz_lo, P, Pb, B, F, T);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
 extern "C" int mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd, mt_stream_t stream) {
     MT_REQUIRE(src && dst && R > 0 && C > 0 && lds >= C && ldd >= R && Cd >= C, MT_EINVAL, "mt_transpose_bf16: bad arguments");
     if (lds % 8 == 0 && ldd % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0)
@@ -557,7 +706,7 @@ extern "C" int mt_gather4_f32(const float* src, float* dst, int n0, int n1, int 
 
 extern "C" int mt_sum_slices_f32(const float* P, long long stride, int ldp, int S, float* out, int ldo, int rows, int cols, mt_stream_t stream) {
     MT_REQUIRE(P && out && S > 0 && rows > 0 && cols > 0 && ldp >= cols && ldo >= cols, MT_EINVAL, "mt_sum_slices_f32: bad arguments");
-    hipLaunchKernelGGL(sum_slices_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, ST(stream), P, stride, ldp, S, out, ldo, rows, cols);
+    hipLaunchKernelGGL(sum_slices_kernel, dim3(cdiv(rows * cols, 32)), dim3(256), 0, ST(stream), P, stride, ldp, S, out, ldo, rows, cols);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

@@ -230,18 +230,12 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         Hr = _ru(Hp, 128)
         dX0 = None
         # Every weight-gradient GEMM contracts over positions, so it wants the forward activations transposed (X_l^T,
-        # h_{t-1}^T, im2col(a1)^T).  None of that depends on the backward pass: it is all produced now, on the side stream,
+        # h_{t-1}^T).  None of that depends on the backward pass: it is all produced now, on the side stream,
         # under the top layer's backward recurrence, instead of after the bottom layer's where nothing is left to hide it.
         Npos = B * F1 * T
-        n64 = (Npos + 63) // 64
-        S = max(1, min(256, n64 // 8))
-        Ks = 64 * ((n64 + S - 1) // S)
-        S = (n64 * 64 + Ks - 1) // Ks
-        Np = S * Ks
         XTs = [torch.empty(_ru(K0 if l == 0 else K1, 128) * Mpad, **bf) for l in range(L)]
         HTs = [torch.zeros(2 * Hr, Mpad, **bf) for l in range(L)]
-        colT = torch.empty(384, Np, **bf)               # rows 288.. only feed output columns that are never stored
-        keep += XTs + HTs + [colT]
+        keep += XTs + HTs
 
         def enqueue_precompute():
             with torch.cuda.stream(side):
@@ -249,9 +243,6 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
                     K = K0 if l == 0 else K1
                     check(lib.mt_transpose_bf16(ptr(Xs[l]), K, M, K, ptr(XTs[l]), Mpad, K, _st()), "mt_transpose_bf16")
                     check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HTs[l]), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
-                if Np > Npos:
-                    colT[:288, Npos:].zero_()           # K-padding columns must be finite zeros
-                check(lib.mt_im2col_t_3x3_c32(ptr(sv["a1"]), ptr(colT), Np, B, F1, T, _st()), "mt_im2col_t_3x3_c32")
         # dW_hh of both directions as one split-K launch when T*B splits evenly (4 Hp x Hp outputs are only 64 tiles)
         nkt = Mpad // 64
         Sh = next((c for c in (8, 7, 6, 5, 4, 3, 2) if nkt % c == 0), 1)
@@ -333,23 +324,19 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         da1 = torch.empty(B, F1, T, 64, **bf)
         check(lib.mt_conv_cl_bf16(ptr(dz2), None, ptr(pk["w2d"]), ptr(pk["zero64"]), ptr(da1), B, F1, T, 64, 0, 64, 3, 0, 0, 0, 0, _st()),
               "mt_conv_cl_bf16 (dgrad)")
-        dz2T = torch.empty(128, Np, **bf)               # rows 0..63 = hi piece, 64..127 = lo piece: one full 128-row operand tile
-        P = torch.empty(S, 128, 288, **f32)             # batch z = K-slice; read back as 2 S slices of 64 x 288
+        nwg = lib.mt_conv2_wgrad_workgroups()
+        P, Pb = torch.empty(nwg, 64, 288, **f32), torch.empty(nwg, 64, **f32)      # per-workgroup partial sums
         gw2 = torch.empty(64, 288, **f32)
         g["cnn.4.weight"], g["cnn.4.bias"] = torch.empty(64, 32, 3, 3, **f32), torch.empty(64, **f32)
-        keep += [dz2, dz2lo, dz2T, P, gw2]
+        keep += [dz2, dz2lo, P, Pb, gw2]
         ev2 = torch.cuda.Event()
         ev2.record(main)
-        with torch.cuda.stream(side):                    # conv2 weight gradient beside the conv1 backward
-            side.wait_event(ev2)
-            # (the transposes write zeros into the K-padding columns themselves)
-            check(lib.mt_transpose_bf16(ptr(dz2), 64, Npos, 64, ptr(dz2T[0]), Np, 64, _st()), "mt_transpose_bf16")
-            check(lib.mt_transpose_bf16(ptr(dz2lo), 64, Npos, 64, ptr(dz2T[64]), Np, 64, _st()), "mt_transpose_bf16")
-            check(lib.mt_gemm_batched_f32(ptr(dz2T), Np, 0, Ks, ptr(colT), Np, 0, Ks, None, ptr(P), 288, 0, 128 * 288,
-                                          128, 288, Ks, S, S, _st()), "mt_gemm_batched_f32 (wgrad)")
-            check(lib.mt_sum_slices_f32(ptr(P), 64 * 288, 288, 2 * S, ptr(gw2), 288, 64, 288, _st()), "mt_sum_slices_f32")
+        with torch.cuda.stream(side):                    # conv2 weight gradient beside the conv1 backward: positions are the MFMA
+            side.wait_event(ev2)                         # contraction index, no im2col and no transposed dz (csrc/train.hip)
+            check(lib.mt_conv2_wgrad(ptr(sv["a1"]), ptr(dz2), ptr(dz2lo), ptr(P), ptr(Pb), nwg, B, F1, T, _st()), "mt_conv2_wgrad")
+            check(lib.mt_sum_slices_f32(ptr(P), 64 * 288, 288, nwg, ptr(gw2), 288, 64, 288, _st()), "mt_sum_slices_f32")
             _gather4(gw2, 0, g["cnn.4.weight"], (1, 64, 32, 9), (0, 288, 1, 32))
-            check(lib.mt_rowsum_bf16(ptr(dz2T[0]), Np, Npos, ptr(g["cnn.4.bias"]), 64, _st()), "mt_rowsum_bf16")
+            check(lib.mt_sum_slices_f32(ptr(Pb), 64, 64, nwg, ptr(g["cnn.4.bias"]), 64, 1, 64, _st()), "mt_sum_slices_f32")
         if debug is not None:
             debug.update(dX0=dX0, dz2=dz2, dz2lo=dz2lo, da1=da1, gw2=gw2, P=P)
         # ---- conv1 (z1 recomputed from the input)

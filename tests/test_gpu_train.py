@@ -462,3 +462,49 @@ def test_gemm_lstm_dh_matches_gemm_plus_relayout(mta, B, T, H, Hv, K, p):
     if p > 0:
         frac = (got == 0).float().mean().item()
         assert frac > 0.5 * p                      # the mask is really applied
+
+
+@pytest.mark.parametrize("B,F,T", [(1, 16, 16), (2, 20, 37), (3, 33, 50), (1, 5, 7)])
+def test_conv2_wgrad_direct_kernel(mta, B, F, T):
+    """mt_conv2_wgrad (position-contracted MFMA, transposed LDS staging, 3 pre-shifted activation copies) against the fp64
+    weight / bias gradient of Conv2d(32, 64, 3, padding=1) computed from the SAME bf16 operands: exact products, so only
+    the f32 accumulation order differs.  Ragged tiles in both axes, batch > 1, a tile smaller than 16 x 16."""
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    import torch.nn.functional as Fn
+    torch.manual_seed(B * 100 + F + T)
+    a1 = torch.randn(B, F, T, 32, device="cuda").bfloat16()
+    dz = torch.randn(B, F, T, 64, device="cuda") * 0.1
+    hi = dz.bfloat16()
+    lo = (dz - hi.float()).bfloat16()
+    nwg = lib.mt_conv2_wgrad_workgroups()
+    P, Pb = torch.empty(nwg, 64, 288, device="cuda"), torch.empty(nwg, 64, device="cuda")
+    check(lib.mt_conv2_wgrad(ptr(a1), ptr(hi), ptr(lo), ptr(P), ptr(Pb), nwg, B, F, T, stream_ptr()), "mt_conv2_wgrad")
+    torch.cuda.synchronize()
+    nt = B * ((F + 15) // 16) * ((T + 15) // 16)
+    got = P[:min(nwg, nt)].double().sum(0).reshape(64, 9, 32).permute(0, 2, 1).reshape(64, 32, 3, 3).cpu()
+    gotb = Pb[:min(nwg, nt)].double().sum(0).cpu()
+    assert torch.all(P[min(nwg, nt):] == 0) and torch.all(Pb[min(nwg, nt):] == 0)      # idle workgroups still write their (zero) partial
+    x = a1.double().cpu().permute(0, 3, 1, 2)                         # NCHW
+    g = (hi.double() + lo.double()).cpu().permute(0, 3, 1, 2)
+    w = torch.zeros(64, 32, 3, 3, dtype=torch.float64, requires_grad=True)
+    Fn.conv2d(x, w, padding=1).backward(g)
+    scale = w.grad.abs().max().item()
+    assert (got - w.grad).abs().max().item() <= 2e-5 * scale + 1e-6
+    wantb = hi.double().cpu().sum((0, 1, 2))
+    assert (gotb - wantb).abs().max().item() <= 1e-4 * wantb.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("S,rows,cols,ldp,ldo", [(1, 3, 5, 5, 5), (7, 64, 288, 288, 288), (256, 1, 64, 64, 64), (19, 10, 33, 40, 36)])
+def test_sum_slices_helper(mta, S, rows, cols, ldp, ldo):
+    """mt_sum_slices_f32: out[r][c] = sum_z P[z][r][c] (split-K / per-workgroup partials), fixed summation tree."""
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    torch.manual_seed(S + rows)
+    P = torch.randn(S, rows, ldp, device="cuda")
+    out = torch.full((rows, ldo), 9.0, device="cuda")
+    check(lib.mt_sum_slices_f32(ptr(P), rows * ldp, ldp, S, ptr(out), ldo, rows, cols, stream_ptr()), "mt_sum_slices_f32")
+    out2 = torch.full((rows, ldo), 9.0, device="cuda")
+    check(lib.mt_sum_slices_f32(ptr(P), rows * ldp, ldp, S, ptr(out2), ldo, rows, cols, stream_ptr()), "mt_sum_slices_f32")
+    torch.cuda.synchronize()
+    want = P[:, :, :cols].double().sum(0)
+    assert (out[:, :cols].double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    assert torch.all(out[:, cols:] == 9.0) and torch.equal(out, out2)
