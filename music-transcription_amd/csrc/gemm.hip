@@ -394,7 +394,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 // run one barrier ahead of the upper half's and a SIMD holds one wave of each half, so while one is in its MFMA block
 // the other fetches its fragments.  The next tile's DMA is issued in phases 0-1 (two phases old when phase 3 waits for
 // it); each phase retires its own fragment reads before its first barrier, so a buffer is never restaged while a
-// lagging wave still reads it.  A wave's 128 x 64 outputs are 8 x 4 tiles of 16 x 16 (C: column = lane & 15,
+// lagging wave still reads it.  (Two phases of 32 MFMAs per K-tile: equal at K = 5120, 5 % faster at K = 1024 alone, but 202 VGPRs.  The
+// kernel is kept within 192 -- 2 waves x 192 + one 120-VGPR wave of a plain recurrence workgroup fill a SIMD's 512 -- so that
+// it can share a CU with a resident recurrence of another batch in flight; tests/test_kernel_budget_cpu.py guards the count.)
+// A wave's 128 x 64 outputs are 8 x 4 tiles of 16 x 16 (C: column = lane & 15,
 // rows 4 (lane >> 4) + j); fragment reads stay conflict-free under the same swizzle (lane = row & 15, 16-B chunk
 // 4 ks + (lane >> 4)).
 // One 16 x 16 accumulator tile.  The operands are ordered so that a lane's 4 registers run along the output's

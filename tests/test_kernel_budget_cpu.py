@@ -1,0 +1,33 @@
+"""Register budgets that multi-stream throughput depends on: the big-tile GEMM shares CUs with resident
+recurrence workgroups only while 2 x GEMM + 1 x recurrence waves fit a SIMD's 512 VGPRs.  Checked on the compiler's own
+metadata (hipcc cross-compiles gfx950 without a GPU)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "music-transcription_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _vgprs(src, tmp_path):
+    out = tmp_path / (src + ".s")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                    os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True, timeout=600)
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"\.set (\S+)\.num_vgpr, (\d+)", out.read_text())}
+
+
+def _alloc(n):
+    return (n + 7) // 8 * 8
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_gemm256x_and_plain_recurrence_share_a_simd(tmp_path):
+    g = {k: v for k, v in _vgprs("gemm.hip", tmp_path).items() if "gemm256x_kernel" in k}
+    r = {k: v for k, v in _vgprs("lstm.hip", tmp_path).items() if "lstm_rec_kernelILi8ELb0ELb0ELb0E" in k}
+    assert g and r
+    gemm, rec = max(g.values()), max(r.values())
+    assert 2 * _alloc(gemm) + _alloc(rec) <= 512, (gemm, rec)
