@@ -366,7 +366,7 @@ int    mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const float* dh
                             void* part_ws, size_t part_bytes, void* sync_ws, size_t sync_bytes, int B, int T, int H,
                             int flags, mt_stream_t stream);
 /* dgx -> dG [(t*B+b)*ldg + d*4H + gate*H + j] bf16 and dGT [(d*4H + gate*H + j)*ldt + t*B + b] bf16
- * (pre-zeroed by the caller: padded rows / columns are not written).                                       */
+ * (pre-zeroed by the caller: padded rows / columns are not written).  Either output may be NULL (skipped). */
 int    mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, long long ldt, int B, int T, int H,
                          mt_stream_t stream);
 /* hx -> HT[(d*rows_per_dir + k)*ld + t*B + b] = bf16 h of the forward pass's PREVIOUS step (zero at the

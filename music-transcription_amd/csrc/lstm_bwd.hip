@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void lstm_dg_unpack_kernel(const bf16_t* __res
     ((uint4*)&img[0][0][0])[threadIdx.x] = src[threadIdx.x];
     ((uint4*)&img[0][0][0])[threadIdx.x + 256] = src[threadIdx.x + 256];
     __syncthreads();
-    {   // dG rows: thread (u = tid & 31, row slot = tid >> 5)
+    if (dG) {   // dG rows: thread (u = tid & 31, row slot = tid >> 5)
         const int u = threadIdx.x & 31, jj = 32 * w + u;
         for (int c = threadIdx.x >> 5; c < 128; c += 8) {
             const int bb = c >> 2, p = c & 3;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void lstm_dg_unpack_kernel(const bf16_t* __res
                 dG[((size_t)t * B + g * 32 + bb) * ldg + (size_t)d * 4 * H + (size_t)p * H + jj] = img[2 * p + (u >> 4)][((u >> 3) & 1) * 32 + bb][u & 7];
         }
     }
-    {   // dGT rows: thread (batch = tid & 31, slot = tid >> 5)
+    if (dGT) {  // dGT rows: thread (batch = tid & 31, slot = tid >> 5)
         const int bb = threadIdx.x & 31;
         for (int c = threadIdx.x >> 5; c < 128; c += 8) {
             const int p = c >> 5, u = c & 31, jj = 32 * w + u;
@@ -376,7 +376,8 @@ extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const floa
 }
 
 extern "C" int mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, long long ldt, int B, int T, int H, mt_stream_t stream) {
-    MT_REQUIRE(dgx && dG && dGT && B > 0 && T > 0 && H % 16 == 0 && ldg >= 8 * H && ldt >= (long long)T * B, MT_EINVAL, "mt_lstm_dg_unpack: bad arguments");
+    MT_REQUIRE(dgx && (dG || dGT) && B > 0 && T > 0 && H % 16 == 0 && (!dG || ldg >= 8 * H) && (!dGT || ldt >= (long long)T * B), MT_EINVAL,
+               "mt_lstm_dg_unpack: bad arguments");
     hipLaunchKernelGGL(lstm_dg_unpack_kernel, dim3((H + 31) / 32, 2 * T, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dgx, (bf16_t*)dG, ldg, (bf16_t*)dGT, ldt, B, T, H);
     MT_CHECK_LAUNCH();

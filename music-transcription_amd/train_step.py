@@ -222,7 +222,9 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         dh = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
         check(lib.mt_gemm_lstm_dh(ptr(dL), 128, ptr(pk["fc_wT"]), 128, ptr(dh), B, T, Hp, H, 128, 0.0, sv["seed"], L - 1, _st()),
               "mt_gemm_lstm_dh (fc)")
-        dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
+        # two dgate buffers: the side stream still unpacks layer l's into dGT while the main stream's recurrence of layer l-1 runs
+        dgxs = [torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8) for _ in range(min(2, L))]
+        ev_unp = [None, None]
         # two partial-product workspaces: the first was filled with the poison pattern during the forward pass, the fill of
         # the next layer's (1 GB at H = 512) runs on the side stream under the current layer's recurrence
         parts = sv["parts"]
@@ -262,17 +264,22 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
                     check(lib.mt_lstm_bwd_poison(ptr(parts[1 - it]), parts[1 - it].numel(), B, T, Hp, _st()), "mt_lstm_bwd_poison")
                     ev_part[1 - it] = torch.cuda.Event()
                     ev_part[1 - it].record(side)
+            dgx = dgxs[it % len(dgxs)]
+            if ev_unp[it % len(dgxs)] is not None:
+                main.wait_event(ev_unp[it % len(dgxs)])  # the side stream's unpack of this buffer's previous user is done
             check(lib.mt_lstm_bidir_bwd_ex(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(part), part.numel(),
                                            ptr(sync), sync.numel(), B, T, Hp, 1, _st()), "mt_lstm_bidir_bwd")
+            ev = torch.cuda.Event()
+            ev.record(main)                              # dgates of this layer are complete
             if l == L - 1:                           # the host queues the side-stream work only once the top recurrence is running
                 enqueue_fc_wgrad()
                 enqueue_precompute()
-            # dGT is also read as a GEMM A operand from row 4Hp (reverse direction): whole 128-row tiles must stay inside it
+            # dG (rows = positions) feeds the input-gradient GEMM on the main stream; dGT (rows = gate units) only the weight
+            # gradients, so its half of the unpack runs on the side stream
+            # (dGT is also read as a GEMM A operand from row 4Hp (reverse direction): whole 128-row tiles must stay inside it)
             dG, dGT = torch.empty(Mpad, 8 * Hp, **bf), torch.empty(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
             dG[M:].zero_()                           # the unpack writes every column of the M valid rows / every row's M valid columns;
-            dGT[:, M:].zero_()                       # the K-padding (rows M.. of dG, columns M.. of dGT) must be zero
-            dGT[8 * Hp:].zero_()
-            check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * Hp, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
+            check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dG), 8 * Hp, None, 0, B, T, Hp, _st()), "mt_lstm_dg_unpack")
             # buffers of the side-stream work are allocated here, on the main stream (stream-ordered allocator)
             XTl, HT = XTs[l], HTs[l]
             gb, gwi, gwh = torch.empty(8 * Hp, **f32), torch.empty(8 * Hp, K, **f32), torch.empty(2, 4 * Hp, Hp, **f32)
@@ -282,8 +289,6 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
                 outs.append((torch.empty(4 * H, 64 * Fo2 if l == 0 else 2 * H, **f32), torch.empty(4 * H, H, **f32), torch.empty(4 * H, **f32),
                              torch.empty(4 * H, **f32)))
             keep += [dG, dGT, gb, gwi, gwh, Ph]
-            ev = torch.cuda.Event()
-            ev.record(main)
             # ---- input gradient: the only product the next layer down waits for
             if l > 0:                                # -> dh of layer l-1, whose output went through dropout in the forward pass
                 check(lib.mt_gemm_lstm_dh(ptr(dG), 8 * Hp, ptr(pk["w_ihT"][l]), 8 * Hp, ptr(dh), B, T, Hp, H, 8 * Hp,
@@ -293,6 +298,11 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
                 _gemm(dG, 8 * Hp, pk["w_ihT"][0], 8 * Hp, dX0, K0, M, K0, 8 * Hp)
             with torch.cuda.stream(side):
                 side.wait_event(ev)
+                dGT[:, M:].zero_()                   # the K-padding (columns M.. of dGT) and the tile rows past 8 Hp must be zero
+                dGT[8 * Hp:].zero_()
+                check(lib.mt_lstm_dg_unpack(ptr(dgx), None, 0, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
+                ev_unp[it % len(dgxs)] = torch.cuda.Event()
+                ev_unp[it % len(dgxs)].record(side)
                 check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
                 _gemm(dGT, Mpad, XTl, Mpad, gwi, K, 8 * Hp, K, Mpad)
                 if Sh > 1:                               # batch z = direction * Sh + K-slice
