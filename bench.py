@@ -223,8 +223,8 @@ def bench_train(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 5 ms: long enough that the first and last rounds of the streams in flight do not weigh)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight per GPU (each step is issued whole on stream i %% streams)")

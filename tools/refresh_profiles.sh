@@ -7,7 +7,7 @@ timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/full_gpu.log 2>&1
 timeout -k 10 300 python bench.py > $O/default_line.json 2> $O/default.err
 timeout -k 10 200 python bench.py --streams 1 --no-cpu-baseline > $O/1stream_line.json 2>/dev/null
 timeout -k 10 200 python bench.py --mode train --batch 16 > $O/train_line.json 2>/dev/null
-timeout -k 10 200 python bench.py --model cnn_rnn_large --batch 16 --steps 100 > $O/large_line.json 2>/dev/null
+timeout -k 10 200 python bench.py --model cnn_rnn_large --batch 16 > $O/large_line.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_default -- python3 $R/bench.py --no-cpu-baseline > $O/p_default.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_1stream -- python3 $R/bench.py --streams 1 --no-cpu-baseline > $O/p_1stream.log 2>&1
