@@ -32,6 +32,13 @@ extern "C" {
 #define MT_EHIP         -3   /* HIP runtime error (launch, memset, ...)          */
 #define MT_EUNSUPPORTED -4   /* configuration outside what the kernels implement */
 
+/* 16-bit operand type of the GEMM / convolution kernels (`_dt` entry points, mt_cnnrnn*_weights.operand_dtype).
+ * Both run at the same MFMA rate with f32 accumulation.  Inference uses f16 (11 significand bits: logits within
+ * ~1e-3 relative of the reference's fp32 arithmetic); the training step uses bf16 (f32's
+ * exponent range for gradients; BASELINE configs[3] names bf16).  The un-suffixed entry points are the bf16 forms. */
+#define MT_DT_BF16 0
+#define MT_DT_F16  1
+
 #define MT_N_FFT 2048        /* librosa default the reference relies on (main.py:117-122) */
 #define MT_N_PITCH 88
 
@@ -82,6 +89,11 @@ int    mt_conv1_bn_relu_pool(const float* mel, const float* chunk_max_power, con
                              void* act1, int B, int n_mels, int T, mt_stream_t stream);
 int    mt_conv2_bn_relu_pool(const void* act1, const void* w2, const float* bias, void* X0, int ldx,
                              int B, int F1, int T, mt_stream_t stream);
+/* The same with the 16-bit operand type chosen by the caller (dt = MT_DT_BF16 | MT_DT_F16). */
+int    mt_conv1_bn_relu_pool_dt(const float* mel, const float* chunk_max_power, const float* w, const float* bias,
+                                void* act1, int B, int n_mels, int T, int dt, mt_stream_t stream);
+int    mt_conv2_bn_relu_pool_dt(const void* act1, const void* w2, const float* bias, void* X0, int ldx,
+                                int B, int F1, int T, int dt, mt_stream_t stream);
 
 /* ------------------------------------------------------------------ GEMM (bf16 MFMA, f32 accumulate)
  * C[M][N] (f32) = A[M][K] (bf16) * W[N][K]^T (bf16) + bias[N] (f32, may be NULL).
@@ -99,6 +111,13 @@ int    mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const 
 /* Final projection with the reference's transpose fused: logits[b][n][t], rows m = t*B+b. */
 int    mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
                       int B, int T, int N, int K, mt_stream_t stream);
+/* The three GEMMs above with the operand type of A and W chosen by the caller (dt = MT_DT_BF16 | MT_DT_F16). */
+int    mt_gemm_f32acc_dt(const void* A, int lda, const void* W, int ldw, const float* bias,
+                         float* C, int ldc, int M, int N, int K, int dt, mt_stream_t stream);
+int    mt_gemm_lstm_gx_dt(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
+                          int B, int T, int H, int K, int dt, mt_stream_t stream);
+int    mt_gemm_logits_dt(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
+                         int B, int T, int N, int K, int dt, mt_stream_t stream);
 
 /* ------------------------------------------------------------------ bidirectional LSTM recurrence
  * nn.LSTM(batch_first, bidirectional) as the reference runs it (cnn_rnn_model.py:45-52,
@@ -142,9 +161,11 @@ typedef struct {
     int hidden;                              /* LSTM hidden size (1..1024); laid out padded to 16 */
     int layers;                              /* LSTM layers (<= MT_MAX_LSTM_LAYERS)               */
     int lstm_mode;                           /* 0 agent-scope hand-off, 1 XCD-local (mt_lstm_bidir_fwd_ex) */
+    int operand_dtype;                       /* MT_DT_BF16 / MT_DT_F16: type of every 16-bit weight below and of the */
+                                             /*   activations between the kernels (model.py packs f16 for inference) */
     const float* conv1_w;                    /* [32][9]  BN-folded                                */
     const float* conv1_b;                    /* [32]                                              */
-    const void*  conv2_w;                    /* bf16 [64][9][32] BN-folded                        */
+    const void*  conv2_w;                    /* 16-bit [64][9][32] BN-folded                        */
     const float* conv2_b;                    /* [64]                                              */
     const void*  w_ih[MT_MAX_LSTM_LAYERS];   /* bf16 [roundup(8Hp,128)][K_l], Hp = roundup(H,16), */
                                              /*   gate row p*Hp + j (zero for j >= H); layer 0 columns in */
@@ -195,6 +216,20 @@ int    mt_gemm_batched_bf16out(const void* A, int lda, long long sA1, long long 
 /* hx -> feature rows with a column offset, dropping padded hidden units (k >= Hv); X (bf16) and/or Y (f32). */
 int    mt_lstm_relayout_ex(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off,
                            int B, int T, int H, int Hv, mt_stream_t stream);
+/* `_dt` forms of the Large model's pieces: operand type (and type of a 16-bit output) dt = MT_DT_BF16 | MT_DT_F16. */
+int    mt_conv_cl_dt(const void* A, const void* S, const void* W, const float* bias, void* out,
+                     int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool,
+                     int out_mode, int ldx, int dt, mt_stream_t stream);
+int    mt_gemm_batched_f32_dt(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw,
+                              long long sW1, long long sW2, const float* bias, float* C, int ldc,
+                              long long sC1, long long sC2, int M, int N, int K, int batch, int zdiv, int dt,
+                              mt_stream_t stream);
+int    mt_gemm_batched_h16out_dt(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw,
+                                 long long sW1, long long sW2, const float* bias, void* C, int ldc,
+                                 long long sC1, long long sC2, int M, int N, int K, int batch, int zdiv,
+                                 int relu, int dt, mt_stream_t stream);
+int    mt_lstm_relayout_dt(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off,
+                           int B, int T, int H, int Hv, int dt, mt_stream_t stream);
 /* MultiHeadAttention pieces (cnn_rnn_model.py:118-139): P = softmax(clamp(S*scale, +-clip)) -> bf16 with
  * the key axis zero-padded to Tp; V^T per (chunk, head); y = LayerNorm(resid + proj) -> bf16.       */
 int    mt_attn_softmax_clamped(const float* S, int lds, void* P, int Tp, int T, long long rows,
@@ -204,6 +239,11 @@ int    mt_attn_transpose_v(const void* qkv, int ld3, int voff, void* VT, int B, 
 int    mt_layernorm_residual(const float* resid, int ldr, const float* proj, int ldp, const float* gamma,
                              const float* beta, void* y, int ldy, long long rows, int n, float eps,
                              mt_stream_t stream);
+int    mt_attn_softmax_clamped_dt(const float* S, int lds, void* P, int Tp, int T, long long rows,
+                                  float scale, float clip, int dt, mt_stream_t stream);
+int    mt_layernorm_residual_dt(const float* resid, int ldr, const float* proj, int ldp, const float* gamma,
+                                const float* beta, void* y, int ldy, long long rows, int n, float eps, int dt,
+                                mt_stream_t stream);
 
 /* CNNRNNModelLarge.forward, eval mode (cnn_rnn_model.py:262-348).  Packed by model.py: pack_large. */
 typedef struct {
@@ -211,6 +251,7 @@ typedef struct {
     int use_attention, use_heads, heads, head_dim_pad;  /* head_dim padded to a multiple of 64         */
     float attn_scale;                             /* (real head_dim)^-1/2                              */
     int lstm_mode;                                /* 0 agent-scope hand-off, 1 XCD-local               */
+    int operand_dtype;                            /* MT_DT_BF16 / MT_DT_F16 (as mt_cnnrnn_weights)     */
     const float* conv1_w; const float* conv1_b;   /* [32][9], [32]                                     */
     const void*  rb1c1_w; const float* rb1c1_b;   /* bf16 [64][9*32]                                   */
     const void*  rb1c2_w; const float* rb1c2_b;   /* bf16 [64][9*64 + 32]  (conv2 + 1x1 skip)          */

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmt_hip.so")
 MAX_LSTM_LAYERS = 8
 N_PITCH = 88
+DT_BF16, DT_F16 = 0, 1          # MT_DT_* (include/mt_hip.h): 16-bit operand type of the GEMM / conv kernels
 
 
 class MtError(RuntimeError):
@@ -49,7 +50,7 @@ class MelDesc(C.Structure):
 
 class CnnRnnWeights(C.Structure):
     """mt_cnnrnn_weights (include/mt_hip.h)."""
-    _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("lstm_mode", i32),
+    _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("lstm_mode", i32), ("operand_dtype", i32),
                 ("conv1_w", vp), ("conv1_b", vp), ("conv2_w", vp), ("conv2_b", vp),
                 ("w_ih", vp * MAX_LSTM_LAYERS), ("b_gates", vp * MAX_LSTM_LAYERS), ("w_hh", vp * MAX_LSTM_LAYERS),
                 ("fc_w", vp), ("fc_b", vp), ("w_ihx", vp * MAX_LSTM_LAYERS)]
@@ -58,7 +59,7 @@ class CnnRnnWeights(C.Structure):
 class CnnRnnLargeWeights(C.Structure):
     """mt_cnnrnn_large_weights (include/mt_hip.h)."""
     _fields_ = ([(n, i32) for n in ("n_mels", "hidden", "layers", "hidden_local", "use_attention", "use_heads", "heads", "head_dim_pad")]
-                + [("attn_scale", C.c_float), ("lstm_mode", i32)]
+                + [("attn_scale", C.c_float), ("lstm_mode", i32), ("operand_dtype", i32)]
                 + [(n, vp) for n in ("conv1_w", "conv1_b", "rb1c1_w", "rb1c1_b", "rb1c2_w", "rb1c2_b", "rb2c1_w", "rb2c1_b",
                                      "rb2c2_w", "rb2c2_b", "fa_w", "fa_b")]
                 + [("main_w_ih", vp * MAX_LSTM_LAYERS), ("main_b", vp * MAX_LSTM_LAYERS), ("main_w_hh", vp * MAX_LSTM_LAYERS)]
@@ -79,6 +80,17 @@ _SIGS = {
     "mt_mel_db_f32": (i32, [vp, C.POINTER(MelDesc), vp, i32, i32, vp, vp, i32, vp]),
     "mt_conv1_bn_relu_pool": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mt_conv2_bn_relu_pool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_conv1_bn_relu_pool_dt": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_conv2_bn_relu_pool_dt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mt_gemm_f32acc_dt": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mt_gemm_lstm_gx_dt": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mt_gemm_logits_dt": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mt_conv_cl_dt": (i32, [vp, vp, vp, vp, vp] + [i32] * 12 + [vp]),
+    "mt_gemm_batched_f32_dt": (i32, [vp, i32, ll, ll, vp, i32, ll, ll, vp, vp, i32, ll, ll, i32, i32, i32, i32, i32, i32, vp]),
+    "mt_gemm_batched_h16out_dt": (i32, [vp, i32, ll, ll, vp, i32, ll, ll, vp, vp, i32, ll, ll, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mt_lstm_relayout_dt": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "mt_attn_softmax_clamped_dt": (i32, [vp, i32, vp, i32, i32, ll, C.c_float, C.c_float, i32, vp]),
+    "mt_layernorm_residual_dt": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, ll, i32, C.c_float, i32, vp]),
     "mt_gemm_bf16_f32acc": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_lstm_gx": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_lstm_dh": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),

@@ -12,6 +12,7 @@
 namespace mt {
 
 // S[row][lds] f32 -> P[row][Tp] bf16, Tp = roundup(T, 64), columns >= T zero.  One wave per row.
+template <int DT>
 __global__ void attn_softmax_kernel(const float* __restrict__ S, int lds, bf16_t* __restrict__ P, int Tp, int T, int rows, float scale, float clip) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= rows) return;
@@ -23,7 +24,7 @@ __global__ void attn_softmax_kernel(const float* __restrict__ S, int lds, bf16_t
     for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
     const float inv = 1.0f / sum;
     for (int j = lane; j < Tp; j += 64)
-        p[j] = j < T ? f32_to_bf16(__expf(fminf(fmaxf(s[j] * scale, -clip), clip)) * inv) : (bf16_t)0;
+        p[j] = j < T ? f32_to_h16<DT>(__expf(fminf(fmaxf(s[j] * scale, -clip), clip)) * inv) : (bf16_t)0;
 }
 
 // V^T: qkv[(t*B+b)*ld3 + voff + head*dp + d]  ->  VT[(b*heads+head)][dpr rows][Tp] bf16, row d < dp (zero for t >= T);
@@ -45,6 +46,7 @@ __global__ void attn_vt_kernel(const bf16_t* __restrict__ qkv, int ld3, int voff
 
 // y = LayerNorm(resid + proj) over the first n columns -> bf16 [rows][ldy] (columns n..ldy-1 untouched).
 // One wave per row; values stay in registers between the two passes (n <= 64 * 32).
+template <int DT>
 __global__ void ln_residual_kernel(const float* __restrict__ resid, int ldr, const float* __restrict__ proj, int ldp,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ y, int ldy,
                                    int rows, int n, float eps) {
@@ -76,7 +78,7 @@ __global__ void ln_residual_kernel(const float* __restrict__ resid, int ldr, con
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int j = lane + 64 * i;
-        if (j < n) y[(size_t)wave * ldy + j] = f32_to_bf16((v[i] - mean) * rstd * gamma[j] + beta[j]);
+        if (j < n) y[(size_t)wave * ldy + j] = f32_to_h16<DT>((v[i] - mean) * rstd * gamma[j] + beta[j]);
     }
 }
 
@@ -84,11 +86,19 @@ __global__ void ln_residual_kernel(const float* __restrict__ resid, int ldr, con
 
 using namespace mt;
 
-extern "C" int mt_attn_softmax_clamped(const float* S, int lds, void* P, int Tp, int T, long long rows, float scale, float clip, mt_stream_t stream) {
+extern "C" int mt_attn_softmax_clamped_dt(const float* S, int lds, void* P, int Tp, int T, long long rows, float scale, float clip, int dt,
+                                          mt_stream_t stream) {
     MT_REQUIRE(S && P && T > 0 && Tp >= T && Tp % 64 == 0 && lds >= T && rows > 0, MT_EINVAL, "mt_attn_softmax_clamped: bad arguments");
-    hipLaunchKernelGGL(attn_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, lds, (bf16_t*)P, Tp, T, (int)rows, scale, clip);
+    MT_REQUIRE_DT(dt, "mt_attn_softmax_clamped");
+    if (dt == MT_DT_F16)
+        hipLaunchKernelGGL(attn_softmax_kernel<MT_DT_F16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, lds, (bf16_t*)P, Tp, T, (int)rows, scale, clip);
+    else
+        hipLaunchKernelGGL(attn_softmax_kernel<MT_DT_BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, lds, (bf16_t*)P, Tp, T, (int)rows, scale, clip);
     MT_CHECK_LAUNCH();
     return MT_OK;
+}
+extern "C" int mt_attn_softmax_clamped(const float* S, int lds, void* P, int Tp, int T, long long rows, float scale, float clip, mt_stream_t stream) {
+    return mt_attn_softmax_clamped_dt(S, lds, P, Tp, T, rows, scale, clip, MT_DT_BF16, stream);
 }
 
 extern "C" int mt_attn_transpose_v(const void* qkv, int ld3, int voff, void* VT, int B, int T, int Tp, int heads, int dp, mt_stream_t stream) {
@@ -99,11 +109,20 @@ extern "C" int mt_attn_transpose_v(const void* qkv, int ld3, int voff, void* VT,
     return MT_OK;
 }
 
-extern "C" int mt_layernorm_residual(const float* resid, int ldr, const float* proj, int ldp, const float* gamma, const float* beta,
-                                     void* y, int ldy, long long rows, int n, float eps, mt_stream_t stream) {
+extern "C" int mt_layernorm_residual_dt(const float* resid, int ldr, const float* proj, int ldp, const float* gamma, const float* beta,
+                                        void* y, int ldy, long long rows, int n, float eps, int dt, mt_stream_t stream) {
     MT_REQUIRE(resid && proj && gamma && beta && y && rows > 0 && n > 0 && n <= 2048 && ldy >= n, MT_EINVAL, "mt_layernorm_residual: bad arguments");
-    hipLaunchKernelGGL(ln_residual_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, resid, ldr, proj, ldp,
-                       gamma, beta, (bf16_t*)y, ldy, (int)rows, n, eps);
+    MT_REQUIRE_DT(dt, "mt_layernorm_residual");
+    if (dt == MT_DT_F16)
+        hipLaunchKernelGGL(ln_residual_kernel<MT_DT_F16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, resid, ldr, proj, ldp,
+                           gamma, beta, (bf16_t*)y, ldy, (int)rows, n, eps);
+    else
+        hipLaunchKernelGGL(ln_residual_kernel<MT_DT_BF16>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, resid, ldr, proj, ldp,
+                           gamma, beta, (bf16_t*)y, ldy, (int)rows, n, eps);
     MT_CHECK_LAUNCH();
     return MT_OK;
+}
+extern "C" int mt_layernorm_residual(const float* resid, int ldr, const float* proj, int ldp, const float* gamma, const float* beta,
+                                     void* y, int ldy, long long rows, int n, float eps, mt_stream_t stream) {
+    return mt_layernorm_residual_dt(resid, ldr, proj, ldp, gamma, beta, y, ldy, rows, n, eps, MT_DT_BF16, stream);
 }

@@ -17,6 +17,7 @@ namespace mt {
 // ---------------------------------------------------------------- conv1 (Cin = 1, direct, fp32 VALU)
 // One thread per pooled output position (b, fo, t): 4x3 input patch, 32 channels x 2 rows x 9 taps.
 // Bandwidth-bound: reads 4 B/position of mel, writes 64 B/position (one full line per thread).
+template <int DT>
 __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ mel, const unsigned* __restrict__ chunk_max,
                                                     const float* __restrict__ w /*[32][9]*/, const float* __restrict__ bias /*[32]*/,
                                                     bf16_t* __restrict__ act1, int F, int T, int Fo) {
@@ -51,8 +52,8 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
                 a1 = fmaf(wv, p[kh + 1][kw], a1);
             }
         const float v = fmaxf(fmaxf(a0, a1), 0.0f);
-        if (c & 1) packed[c >> 1] |= ((unsigned)f32_to_bf16(v)) << 16;
-        else packed[c >> 1] = f32_to_bf16(v);
+        if (c & 1) packed[c >> 1] |= ((unsigned)f32_to_h16<DT>(v)) << 16;
+        else packed[c >> 1] = f32_to_h16<DT>(v);
     }
     uint4* dst = (uint4*)(act1 + (((size_t)b * Fo + fo) * T + t) * 32);
 #pragma unroll
@@ -80,6 +81,7 @@ constexpr int C2_ROWS = 2 * C2_TF + 2, C2_PITCH = 20; // input tile rows, positi
 constexpr int C2_DMA_INSTRS = (C2_ROWS * C2_PITCH * 4 + 63) / 64;          // 64 x 16-B pieces per wave instruction
 constexpr int C2_LDS_BYTES = C2_DMA_INSTRS * 1024;
 
+template <int DT>
 __global__ __launch_bounds__(256, 2) void conv2_kernel(const bf16_t* __restrict__ act1, const bf16_t* __restrict__ w2 /*[64][9][32]*/,
                                                        const float* __restrict__ bias /*[64]*/, bf16_t* __restrict__ X0,
                                                        int B, int F1, int T, int Fo2, int ldx, int tiles_f, int tiles_t) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv2_kernel(const bf16_t* __restrict_
                     for (int mi = 0; mi < 4; ++mi) {
                         const int row = 2 * (mgrp * 8 + half * 4 + mi) + fbit + kh;
                         const bf16x8 afrag = *(const bf16x8*)(in_s + (row * C2_PITCH + col) * 64 + (chunk << 4));
-                        acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, wf[tap * 2 + s2], acc[mi], 0, 0, 0);
+                        acc[mi] = mfma_32x32x16<DT>(afrag, wf[tap * 2 + s2], acc[mi]);
                     }
                 }
             }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv2_kernel(const bf16_t* __restrict_
                     for (int p = 0; p < 4; ++p) {
                         const int tl = p + 8 * q + 4 * h, t = t0 + tl;
                         const float v = fmaxf(fmaxf(acc[mi][4 * q + p], acc[mi][4 * (q + 2) + p]) + bv, 0.0f);
-                        if (t < T) X0[((size_t)t * B + b) * ldx + fo * 64 + co] = f32_to_bf16(v);
+                        if (t < T) X0[((size_t)t * B + b) * ldx + fo * 64 + co] = f32_to_h16<DT>(v);
                     }
             }
         }
@@ -174,33 +176,53 @@ __global__ __launch_bounds__(256, 2) void conv2_kernel(const bf16_t* __restrict_
 
 using namespace mt;
 
-extern "C" int mt_conv1_bn_relu_pool(const float* mel, const float* chunk_max_power, const float* w, const float* bias,
-                                     void* act1, int B, int n_mels, int T, mt_stream_t stream) {
+extern "C" int mt_conv1_bn_relu_pool_dt(const float* mel, const float* chunk_max_power, const float* w, const float* bias,
+                                        void* act1, int B, int n_mels, int T, int dt, mt_stream_t stream) {
     MT_REQUIRE(mel && w && bias && act1, MT_EINVAL, "mt_conv1_bn_relu_pool: null pointer");
     MT_REQUIRE(B > 0 && n_mels >= 2 && T > 0, MT_EINVAL, "mt_conv1_bn_relu_pool: bad dims B=%d n_mels=%d T=%d", B, n_mels, T);
+    MT_REQUIRE_DT(dt, "mt_conv1_bn_relu_pool");
     const int Fo = n_mels / 2;
     dim3 grid(cdiv(T, 64), cdiv(Fo, 4), B);
-    hipLaunchKernelGGL(conv1_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel, (const unsigned*)chunk_max_power, w, bias,
-                       (bf16_t*)act1, n_mels, T, Fo);
+    if (dt == MT_DT_F16)
+        hipLaunchKernelGGL(conv1_kernel<MT_DT_F16>, grid, dim3(256), 0, (hipStream_t)stream, mel, (const unsigned*)chunk_max_power, w, bias,
+                           (bf16_t*)act1, n_mels, T, Fo);
+    else
+        hipLaunchKernelGGL(conv1_kernel<MT_DT_BF16>, grid, dim3(256), 0, (hipStream_t)stream, mel, (const unsigned*)chunk_max_power, w, bias,
+                           (bf16_t*)act1, n_mels, T, Fo);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
+extern "C" int mt_conv1_bn_relu_pool(const float* mel, const float* chunk_max_power, const float* w, const float* bias,
+                                     void* act1, int B, int n_mels, int T, mt_stream_t stream) {
+    return mt_conv1_bn_relu_pool_dt(mel, chunk_max_power, w, bias, act1, B, n_mels, T, MT_DT_BF16, stream);
+}
 
-extern "C" int mt_conv2_bn_relu_pool(const void* act1, const void* w2, const float* bias, void* X0, int ldx,
-                                     int B, int F1, int T, mt_stream_t stream) {
-    MT_REQUIRE(act1 && w2 && bias && X0, MT_EINVAL, "mt_conv2_bn_relu_pool: null pointer");
-    MT_REQUIRE(B > 0 && F1 >= 2 && T > 0 && ldx >= (F1 / 2) * 64, MT_EINVAL, "mt_conv2_bn_relu_pool: bad dims");
+template <int DT>
+static int conv2_launch(const void* act1, const void* w2, const float* bias, void* X0, int ldx, int B, int F1, int T, hipStream_t st) {
     const int Fo2 = F1 / 2;
-    MT_REQUIRE((size_t)F1 * T * 64 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_conv2_bn_relu_pool: chunk activation too large for one buffer descriptor");
     static bool attr_set = false;
     if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv2_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
         attr_set = true;
     }
     const int tiles_t = cdiv(T, C2_TT), tiles_f = cdiv(Fo2, C2_TF), n_tiles = B * tiles_f * tiles_t;
     dim3 grid(n_tiles < 512 ? n_tiles : 512);          // persistent: two workgroups per CU walk the tiles
-    hipLaunchKernelGGL(conv2_kernel, grid, dim3(256), C2_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)act1,
+    hipLaunchKernelGGL(conv2_kernel<DT>, grid, dim3(256), C2_LDS_BYTES, st, (const bf16_t*)act1,
                        (const bf16_t*)w2, bias, (bf16_t*)X0, B, F1, T, Fo2, ldx, tiles_f, tiles_t);
     MT_CHECK_LAUNCH();
     return MT_OK;
+}
+
+extern "C" int mt_conv2_bn_relu_pool_dt(const void* act1, const void* w2, const float* bias, void* X0, int ldx,
+                                        int B, int F1, int T, int dt, mt_stream_t stream) {
+    MT_REQUIRE(act1 && w2 && bias && X0, MT_EINVAL, "mt_conv2_bn_relu_pool: null pointer");
+    MT_REQUIRE(B > 0 && F1 >= 2 && T > 0 && ldx >= (F1 / 2) * 64, MT_EINVAL, "mt_conv2_bn_relu_pool: bad dims");
+    MT_REQUIRE_DT(dt, "mt_conv2_bn_relu_pool");
+    MT_REQUIRE((size_t)F1 * T * 64 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_conv2_bn_relu_pool: chunk activation too large for one buffer descriptor");
+    return dt == MT_DT_F16 ? conv2_launch<MT_DT_F16>(act1, w2, bias, X0, ldx, B, F1, T, (hipStream_t)stream)
+                           : conv2_launch<MT_DT_BF16>(act1, w2, bias, X0, ldx, B, F1, T, (hipStream_t)stream);
+}
+extern "C" int mt_conv2_bn_relu_pool(const void* act1, const void* w2, const float* bias, void* X0, int ldx,
+                                     int B, int F1, int T, mt_stream_t stream) {
+    return mt_conv2_bn_relu_pool_dt(act1, w2, bias, X0, ldx, B, F1, T, MT_DT_BF16, stream);
 }

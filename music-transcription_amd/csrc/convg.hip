@@ -38,7 +38,7 @@ __device__ __forceinline__ int cg_swz(int col, int nc_log2) {
     return (col >> (4 - nc_log2)) & ((1 << nc_log2) - 1);
 }
 
-template <int KC, int BN_, bool POOL, int OUT>
+template <int KC, int BN_, bool POOL, int OUT, int DT>
 __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #define CG_MFMA(S)                                                                                                \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                              \
         _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                         \
-            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i_], fb[S][j_], acc[i_][j_], 0, 0, 0);
+            acc[i_][j_] = mfma_32x32x16<DT>(fa[S][i_], fb[S][j_], acc[i_][j_]);
 #define CG_CHUNK(inp, abase, tapoff, cb, sw)                                                                      \
     do {                                                                                                          \
         const char* wb_ = wbuf + (q & 1) * WB;                                                                    \
@@ -197,18 +197,18 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
                         if (fo >= Fo) continue;
                         float v = fmaxf(v0, v1);
                         if (a.relu) v = fmaxf(v, 0.0f);
-                        if (OUT == CG_OUT_CL) a.out[(((size_t)b * Fo + fo) * a.T + t) * a.Cout + co] = f32_to_bf16(v);
-                        else a.out[((size_t)t * a.B + b) * a.ldx + (size_t)fo * a.Cout + co] = f32_to_bf16(v);
+                        if (OUT == CG_OUT_CL) a.out[(((size_t)b * Fo + fo) * a.T + t) * a.Cout + co] = f32_to_h16<DT>(v);
+                        else a.out[((size_t)t * a.B + b) * a.ldx + (size_t)fo * a.Cout + co] = f32_to_h16<DT>(v);
                     } else {
                         const int f = f0 + 4 * wm + 2 * i;
                         float u0 = v0, u1 = v1;
                         if (a.relu) { u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
                         if (OUT == CG_OUT_CL) {
-                            if (f < Fo) a.out[(((size_t)b * Fo + f) * a.T + t) * a.Cout + co] = f32_to_bf16(u0);
-                            if (f + 1 < Fo) a.out[(((size_t)b * Fo + f + 1) * a.T + t) * a.Cout + co] = f32_to_bf16(u1);
+                            if (f < Fo) a.out[(((size_t)b * Fo + f) * a.T + t) * a.Cout + co] = f32_to_h16<DT>(u0);
+                            if (f + 1 < Fo) a.out[(((size_t)b * Fo + f + 1) * a.T + t) * a.Cout + co] = f32_to_h16<DT>(u1);
                         } else {
-                            if (f < Fo) a.out[((size_t)t * a.B + b) * a.ldx + (size_t)f * a.Cout + co] = f32_to_bf16(u0);
-                            if (f + 1 < Fo) a.out[((size_t)t * a.B + b) * a.ldx + (size_t)(f + 1) * a.Cout + co] = f32_to_bf16(u1);
+                            if (f < Fo) a.out[((size_t)t * a.B + b) * a.ldx + (size_t)f * a.Cout + co] = f32_to_h16<DT>(u0);
+                            if (f + 1 < Fo) a.out[((size_t)t * a.B + b) * a.ldx + (size_t)(f + 1) * a.Cout + co] = f32_to_h16<DT>(u1);
                         }
                     }
                 }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #undef CG_WSWZ
 }
 
-template <int KC, int BN_, bool POOL, int OUT>
+template <int KC, int BN_, bool POOL, int OUT, int DT>
 static int cg_launch(const ConvGArgs& a, hipStream_t st) {
     const int nc1 = a.C1 / 8, pr1 = 16 / nc1 > 0 ? 16 / nc1 : 1;
     const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
@@ -227,12 +227,12 @@ static int cg_launch(const ConvGArgs& a, hipStream_t st) {
     MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "conv: tile needs %zu B of LDS", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)convg_kernel<KC, BN_, POOL, OUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)convg_kernel<KC, BN_, POOL, OUT, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int tiles_t = cdiv(a.T, CG_TT);
     dim3 grid(tiles_t * (a.Cout / BN_), cdiv(a.F, CG_TF), a.B);
-    hipLaunchKernelGGL((convg_kernel<KC, BN_, POOL, OUT>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((convg_kernel<KC, BN_, POOL, OUT, DT>), grid, dim3(512), lds, st, a);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
@@ -241,28 +241,39 @@ static int cg_launch(const ConvGArgs& a, hipStream_t st) {
 
 using namespace mt;
 
-// out_mode 0: channels-last activation [B][Fout][T][Cout] bf16; 1: GEMM-A rows X[(t*B+b)*ldx + fo*Cout + co].
-extern "C" int mt_conv_cl_bf16(const void* A, const void* S, const void* W, const float* bias, void* out,
-                               int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,
-                               mt_stream_t stream) {
-    MT_REQUIRE(A && W && bias && out, MT_EINVAL, "mt_conv_cl_bf16: null pointer");
-    MT_REQUIRE(B > 0 && F > 0 && T > 0 && (KH == 3 || KH == 7) && (C1 == 32 || C1 == 64 || C1 == 128) &&
-               (C2 == 0 || C2 == 32 || C2 == 64 || C2 == 128) && (C2 == 0 || S) && (Cout % 64 == 0), MT_EUNSUPPORTED,
-               "mt_conv_cl_bf16: unsupported shape C1=%d C2=%d Cout=%d KH=%d", C1, C2, Cout, KH);
-    ConvGArgs a{(const bf16_t*)A, (const bf16_t*)S, (const bf16_t*)W, bias, (bf16_t*)out, B, F, T, C1, C2, Cout, KH, relu, ldx};
-    hipStream_t st = (hipStream_t)stream;
-    const bool kc64 = (C1 % 64 == 0) && (C2 % 64 == 0);
-    const bool bn128 = (Cout % 128 == 0);
+// out_mode 0: channels-last activation [B][Fout][T][Cout] (16-bit, operand type dt); 1: GEMM-A rows X[(t*B+b)*ldx + fo*Cout + co].
+template <int DT>
+static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStream_t st) {
+    const bool kc64 = (a.C1 % 64 == 0) && (a.C2 % 64 == 0);
+    const bool bn128 = (a.Cout % 128 == 0);
 #define CG_DISPATCH(KC_, BN__)                                                                     \
     do {                                                                                           \
-        if (pool && out_mode == 1) return cg_launch<KC_, BN__, true, CG_OUT_X>(a, st);            \
-        if (pool) return cg_launch<KC_, BN__, true, CG_OUT_CL>(a, st);                            \
-        if (out_mode == 1) return cg_launch<KC_, BN__, false, CG_OUT_X>(a, st);                   \
-        return cg_launch<KC_, BN__, false, CG_OUT_CL>(a, st);                                     \
+        if (pool && out_mode == 1) return cg_launch<KC_, BN__, true, CG_OUT_X, DT>(a, st);        \
+        if (pool) return cg_launch<KC_, BN__, true, CG_OUT_CL, DT>(a, st);                        \
+        if (out_mode == 1) return cg_launch<KC_, BN__, false, CG_OUT_X, DT>(a, st);               \
+        return cg_launch<KC_, BN__, false, CG_OUT_CL, DT>(a, st);                                 \
     } while (0)
     if (kc64 && bn128) CG_DISPATCH(64, 128);
     if (kc64) CG_DISPATCH(64, 64);
     if (bn128) CG_DISPATCH(32, 128);
     CG_DISPATCH(32, 64);
 #undef CG_DISPATCH
+}
+
+extern "C" int mt_conv_cl_dt(const void* A, const void* S, const void* W, const float* bias, void* out,
+                             int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,
+                             int dt, mt_stream_t stream) {
+    MT_REQUIRE(A && W && bias && out, MT_EINVAL, "mt_conv_cl: null pointer");
+    MT_REQUIRE_DT(dt, "mt_conv_cl");
+    MT_REQUIRE(B > 0 && F > 0 && T > 0 && (KH == 3 || KH == 7) && (C1 == 32 || C1 == 64 || C1 == 128) &&
+               (C2 == 0 || C2 == 32 || C2 == 64 || C2 == 128) && (C2 == 0 || S) && (Cout % 64 == 0), MT_EUNSUPPORTED,
+               "mt_conv_cl: unsupported shape C1=%d C2=%d Cout=%d KH=%d", C1, C2, Cout, KH);
+    ConvGArgs a{(const bf16_t*)A, (const bf16_t*)S, (const bf16_t*)W, bias, (bf16_t*)out, B, F, T, C1, C2, Cout, KH, relu, ldx};
+    return dt == MT_DT_F16 ? conv_cl_dispatch<MT_DT_F16>(a, pool, out_mode, (hipStream_t)stream)
+                           : conv_cl_dispatch<MT_DT_BF16>(a, pool, out_mode, (hipStream_t)stream);
+}
+extern "C" int mt_conv_cl_bf16(const void* A, const void* S, const void* W, const float* bias, void* out,
+                               int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,
+                               mt_stream_t stream) {
+    return mt_conv_cl_dt(A, S, W, bias, out, B, F, T, C1, C2, Cout, KH, relu, pool, out_mode, ldx, MT_DT_BF16, stream);
 }

@@ -58,7 +58,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 
 // Epilogue of ONE 32x32 accumulator tile whose first row / column is (mb, nb).  Unswapped: lane column = n, register
 // rows = m.  Swapped (EPI_LSTM_GX): lane column = m, register rows = n.
-template <int EPI>
+template <int EPI, int DT>
 __device__ __forceinline__ void epilogue_tile(const f32x16& acc, int mb, int nb, int r, int h, int M, int N, const GemmEpi& ep, float* outp) {
     if (EPI == EPI_ROWMAJOR) {
         const int n = nb + r;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, int mb, int nb,
             const int m = mb + (e & 3) + 8 * (e >> 2) + 4 * h;
             float v = acc[e] + bv;
             if (ep.relu) v = fmaxf(v, 0.0f);
-            if (m < M && n < N) o[(size_t)m * ep.ldc + n] = f32_to_bf16(v);
+            if (m < M && n < N) o[(size_t)m * ep.ldc + n] = f32_to_h16<DT>(v);
         }
     } else if (EPI == EPI_LSTM_DH) {
         const int n = nb + r;
@@ -129,7 +129,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, int mb, int nb,
     }
 }
 
-template <int EPI>
+template <int EPI, int DT>
 __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                    int M, int N, int K, GemmEpi ep) {
     constexpr bool SWAP = (EPI == EPI_LSTM_GX);
@@ -190,15 +190,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
     fb1##S = *(const bf16x8*)((ws) + roww1 * 128 + (swz(roww1, (ks) * 2 + h) << 4));
 #define MT_MFMA4(S)                                                                                            \
     if (SWAP) {                                                                                                \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0##S, fa0##S, acc[0][0], 0, 0, 0);               \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1##S, fa0##S, acc[0][1], 0, 0, 0);               \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb0##S, fa1##S, acc[1][0], 0, 0, 0);               \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1##S, fa1##S, acc[1][1], 0, 0, 0);               \
+        acc[0][0] = mfma_32x32x16<DT>(fb0##S, fa0##S, acc[0][0]);               \
+        acc[0][1] = mfma_32x32x16<DT>(fb1##S, fa0##S, acc[0][1]);               \
+        acc[1][0] = mfma_32x32x16<DT>(fb0##S, fa1##S, acc[1][0]);               \
+        acc[1][1] = mfma_32x32x16<DT>(fb1##S, fa1##S, acc[1][1]);               \
     } else {                                                                                                   \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0##S, fb0##S, acc[0][0], 0, 0, 0);               \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0##S, fb1##S, acc[0][1], 0, 0, 0);               \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1##S, fb0##S, acc[1][0], 0, 0, 0);               \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1##S, fb1##S, acc[1][1], 0, 0, 0);               \
+        acc[0][0] = mfma_32x32x16<DT>(fa0##S, fb0##S, acc[0][0]);               \
+        acc[0][1] = mfma_32x32x16<DT>(fa0##S, fb1##S, acc[0][1]);               \
+        acc[1][0] = mfma_32x32x16<DT>(fa1##S, fb0##S, acc[1][0]);               \
+        acc[1][1] = mfma_32x32x16<DT>(fa1##S, fb1##S, acc[1][1]);               \
     }
 #define MT_COMPUTE(buf)                                                     \
     do {                                                                    \
@@ -256,139 +256,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) epilogue_tile<EPI>(acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, r, h, M, N, ep, outp);
+        for (int j = 0; j < 2; ++j) epilogue_tile<EPI, DT>(acc[i][j], m0 + wm * 64 + i * 32, n0 + wn * 64 + j * 32, r, h, M, N, ep, outp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs each = 4 x 2 MFMA tiles), one workgroup per CU
-// (128 KB of LDS: two K-tile buffers).  Same staging as gemm_kernel (LDS-DMA, source-side swizzle, one barrier per
-// K-tile, the next tile's DMA in flight under this tile's MFMAs), but a wave now feeds 8 MFMAs from 6 fragment reads
-// per 16-wide k-step (gemm_kernel: 4 from 4) and a K-tile carries 4x the MFMA work per barrier.  Rows past the
-// operands' readable extent (a_rows / w_rows = roundup(M or N, 128), the entry points' contract) are clamped to the last
-// readable row: they only feed outputs that are never stored.
+// 256 x 256 x 64 tile, 8 waves (2 along M x 4 along N, 128 x 64 outputs each), one workgroup per CU (128 KB of LDS: two
+// K-tile buffers).  Same staging as gemm_kernel (LDS-DMA, source-side swizzle).  Rows past the operands' readable extent
+// (a_rows / w_rows = roundup(M or N, 128), the entry points' contract) are clamped to the last readable row: they only
+// feed outputs that are never stored.
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int G256_LDS = 2 * (BM2 + BN2) * BK * 2;
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
-                                                      int M, int N, int K, GemmEpi ep) {
-    constexpr bool SWAP = (EPI == EPI_LSTM_GX);
-    extern __shared__ __attribute__((aligned(16))) char smem2[];
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    int m0, n0;
-    {
-        const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = (N + BN2 - 1) / BN2, total = tiles_m * tiles_n;
-        const int bid = blockIdx.x, xcd = bid & 7, q = total >> 3, rmd = total & 7;
-        const int pid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
-        constexpr int GM = 4;                              // an XCD's 32 resident tiles: 4 tile rows x 8 tile columns
-        const int per_group = GM * tiles_n, grp = pid / per_group, first_m = grp * GM;
-        const int gm = min(GM, tiles_m - first_m), in_grp = pid - grp * per_group;
-        m0 = (first_m + in_grp % gm) * BM2;
-        n0 = (in_grp / gm) * BN2;
-    }
-    float* outp;
-    {
-        const int z1 = blockIdx.z / ep.zdiv, z2 = blockIdx.z - z1 * ep.zdiv;
-        A += (size_t)(z1 * ep.sA + z2 * ep.sA2);
-        W += (size_t)(z1 * ep.sW + z2 * ep.sW2);
-        const long long oc = z1 * ep.sC + z2 * ep.sC2;
-        outp = ep.out + (EPI == EPI_ROWMAJOR_BF16 ? oc / 2 : oc);
-    }
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = wv >> 2, wn = wv & 3;
-    const int a_last = ((M + 127) & ~127) - 1, w_last = ((N + 127) & ~127) - 1;
-
-    typedef __attribute__((address_space(1))) const void gvoid_t;
-    typedef __attribute__((address_space(3))) void lvoid_t;
-    const int drow = lane >> 3, dslot = lane & 7;
-    // wave wv stages rows [32 wv, 32 wv + 32) of both 256-row tiles: 4 + 4 wave instructions of 1 KB per K-tile
-#define G2_DMA1(kt, buf, J)                                                                                   \
-    {                                                                                                         \
-        const int row_ = wv * 32 + (J) * 8 + drow;                                                            \
-        const int chunk_ = dslot ^ ((row_ >> 1) & 7);                                                         \
-        const bf16_t* ga_ = A + (size_t)min(m0 + row_, a_last) * lda + (size_t)(kt) * BK + chunk_ * 8;        \
-        const bf16_t* gw_ = W + (size_t)min(n0 + row_, w_last) * ldw + (size_t)(kt) * BK + chunk_ * 8;        \
-        char* la_ = smem2 + (buf) * (BM2 + BN2) * BK * 2 + (wv * 32 + (J) * 8) * 128;                         \
-        __builtin_amdgcn_global_load_lds((gvoid_t*)ga_, (lvoid_t*)la_, 16, 0, 0);                             \
-        __builtin_amdgcn_global_load_lds((gvoid_t*)gw_, (lvoid_t*)(la_ + BM2 * BK * 2), 16, 0, 0);            \
-    }
-#define G2_DMA(kt, buf) do { G2_DMA1(kt, buf, 0) G2_DMA1(kt, buf, 1) G2_DMA1(kt, buf, 2) G2_DMA1(kt, buf, 3) } while (0)
-#define G2_READ(S, as, ws, ks)                                                                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                         \
-        const int ra_ = wm * 128 + i_ * 32 + r;                                                                \
-        fa[S][i_] = *(const bf16x8*)((as) + ra_ * 128 + (swz(ra_, (ks) * 2 + h) << 4));                        \
-    }                                                                                                          \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                         \
-        const int rw_ = wn * 64 + j_ * 32 + r;                                                                 \
-        fb[S][j_] = *(const bf16x8*)((ws) + rw_ * 128 + (swz(rw_, (ks) * 2 + h) << 4));                        \
-    }
-#define G2_MFMA(S)                                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                           \
-        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                       \
-            acc[i_][j_] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[S][j_], fa[S][i_], acc[i_][j_], 0, 0, 0) \
-                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][i_], fb[S][j_], acc[i_][j_], 0, 0, 0);
-    // raised wave priority around the MFMA groups: the SIMD's other wave gets the issue slots for its LDS reads and DMA
-    // in between (+6 % measured)
-#define G2_PRIO(x) __builtin_amdgcn_s_setprio(x);
-#define G2_COMPUTE(buf)                                                     \
-    do {                                                                    \
-        const char* as = smem2 + (buf) * (BM2 + BN2) * BK * 2;              \
-        const char* ws = as + BM2 * BK * 2;                                 \
-        G2_READ(0, as, ws, 0)                                               \
-        G2_READ(1, as, ws, 1)                                               \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        G2_PRIO(1) G2_MFMA(0) G2_PRIO(0)                                    \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        G2_READ(0, as, ws, 2)                                               \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        G2_PRIO(1) G2_MFMA(1) G2_PRIO(0)                                    \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        G2_READ(1, as, ws, 3)                                               \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        G2_PRIO(1) G2_MFMA(0) G2_PRIO(0)                                    \
-        G2_PRIO(1) G2_MFMA(1) G2_PRIO(0)                                    \
-    } while (0)
-
-    bf16x8 fa[2][4], fb[2][2];
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const int nk = K / BK;
-    G2_DMA(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 1 < nk) G2_DMA(kt + 1, 1);
-        G2_COMPUTE(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) {
-            if (kt + 2 < nk) G2_DMA(kt + 2, 0);
-            G2_COMPUTE(1);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-    }
-#undef G2_DMA
-#undef G2_DMA1
-#undef G2_COMPUTE
-#undef G2_READ
-#undef G2_MFMA
-#undef G2_PRIO
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) epilogue_tile<EPI>(acc[i][j], m0 + wm * 128 + i * 32, n0 + wn * 64 + j * 32, r, h, M, N, ep, outp);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// The same 256 x 256 x 64 tile on v_mfma_f32_16x16x32_bf16 with a ping-pong schedule.  Two things bound gemm256_kernel:
-// every wave's LDS latency sits in front of its own MFMAs, and under MFMA load on real data the chip holds a lower
+// The 256 x 256 x 64 tile on v_mfma_f32_16x16x32_{bf16,f16} with a ping-pong schedule.  Two things bound a plain
+// 32x32x16 version of this tile: every wave's LDS latency sits in front of its own MFMAs, and under MFMA load on real data the chip holds a lower
 // clock for the 32x32x16 shape than for 16x16x32 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back 7).
 // Here a K-tile is 4 phases of [fragment reads (+ DMA issue)] barrier [16 MFMAs] barrier; the waves of the lower M half
 // run one barrier ahead of the upper half's and a SIMD holds one wave of each half, so while one is in its MFMA block
@@ -403,7 +284,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const bf16_t* __restrict__
 // One 16 x 16 accumulator tile.  The operands are ordered so that a lane's 4 registers run along the output's
 // contiguous axis (one 16-byte store per lane and tile): for the gx layout that is the chunk index b (rows = m, lane
 // column = n), for the row-major outputs it is n (operands swapped: rows = n, lane column = m).
-template <int EPI>
+template <int EPI, int DT>
 __device__ __forceinline__ void epilogue_tile16(const f32x4& acc, int mb, int nb, int c16, int q, int M, int N, const GemmEpi& ep, float* outp) {
     if (EPI == EPI_LSTM_GX) {
         const int n = nb + c16, m4 = mb + 4 * q;
@@ -445,12 +326,12 @@ __device__ __forceinline__ void epilogue_tile16(const f32x4& acc, int mb, int nb
                 bf16_t* o = (bf16_t*)outp + (size_t)m * ep.ldc + n4;
                 if (n4 + 4 <= N && ((uintptr_t)o & 7) == 0) {
                     uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    pk.x = (uint32_t)f32_to_h16<DT>(v[0]) | ((uint32_t)f32_to_h16<DT>(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_h16<DT>(v[2]) | ((uint32_t)f32_to_h16<DT>(v[3]) << 16);
                     *(uint2*)o = pk;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (n4 + j < N) o[j] = f32_to_bf16(v[j]);
+                    for (int j = 0; j < 4; ++j) if (n4 + j < N) o[j] = f32_to_h16<DT>(v[j]);
                 }
             } else {
                 float* o = outp + (size_t)m * ep.ldc + n4;
@@ -465,7 +346,7 @@ __device__ __forceinline__ void epilogue_tile16(const f32x4& acc, int mb, int nb
     }
 }
 
-template <int EPI>
+template <int EPI, int DT>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                        int M, int N, int K, GemmEpi ep) {
     constexpr bool SWAP = (EPI != EPI_LSTM_GX && EPI != EPI_LSTM_DH);      // see epilogue_tile16
@@ -520,8 +401,8 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict_
 #define GX_MFMA(I0)                                                                                            \
     _Pragma("unroll") for (int i_ = (I0); i_ < (I0) + 4; ++i_)                                                 \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                       \
-            acc[i_][j_] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j_], fa[i_], acc[i_][j_], 0, 0, 0) \
-                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i_], fb[j_], acc[i_][j_], 0, 0, 0);
+            acc[i_][j_] = SWAP ? mfma_16x16x32<DT>(fb[j_], fa[i_], acc[i_][j_]) \
+                               : mfma_16x16x32<DT>(fa[i_], fb[j_], acc[i_][j_]);
 #define GX_MID(I0)                                                                                             \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
     __builtin_amdgcn_s_barrier();                                                                              \
@@ -644,66 +525,79 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict_
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            epilogue_tile16<EPI>(acc[i][j], m0 + wm * 128 + i * 16, n0 + wn * 64 + j * 16, c16, q, M, N, ep, outp);
+            epilogue_tile16<EPI, DT>(acc[i][j], m0 + wm * 128 + i * 16, n0 + wn * 64 + j * 16, c16, q, M, N, ep, outp);
 }
 
-template <int EPI>
+template <int EPI, int DT>
 static int launch256(const bf16_t* a, int lda, const bf16_t* w, int ldw, int M, int N, int K, const GemmEpi& ep, hipStream_t st, int batch) {
     static bool attr_set = false;
-    // MT_GEMM_TILE=256 keeps the 32x32x16 kernel (A/B runs); the default is the 16x16x32 ping-pong kernel
-    static const bool old256 = getenv("MT_GEMM_TILE") && atoi(getenv("MT_GEMM_TILE")) == 256;
     if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256x_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256x_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
         attr_set = true;
     }
     dim3 grid(cdiv(N, BN2) * cdiv(M, BM2), 1, batch);
-    if (old256) hipLaunchKernelGGL(gemm256_kernel<EPI>, grid, dim3(512), G256_LDS, st, a, lda, w, ldw, M, N, K, ep);
-    else hipLaunchKernelGGL(gemm256x_kernel<EPI>, grid, dim3(512), G256_LDS, st, a, lda, w, ldw, M, N, K, ep);
+    hipLaunchKernelGGL((gemm256x_kernel<EPI, DT>), grid, dim3(512), G256_LDS, st, a, lda, w, ldw, M, N, K, ep);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
 
-static int launch(int epi, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st, int batch = 1) {
-    MT_REQUIRE(A && W && ep.out, MT_EINVAL, "gemm: null pointer");
-    MT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MT_EINVAL,
-               "gemm: bad dims M=%d N=%d K=%d lda=%d ldw=%d (K must be a multiple of %d)", M, N, K, lda, ldw, BK);
+template <int DT>
+static int launch_dt(int epi, const bf16_t* a, int lda, const bf16_t* w, int ldw, int M, int N, int K, const GemmEpi& ep, hipStream_t st, int batch) {
     dim3 grid(cdiv(N, BN) * cdiv(M, BM), 1, batch);
-    const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
     // big problems: the 256 x 256 tile (one workgroup per CU); MT_GEMM_TILE=128 in the environment keeps the small tile
     static const bool allow256 = !(getenv("MT_GEMM_TILE") && atoi(getenv("MT_GEMM_TILE")) == 128);
     if (allow256 && M >= 1024 && N >= 512 && N % 128 == 0 && (long long)cdiv(M, BM2) * cdiv(N, BN2) * batch >= 128) {
-        if (epi == EPI_ROWMAJOR) return launch256<EPI_ROWMAJOR>(a, lda, w, ldw, M, N, K, ep, st, batch);
-        if (epi == EPI_LSTM_GX) return launch256<EPI_LSTM_GX>(a, lda, w, ldw, M, N, K, ep, st, batch);
-        if (epi == EPI_ROWMAJOR_BF16) return launch256<EPI_ROWMAJOR_BF16>(a, lda, w, ldw, M, N, K, ep, st, batch);
-        if (epi == EPI_LSTM_DH) return launch256<EPI_LSTM_DH>(a, lda, w, ldw, M, N, K, ep, st, batch);
+        if (epi == EPI_ROWMAJOR) return launch256<EPI_ROWMAJOR, DT>(a, lda, w, ldw, M, N, K, ep, st, batch);
+        if (epi == EPI_LSTM_GX) return launch256<EPI_LSTM_GX, DT>(a, lda, w, ldw, M, N, K, ep, st, batch);
+        if (epi == EPI_ROWMAJOR_BF16) return launch256<EPI_ROWMAJOR_BF16, DT>(a, lda, w, ldw, M, N, K, ep, st, batch);
+        if (epi == EPI_LSTM_DH) return launch256<EPI_LSTM_DH, DT>(a, lda, w, ldw, M, N, K, ep, st, batch);
     }
-    if (epi == EPI_ROWMAJOR) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
-    else if (epi == EPI_LSTM_GX) hipLaunchKernelGGL(gemm_kernel<EPI_LSTM_GX>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
-    else if (epi == EPI_ROWMAJOR_BF16) hipLaunchKernelGGL(gemm_kernel<EPI_ROWMAJOR_BF16>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
-    else if (epi == EPI_LSTM_DH) hipLaunchKernelGGL(gemm_kernel<EPI_LSTM_DH>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
-    else hipLaunchKernelGGL(gemm_kernel<EPI_LOGITS>, grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
+    if (epi == EPI_ROWMAJOR) hipLaunchKernelGGL((gemm_kernel<EPI_ROWMAJOR, DT>), grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
+    else if (epi == EPI_LSTM_GX) hipLaunchKernelGGL((gemm_kernel<EPI_LSTM_GX, DT>), grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
+    else if (epi == EPI_ROWMAJOR_BF16) hipLaunchKernelGGL((gemm_kernel<EPI_ROWMAJOR_BF16, DT>), grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
+    else if (epi == EPI_LSTM_DH) hipLaunchKernelGGL((gemm_kernel<EPI_LSTM_DH, DT>), grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
+    else hipLaunchKernelGGL((gemm_kernel<EPI_LOGITS, DT>), grid, dim3(256), 0, st, a, lda, w, ldw, M, N, K, ep);
     MT_CHECK_LAUNCH();
     return MT_OK;
+}
+
+static int launch(int epi, int dt, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st, int batch = 1) {
+    MT_REQUIRE(A && W && ep.out, MT_EINVAL, "gemm: null pointer");
+    MT_REQUIRE_DT(dt, "gemm");
+    MT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MT_EINVAL,
+               "gemm: bad dims M=%d N=%d K=%d lda=%d ldw=%d (K must be a multiple of %d)", M, N, K, lda, ldw, BK);
+    const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
+    return dt == MT_DT_F16 ? launch_dt<MT_DT_F16>(epi, a, lda, w, ldw, M, N, K, ep, st, batch)
+                           : launch_dt<MT_DT_BF16>(epi, a, lda, w, ldw, M, N, K, ep, st, batch);
 }
 
 }  // namespace mt
 
 using namespace mt;
 
+// The `_dt` entry points take the operand type of A and W (and of a 16-bit output): MT_DT_BF16 or MT_DT_F16; the
+// un-suffixed names are the bf16 forms the training step uses.
+extern "C" int mt_gemm_f32acc_dt(const void* A, int lda, const void* W, int ldw, const float* bias,
+                                 float* C, int ldc, int M, int N, int K, int dt, mt_stream_t stream) {
+    MT_REQUIRE(ldc >= N, MT_EINVAL, "mt_gemm_f32acc: ldc < N");
+    GemmEpi ep{C, bias, ldc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+    return launch(EPI_ROWMAJOR, dt, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream);
+}
 extern "C" int mt_gemm_bf16_f32acc(const void* A, int lda, const void* W, int ldw, const float* bias,
                                    float* C, int ldc, int M, int N, int K, mt_stream_t stream) {
-    MT_REQUIRE(ldc >= N, MT_EINVAL, "mt_gemm_bf16_f32acc: ldc < N");
-    GemmEpi ep{C, bias, ldc, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
-    return launch(EPI_ROWMAJOR, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream);
+    return mt_gemm_f32acc_dt(A, lda, W, ldw, bias, C, ldc, M, N, K, MT_DT_BF16, stream);
 }
 
-extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
-                               int B, int T, int H, int K, mt_stream_t stream) {
+extern "C" int mt_gemm_lstm_gx_dt(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
+                                  int B, int T, int H, int K, int dt, mt_stream_t stream) {
     MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx: bias is required (b_ih + b_hh)");
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx: bad dims B=%d T=%d H=%d", B, T, H);
     GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1};
-    return launch(EPI_LSTM_GX, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream);
+    return launch(EPI_LSTM_GX, dt, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream);
+}
+extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
+                               int B, int T, int H, int K, mt_stream_t stream) {
+    return mt_gemm_lstm_gx_dt(X, ldx, W_ih, ldw, bias, gx, B, T, H, K, MT_DT_BF16, stream);
 }
 
 extern "C" int mt_gemm_lstm_dh(const void* dY, int ldy, const void* W, int ldw, float* dh, int B, int T, int H, int Hv, int K,
@@ -711,30 +605,44 @@ extern "C" int mt_gemm_lstm_dh(const void* dY, int ldy, const void* W, int ldw, 
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0 && Hv > 0 && Hv <= H && p >= 0.0f && p < 1.0f, MT_EINVAL,
                "mt_gemm_lstm_dh: bad dims B=%d T=%d H=%d Hv=%d p=%g", B, T, H, Hv, (double)p);
     GemmEpi ep{dh, nullptr, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1, Hv, p, seed, layer};
-    return launch(EPI_LSTM_DH, dY, ldy, W, ldw, T * B, 2 * Hv, K, ep, (hipStream_t)stream);
+    return launch(EPI_LSTM_DH, MT_DT_BF16, dY, ldy, W, ldw, T * B, 2 * Hv, K, ep, (hipStream_t)stream);
 }
 
-extern "C" int mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
-                              int B, int T, int N, int K, mt_stream_t stream) {
+extern "C" int mt_gemm_logits_dt(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
+                                 int B, int T, int N, int K, int dt, mt_stream_t stream) {
     MT_REQUIRE(B > 0 && T > 0 && N % MT_N_PITCH == 0, MT_EINVAL, "mt_gemm_logits: bad dims (N must be a multiple of 88)");
     GemmEpi ep{logits, bias, 0, B, T, 0, 0, 0, 0, 0, 0, 0, 0, 1};
-    return launch(EPI_LOGITS, X, ldx, W, ldw, T * B, N, K, ep, (hipStream_t)stream);
+    return launch(EPI_LOGITS, dt, X, ldx, W, ldw, T * B, N, K, ep, (hipStream_t)stream);
+}
+extern "C" int mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
+                              int B, int T, int N, int K, mt_stream_t stream) {
+    return mt_gemm_logits_dt(X, ldx, W, ldw, bias, logits, B, T, N, K, MT_DT_BF16, stream);
 }
 
 // Batched variants: batch index z -> (z / zdiv, z % zdiv), element offsets z1*stride1 + z2*stride2 on A, W and C
-// (zdiv = 1: a plain stride).  f32, or bf16 (+bias, optional ReLU), row-major output.
+// (zdiv = 1: a plain stride).  f32, or 16-bit (+bias, optional ReLU), row-major output.
+extern "C" int mt_gemm_batched_f32_dt(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw, long long sW1, long long sW2,
+                                      const float* bias, float* C, int ldc, long long sC1, long long sC2, int M, int N, int K,
+                                      int batch, int zdiv, int dt, mt_stream_t stream) {
+    MT_REQUIRE(ldc >= N && batch > 0 && zdiv > 0, MT_EINVAL, "mt_gemm_batched_f32: bad arguments");
+    GemmEpi ep{C, bias, ldc, 0, 0, 0, 0, sA1, sW1, sC1, sA2, sW2, sC2, zdiv};
+    return launch(EPI_ROWMAJOR, dt, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream, batch);
+}
 extern "C" int mt_gemm_batched_f32(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw, long long sW1, long long sW2,
                                    const float* bias, float* C, int ldc, long long sC1, long long sC2, int M, int N, int K,
                                    int batch, int zdiv, mt_stream_t stream) {
-    MT_REQUIRE(ldc >= N && batch > 0 && zdiv > 0, MT_EINVAL, "mt_gemm_batched_f32: bad arguments");
-    GemmEpi ep{C, bias, ldc, 0, 0, 0, 0, sA1, sW1, sC1, sA2, sW2, sC2, zdiv};
-    return launch(EPI_ROWMAJOR, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream, batch);
+    return mt_gemm_batched_f32_dt(A, lda, sA1, sA2, W, ldw, sW1, sW2, bias, C, ldc, sC1, sC2, M, N, K, batch, zdiv, MT_DT_BF16, stream);
 }
 
+extern "C" int mt_gemm_batched_h16out_dt(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw, long long sW1, long long sW2,
+                                         const float* bias, void* C, int ldc, long long sC1, long long sC2, int M, int N, int K,
+                                         int batch, int zdiv, int relu, int dt, mt_stream_t stream) {
+    MT_REQUIRE(ldc >= N && batch > 0 && zdiv > 0 && sC1 % 2 == 0 && sC2 % 2 == 0, MT_EINVAL, "mt_gemm_batched_h16out: bad arguments");
+    GemmEpi ep{(float*)C, bias, ldc, 0, 0, 0, relu, sA1, sW1, sC1, sA2, sW2, sC2, zdiv};
+    return launch(EPI_ROWMAJOR_BF16, dt, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream, batch);
+}
 extern "C" int mt_gemm_batched_bf16out(const void* A, int lda, long long sA1, long long sA2, const void* W, int ldw, long long sW1, long long sW2,
                                        const float* bias, void* C, int ldc, long long sC1, long long sC2, int M, int N, int K,
                                        int batch, int zdiv, int relu, mt_stream_t stream) {
-    MT_REQUIRE(ldc >= N && batch > 0 && zdiv > 0 && sC1 % 2 == 0 && sC2 % 2 == 0, MT_EINVAL, "mt_gemm_batched_bf16out: bad arguments");
-    GemmEpi ep{(float*)C, bias, ldc, 0, 0, 0, relu, sA1, sW1, sC1, sA2, sW2, sC2, zdiv};
-    return launch(EPI_ROWMAJOR_BF16, A, lda, W, ldw, M, N, K, ep, (hipStream_t)stream, batch);
+    return mt_gemm_batched_h16out_dt(A, lda, sA1, sA2, W, ldw, sW1, sW2, bias, C, ldc, sC1, sC2, M, N, K, batch, zdiv, relu, MT_DT_BF16, stream);
 }

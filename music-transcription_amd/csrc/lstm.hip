@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
 // H = layout hidden size (multiple of 16), Hv <= H = real hidden size (units >= Hv are zero padding and are
 // dropped), col_off = first column of this LSTM's features in a concatenated row.  Optionally also writes
 // the value as fp32 to Y (residual / LayerNorm input of the Large model).
+template <int DT>
 __global__ void lstm_relayout_kernel(const f16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, float* __restrict__ Y, int ldy,
                                      int col_off, int B, int T, int H, int Hv) {
     const int nkb = H >> 3, nkv = (Hv + 7) >> 3;
@@ -540,11 +541,13 @@ __global__ void lstm_relayout_kernel(const f16_t* __restrict__ hx, bf16_t* __res
         const int c0 = col_off + d * Hv + kb * 8;
         const f16x8 h8 = *(const f16x8*)src;
         if (X) {
-            if ((c0 & 7) == 0 && kb * 8 + 8 <= Hv) {
+            if (DT == MT_DT_F16 && (c0 & 7) == 0 && kb * 8 + 8 <= Hv) {
+                *(f16x8*)(X + m * ldx + c0) = h8;                    // the exchanged h is f16 already: a plain copy
+            } else if ((c0 & 7) == 0 && kb * 8 + 8 <= Hv) {
                 *(uint4*)(X + m * ldx + c0) = make_uint4(pack_bf16x2((float)h8[0], (float)h8[1]), pack_bf16x2((float)h8[2], (float)h8[3]),
                                                          pack_bf16x2((float)h8[4], (float)h8[5]), pack_bf16x2((float)h8[6], (float)h8[7]));
             } else {
-                for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) X[m * ldx + c0 + j] = f32_to_bf16((float)h8[j]);
+                for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) X[m * ldx + c0 + j] = f32_to_h16<DT>((float)h8[j]);
             }
         }
         if (Y)
@@ -685,16 +688,25 @@ extern "C" int mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* h
     return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, mode, stream);
 }
 
-extern "C" int mt_lstm_relayout_ex(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off, int B, int T, int H, int Hv,
-                                   mt_stream_t stream) {
+extern "C" int mt_lstm_relayout_dt(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off, int B, int T, int H, int Hv,
+                                   int dt, mt_stream_t stream) {
     MT_REQUIRE(hx && (X || Y) && H % 16 == 0 && Hv > 0 && Hv <= H && col_off >= 0, MT_EINVAL, "mt_lstm_relayout_ex: bad arguments");
     MT_REQUIRE((!X || (ldx >= col_off + 2 * Hv && ldx % 8 == 0)) && (!Y || ldy >= col_off + 2 * Hv), MT_EINVAL, "mt_lstm_relayout_ex: bad leading dimension");
+    MT_REQUIRE_DT(dt, "mt_lstm_relayout");
     const size_t total = (size_t)T * B * 2 * ((Hv + 7) >> 3);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(lstm_relayout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, Y, ldy,
-                       col_off, B, T, H, Hv);
+    if (dt == MT_DT_F16)
+        hipLaunchKernelGGL(lstm_relayout_kernel<MT_DT_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, Y, ldy,
+                           col_off, B, T, H, Hv);
+    else
+        hipLaunchKernelGGL(lstm_relayout_kernel<MT_DT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, Y, ldy,
+                           col_off, B, T, H, Hv);
     MT_CHECK_LAUNCH();
     return MT_OK;
+}
+extern "C" int mt_lstm_relayout_ex(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off, int B, int T, int H, int Hv,
+                                   mt_stream_t stream) {
+    return mt_lstm_relayout_dt(hx, X, ldx, Y, ldy, col_off, B, T, H, Hv, MT_DT_BF16, stream);
 }
 
 extern "C" int mt_lstm_relayout_bf16(const float* hx, void* X, int ldx, int B, int T, int H, mt_stream_t stream) {

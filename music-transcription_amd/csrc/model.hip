@@ -5,12 +5,12 @@
 #include "mt_common.h"
 
 extern "C" {
-int mt_conv1_bn_relu_pool(const float*, const float*, const float*, const float*, void*, int, int, int, mt_stream_t);
-int mt_conv2_bn_relu_pool(const void*, const void*, const float*, void*, int, int, int, int, mt_stream_t);
-int mt_gemm_lstm_gx(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
-int mt_gemm_logits(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
+int mt_conv1_bn_relu_pool_dt(const float*, const float*, const float*, const float*, void*, int, int, int, int, mt_stream_t);
+int mt_conv2_bn_relu_pool_dt(const void*, const void*, const float*, void*, int, int, int, int, int, mt_stream_t);
+int mt_gemm_lstm_gx_dt(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
+int mt_gemm_logits_dt(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
-int mt_lstm_relayout_ex(const float*, void*, int, float*, int, int, int, int, int, int, mt_stream_t);
+int mt_lstm_relayout_dt(const float*, void*, int, float*, int, int, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 size_t mt_lstm_gx_bytes(int, int, int);
 size_t mt_lstm_hx_bytes(int, int, int);
@@ -50,6 +50,7 @@ static int check_weights(const mt_cnnrnn_weights* w) {
     MT_REQUIRE(w->n_mels >= 4 && w->layers >= 1 && w->layers <= MT_MAX_LSTM_LAYERS, MT_EINVAL,
                "cnnrnn: bad config n_mels=%d layers=%d", w->n_mels, w->layers);
     MT_REQUIRE(w->hidden >= 1 && w->hidden <= 1024, MT_EUNSUPPORTED, "cnnrnn: hidden size %d unsupported (1..1024)", w->hidden);
+    MT_REQUIRE_DT(w->operand_dtype, "cnnrnn");
     MT_REQUIRE(w->conv1_w && w->conv1_b && w->conv2_w && w->conv2_b && w->fc_w && w->fc_b, MT_EINVAL, "cnnrnn: null weight pointer");
     for (int l = 0; l < w->layers; ++l)
         MT_REQUIRE(w->w_ih[l] && w->b_gates[l] && w->w_hh[l], MT_EINVAL, "cnnrnn: null LSTM weight pointer (layer %d)", l);
@@ -89,13 +90,13 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
     const CnnRnnPlan p = plan(w, B, T);
     MT_REQUIRE(workspace_bytes >= p.total, MT_EWORKSPACE, "mt_cnnrnn_forward: workspace %zu < %zu bytes", workspace_bytes, p.total);
     char* ws = (char*)workspace;
-    const int H = p.Hp, Hv = w->hidden;
+    const int H = p.Hp, Hv = w->hidden, dt = w->operand_dtype;
     hipStream_t st = (hipStream_t)stream;
     int ei = 0;
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;                      // event 0: start
-    if ((rc = mt_conv1_bn_relu_pool(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, stream)) != MT_OK) return rc;
+    if ((rc = mt_conv1_bn_relu_pool_dt(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, dt, stream)) != MT_OK) return rc;
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
-    if ((rc = mt_conv2_bn_relu_pool(ws + p.act1, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, p.F1, T, stream)) != MT_OK) return rc;
+    if ((rc = mt_conv2_bn_relu_pool_dt(ws + p.act1, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, p.F1, T, dt, stream)) != MT_OK) return rc;
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     if (p.K1 != 2 * Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, (hipStream_t)stream));
     char* hcur = ws + p.hx;                  // the previous layer's output images
@@ -112,7 +113,7 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
         } else {
             const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
             const int K = l == 0 ? p.K0 : p.K1;
-            if ((rc = mt_gemm_lstm_gx(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, stream)) != MT_OK) return rc;
+            if ((rc = mt_gemm_lstm_gx_dt(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, dt, stream)) != MT_OK) return rc;
             if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
             if ((rc = mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * l,
                                            p.sync_stride, B, T, H, w->lstm_mode, stream)) != MT_OK) return rc;
@@ -121,10 +122,10 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
         // the next consumer of feature ROWS: a GEMM-projected layer, or the final fc
         const bool next_fused = !last && w->w_ihx[l + 1] && w->lstm_mode == 0 && H <= 512;
         if (!next_fused)
-            if ((rc = mt_lstm_relayout_ex((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, H, Hv, stream)) != MT_OK) return rc;
+            if ((rc = mt_lstm_relayout_dt((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, H, Hv, dt, stream)) != MT_OK) return rc;
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     }
-    if ((rc = mt_gemm_logits(ws + p.x1, p.K1, w->fc_w, p.K1, w->fc_b, logits, B, T, MT_N_PITCH, p.K1, stream)) != MT_OK) return rc;
+    if ((rc = mt_gemm_logits_dt(ws + p.x1, p.K1, w->fc_w, p.K1, w->fc_b, logits, B, T, MT_N_PITCH, p.K1, dt, stream)) != MT_OK) return rc;
     return rec(events, n_events, ei, st);
 }
 

@@ -7,20 +7,20 @@
 #include "mt_common.h"
 
 extern "C" {
-int mt_conv1_bn_relu_pool(const float*, const float*, const float*, const float*, void*, int, int, int, mt_stream_t);
-int mt_conv_cl_bf16(const void*, const void*, const void*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, mt_stream_t);
-int mt_gemm_lstm_gx(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
-int mt_gemm_logits(const void*, int, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
-int mt_gemm_batched_f32(const void*, int, long long, long long, const void*, int, long long, long long, const float*, float*, int,
-                        long long, long long, int, int, int, int, int, mt_stream_t);
-int mt_gemm_batched_bf16out(const void*, int, long long, long long, const void*, int, long long, long long, const float*, void*, int,
-                            long long, long long, int, int, int, int, int, int, mt_stream_t);
+int mt_conv1_bn_relu_pool_dt(const float*, const float*, const float*, const float*, void*, int, int, int, int, mt_stream_t);
+int mt_conv_cl_dt(const void*, const void*, const void*, const float*, void*, int, int, int, int, int, int, int, int, int, int, int, int, mt_stream_t);
+int mt_gemm_lstm_gx_dt(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
+int mt_gemm_logits_dt(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
+int mt_gemm_batched_f32_dt(const void*, int, long long, long long, const void*, int, long long, long long, const float*, float*, int,
+                           long long, long long, int, int, int, int, int, int, mt_stream_t);
+int mt_gemm_batched_h16out_dt(const void*, int, long long, long long, const void*, int, long long, long long, const float*, void*, int,
+                              long long, long long, int, int, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
-int mt_lstm_relayout_ex(const float*, void*, int, float*, int, int, int, int, int, int, mt_stream_t);
+int mt_lstm_relayout_dt(const float*, void*, int, float*, int, int, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
-int mt_attn_softmax_clamped(const float*, int, void*, int, int, long long, float, float, mt_stream_t);
+int mt_attn_softmax_clamped_dt(const float*, int, void*, int, int, long long, float, float, int, mt_stream_t);
 int mt_attn_transpose_v(const void*, int, int, void*, int, int, int, int, int, mt_stream_t);
-int mt_layernorm_residual(const float*, int, const float*, int, const float*, const float*, void*, int, long long, int, float, mt_stream_t);
+int mt_layernorm_residual_dt(const float*, int, const float*, int, const float*, const float*, void*, int, long long, int, float, int, mt_stream_t);
 size_t mt_lstm_gx_bytes(int, int, int);
 size_t mt_lstm_hx_bytes(int, int, int);
 size_t mt_lstm_sync_bytes(int, int);
@@ -82,6 +82,7 @@ static int check_large(const mt_cnnrnn_large_weights* w) {
     MT_REQUIRE(w->n_mels >= 8 && w->layers >= 1 && w->layers <= MT_MAX_LSTM_LAYERS && w->hidden >= 1 && w->hidden <= 1024 &&
                w->hidden_local >= 1 && w->hidden_local <= 1024, MT_EUNSUPPORTED, "cnnrnn_large: unsupported config");
     MT_REQUIRE(!w->use_attention || (w->heads > 0 && w->head_dim_pad > 0 && w->head_dim_pad % 64 == 0), MT_EINVAL, "cnnrnn_large: bad attention dims");
+    MT_REQUIRE_DT(w->operand_dtype, "cnnrnn_large");
     MT_REQUIRE(2 * w->hidden + 2 * w->hidden_local <= 2048, MT_EUNSUPPORTED, "cnnrnn_large: combined feature size > 2048");
     return MT_OK;
 }
@@ -111,14 +112,14 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
     MT_REQUIRE(workspace_bytes >= p.total, MT_EWORKSPACE, "mt_cnnrnn_large_forward: workspace %zu < %zu bytes", workspace_bytes, p.total);
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    const int Hv = w->hidden, Hl = w->hidden_local;
+    const int Hv = w->hidden, Hl = w->hidden_local, dt = w->operand_dtype;
     // ---- CNN
-    RUN(mt_conv1_bn_relu_pool(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, stream));
-    RUN(mt_conv_cl_bf16(ws + p.act1, nullptr, w->rb1c1_w, w->rb1c1_b, ws + p.r1a, B, p.F1, T, 32, 0, 64, 3, 1, 0, 0, 0, stream));
-    RUN(mt_conv_cl_bf16(ws + p.r1a, ws + p.act1, w->rb1c2_w, w->rb1c2_b, ws + p.r1, B, p.F1, T, 64, 32, 64, 3, 1, 1, 0, 0, stream));
-    RUN(mt_conv_cl_bf16(ws + p.r1, nullptr, w->rb2c1_w, w->rb2c1_b, ws + p.r2a, B, p.F2, T, 64, 0, 128, 3, 1, 0, 0, 0, stream));
-    RUN(mt_conv_cl_bf16(ws + p.r2a, ws + p.r1, w->rb2c2_w, w->rb2c2_b, ws + p.r2, B, p.F2, T, 128, 64, 128, 3, 1, 0, 0, 0, stream));
-    RUN(mt_conv_cl_bf16(ws + p.r2, nullptr, w->fa_w, w->fa_b, ws + p.x0, B, p.F2, T, 128, 0, 256, 7, 1, 1, 1, p.K0, stream));
+    RUN(mt_conv1_bn_relu_pool_dt(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, dt, stream));
+    RUN(mt_conv_cl_dt(ws + p.act1, nullptr, w->rb1c1_w, w->rb1c1_b, ws + p.r1a, B, p.F1, T, 32, 0, 64, 3, 1, 0, 0, 0, dt, stream));
+    RUN(mt_conv_cl_dt(ws + p.r1a, ws + p.act1, w->rb1c2_w, w->rb1c2_b, ws + p.r1, B, p.F1, T, 64, 32, 64, 3, 1, 1, 0, 0, dt, stream));
+    RUN(mt_conv_cl_dt(ws + p.r1, nullptr, w->rb2c1_w, w->rb2c1_b, ws + p.r2a, B, p.F2, T, 64, 0, 128, 3, 1, 0, 0, 0, dt, stream));
+    RUN(mt_conv_cl_dt(ws + p.r2a, ws + p.r1, w->rb2c2_w, w->rb2c2_b, ws + p.r2, B, p.F2, T, 128, 64, 128, 3, 1, 0, 0, 0, dt, stream));
+    RUN(mt_conv_cl_dt(ws + p.r2, nullptr, w->fa_w, w->fa_b, ws + p.x0, B, p.F2, T, 128, 0, 256, 7, 1, 1, 1, p.K0, dt, stream));
     // ---- concatenated feature rows: bf16 GEMM operand (zero pad columns) + fp32 copy for the residual
     if (p.Cp != p.comb) MT_CHECK_HIP(hipMemsetAsync(ws + p.rb, 0, (size_t)p.Mpad * p.Cp * 2, st));
     if (p.K1 != 2 * Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, st));
@@ -129,9 +130,9 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
         MT_CHECK_HIP(hipEventRecord((hipEvent_t)ev_fork, st));
         MT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, (hipEvent_t)ev_fork, 0));
     }
-    RUN(mt_gemm_lstm_gx(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, ls));
+    RUN(mt_gemm_lstm_gx_dt(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, dt, ls));
     RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode, ls));
-    RUN(mt_lstm_relayout_ex((const float*)(ws + p.hx2), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, ls));
+    RUN(mt_lstm_relayout_dt((const float*)(ws + p.hx2), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, dt, ls));
     if (fork) MT_CHECK_HIP(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)side_stream));
     // main LSTM; layers > 0 with a packed W_ihx take their input projection inside the recurrence (no GEMM, no re-layout)
     char* hcur = ws + p.hx;
@@ -146,43 +147,43 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
         } else {
             const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
             const int K = l == 0 ? p.K0 : p.K1;
-            RUN(mt_gemm_lstm_gx(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, stream));
+            RUN(mt_gemm_lstm_gx_dt(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, dt, stream));
             RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * (l + 1),
                                   p.sync_stride, B, T, p.Hp, w->lstm_mode, stream));
         }
         const bool next_fused = !last && w->main_w_ihx[l + 1] && w->lstm_mode == 0 && p.Hp <= 512;
-        if (last) RUN(mt_lstm_relayout_ex((const float*)hcur, ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, stream));
-        else if (!next_fused) RUN(mt_lstm_relayout_ex((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, stream));
+        if (last) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, dt, stream));
+        else if (!next_fused) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, dt, stream));
     }
     if (fork) MT_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0));      // both column ranges of rb / r32 are complete
     const void* feat = ws + p.rb;            // [Mpad][Cp] bf16
     if (w->use_attention) {
         const int heads = w->heads, dp = p.dp;
         // qkv projection (rows up to Tr*B are readable as padding of the per-head GEMMs below)
-        RUN(mt_gemm_batched_bf16out(ws + p.rb, p.Cp, 0, 0, w->qkv_w, p.Cp, 0, 0, w->qkv_b, ws + p.qkv, p.ld3, 0, 0, p.M, p.ld3, p.Cp, 1, 1, 0, stream));
+        RUN(mt_gemm_batched_h16out_dt(ws + p.rb, p.Cp, 0, 0, w->qkv_w, p.Cp, 0, 0, w->qkv_b, ws + p.qkv, p.ld3, 0, 0, p.M, p.ld3, p.Cp, 1, 1, 0, dt, stream));
         const bf16_t* qkv = (const bf16_t*)(ws + p.qkv);
         // S[b][head] = Q K^T : A rows t -> qkv row t*B+b (lda = B*ld3), batch z = b*heads + head
-        RUN(mt_gemm_batched_f32(qkv, B * p.ld3, p.ld3, dp, qkv + p.Ca, B * p.ld3, p.ld3, dp, nullptr, (float*)(ws + p.S), p.Tp,
-                                (long long)heads * T * p.Tp, (long long)T * p.Tp, T, T, dp, B * heads, heads, stream));
-        RUN(mt_attn_softmax_clamped((const float*)(ws + p.S), p.Tp, ws + p.P, p.Tp, T, (long long)B * heads * T, w->attn_scale, 10.0f, stream));
+        RUN(mt_gemm_batched_f32_dt(qkv, B * p.ld3, p.ld3, dp, qkv + p.Ca, B * p.ld3, p.ld3, dp, nullptr, (float*)(ws + p.S), p.Tp,
+                                (long long)heads * T * p.Tp, (long long)T * p.Tp, T, T, dp, B * heads, heads, dt, stream));
+        RUN(mt_attn_softmax_clamped_dt((const float*)(ws + p.S), p.Tp, ws + p.P, p.Tp, T, (long long)B * heads * T, w->attn_scale, 10.0f, dt, stream));
         // P is [B*heads][T][Tp]; the PV GEMM may read A rows up to roundup(T,128) of a head, i.e. into the next head's
         // rows (or the buffer's tail, sized for it): those rows only feed masked outputs.
         RUN(mt_attn_transpose_v(qkv, p.ld3, 2 * p.Ca, ws + p.VT, B, T, p.Tp, heads, dp, stream));
-        RUN(mt_gemm_batched_bf16out(ws + p.P, p.Tp, (long long)heads * T * p.Tp, (long long)T * p.Tp, ws + p.VT, p.Tp,
+        RUN(mt_gemm_batched_h16out_dt(ws + p.P, p.Tp, (long long)heads * T * p.Tp, (long long)T * p.Tp, ws + p.VT, p.Tp,
                                     (long long)heads * align_up((size_t)dp, 128) * p.Tp, (long long)align_up((size_t)dp, 128) * p.Tp, nullptr,
-                                    ws + p.ao, B * p.Ca, p.Ca, dp, T, dp, p.Tp, B * heads, heads, 0, stream));
-        RUN(mt_gemm_batched_f32(ws + p.ao, p.Ca, 0, 0, w->proj_w, p.Ca, 0, 0, w->proj_b, (float*)(ws + p.proj), p.comb, 0, 0, p.M, p.comb, p.Ca, 1, 1, stream));
+                                    ws + p.ao, B * p.Ca, p.Ca, dp, T, dp, p.Tp, B * heads, heads, 0, dt, stream));
+        RUN(mt_gemm_batched_f32_dt(ws + p.ao, p.Ca, 0, 0, w->proj_w, p.Ca, 0, 0, w->proj_b, (float*)(ws + p.proj), p.comb, 0, 0, p.M, p.comb, p.Ca, 1, 1, dt, stream));
         if (p.Cp != p.comb) MT_CHECK_HIP(hipMemsetAsync(ws + p.ln, 0, (size_t)p.Mpad * p.Cp * 2, st));
-        RUN(mt_layernorm_residual((const float*)(ws + p.r32), p.comb, (const float*)(ws + p.proj), p.comb, w->ln_g, w->ln_b, ws + p.ln, p.Cp,
-                                  p.M, p.comb, 1e-6f, stream));
+        RUN(mt_layernorm_residual_dt((const float*)(ws + p.r32), p.comb, (const float*)(ws + p.proj), p.comb, w->ln_g, w->ln_b, ws + p.ln, p.Cp,
+                                  p.M, p.comb, 1e-6f, dt, stream));
         feat = ws + p.ln;
     }
     if (w->use_heads) {
         if (p.Hs != Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.sh, 0, (size_t)p.Mpad * p.Hs * 2, st));
-        RUN(mt_gemm_batched_bf16out(feat, p.Cp, 0, 0, w->shared_w, p.Cp, 0, 0, w->shared_b, ws + p.sh, p.Hs, 0, 0, p.M, Hv, p.Cp, 1, 1, 1, stream));
-        return mt_gemm_logits(ws + p.sh, p.Hs, w->heads_w, p.Hs, w->heads_b, logits3, B, T, 3 * MT_N_PITCH, p.Hs, stream);
+        RUN(mt_gemm_batched_h16out_dt(feat, p.Cp, 0, 0, w->shared_w, p.Cp, 0, 0, w->shared_b, ws + p.sh, p.Hs, 0, 0, p.M, Hv, p.Cp, 1, 1, 1, dt, stream));
+        return mt_gemm_logits_dt(ws + p.sh, p.Hs, w->heads_w, p.Hs, w->heads_b, logits3, B, T, 3 * MT_N_PITCH, p.Hs, dt, stream);
     }
-    return mt_gemm_logits(feat, p.Cp, w->fc_w, p.Cp, w->fc_b, logits3, B, T, MT_N_PITCH, p.Cp, stream);
+    return mt_gemm_logits_dt(feat, p.Cp, w->fc_w, p.Cp, w->fc_b, logits3, B, T, MT_N_PITCH, p.Cp, dt, stream);
 }
 
 extern "C" int mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,

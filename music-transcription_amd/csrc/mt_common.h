@@ -59,4 +59,30 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;  // f16 MFMA A/B fra
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+// ---- 16-bit GEMM / conv operand type (MT_DT_BF16 | MT_DT_F16, include/mt_hip.h).  Both run on the same MFMA rate;
+// f16 carries 11 significand bits against bf16's 8 (inference activations and weights are far inside its range: the
+// conversion saturates at +-65504 instead of producing an infinity), bf16 keeps f32's exponent range (training:
+// gradients).  Storage is always raw 16-bit words (bf16_t / bf16x8): the type only selects the conversion and the
+// MFMA opcode.
+template <int DT> __device__ __forceinline__ bf16_t f32_to_h16(float f) {
+    if (DT == MT_DT_F16) {
+        const f16_t h = (f16_t)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);     // NaN stays NaN through v_med3 + v_cvt
+        return __builtin_bit_cast(unsigned short, h);
+    }
+    return f32_to_bf16(f);
+}
+template <int DT> __device__ __forceinline__ float h16_to_f32(bf16_t v) {
+    if (DT == MT_DT_F16) return (float)__builtin_bit_cast(f16_t, v);
+    return bf16_to_f32(v);
+}
+template <int DT> __device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if (DT == MT_DT_F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <int DT> __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    if (DT == MT_DT_F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+#define MT_REQUIRE_DT(dt, who) MT_REQUIRE((dt) == MT_DT_BF16 || (dt) == MT_DT_F16, MT_EINVAL, who ": operand dtype must be MT_DT_BF16 or MT_DT_F16")
+
 }  // namespace mt

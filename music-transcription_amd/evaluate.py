@@ -42,6 +42,9 @@ def collect_logits(model, dataset, indices: Sequence[int], device="cuda", max_ba
             logits = model(mel)
             for (i, _, roll), lg in zip(grp, logits):
                 out.append((i, lg.contiguous(), roll.to(device).float().contiguous()))
+    net = getattr(model, "model", model)
+    if hasattr(net, "raise_on_handoff_timeout"):
+        net.raise_on_handoff_timeout(sync=True)        # a timed-out recurrence would have left NaN logits: fail loudly, once per pass
     out.sort(key=lambda x: x[0])
     return out
 

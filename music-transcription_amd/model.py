@@ -69,13 +69,31 @@ def _bf16(t):
     return t.to(torch.bfloat16).contiguous()
 
 
+def operand_dtype(model=None) -> int:
+    """16-bit operand type of the inference GEMM / conv kernels (MT_DT_*): f16 by default -- 11 significand bits against
+    bf16's 8 at the same MFMA rate, which is what keeps the logits (and the framewise F1) on the fp32 reference's
+    (tests/test_gpu_f1_parity.py).  `model.operand_dtype = "bf16"` or MT_OPERAND_DTYPE=bf16 select
+    bf16 (A/B comparisons).  The training step always runs bf16 (train_step.py)."""
+    v = os.environ.get("MT_OPERAND_DTYPE") or getattr(model, "operand_dtype", "f16")
+    if v not in ("f16", "bf16"):
+        raise ValueError(f"operand dtype must be 'f16' or 'bf16', got {v!r}")
+    return _lib.DT_F16 if v == "f16" else _lib.DT_BF16
+
+
+def _h16(t, dt: int):
+    """f32 -> the 16-bit operand type (f16 saturates instead of overflowing, like the kernels' conversion)."""
+    if dt == _lib.DT_F16:
+        return t.clamp(-65504.0, 65504.0).to(torch.float16).contiguous()
+    return t.to(torch.bfloat16).contiguous()
+
+
 def _pad2(t, rows, cols):
     out = torch.zeros(rows, cols, dtype=t.dtype)
     out[:t.shape[0], :t.shape[1]] = t
     return out
 
 
-def _pack_bilstm(rnn: nn.LSTM, layers: int, H: int, k0_cols, dev):
+def _pack_bilstm(rnn: nn.LSTM, layers: int, H: int, k0_cols, dev, dt: int = _lib.DT_BF16):
     """Pack a bidirectional nn.LSTM for mt_gemm_lstm_gx + mt_lstm_bidir_fwd (computed on `dev`: the training
     step re-packs after every optimizer step).  The hidden size is laid out padded to Hp = roundup(H, 16): a
     padded unit has zero weights and bias, so its gates are 0 and its c, h stay 0.  Gate row p*Hp + j;
@@ -99,7 +117,7 @@ def _pack_bilstm(rnn: nn.LSTM, layers: int, H: int, k0_cols, dev):
             b = (getattr(rnn, f"bias_ih_l{l}{suf}") + getattr(rnn, f"bias_hh_l{l}{suf}")).detach().to(dev, torch.float32)
             bcat[di, :, :H] = b.reshape(4, H)
             hcat[di, :, :H, :H] = getattr(rnn, f"weight_hh_l{l}{suf}").detach().to(dev, torch.float32).reshape(4, H, H)
-        w_ih.append(wcat.to(torch.bfloat16))
+        w_ih.append(_h16(wcat, dt))
         b_g.append(bcat.reshape(-1).contiguous())
         w_hh.append(hcat.reshape(2, 4 * Hp, Hp).contiguous())
     return w_ih, b_g, w_hh
@@ -113,12 +131,55 @@ class _HipForward:
         return (WEIGHTS_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
 
     def _ensure_packed(self, device):
-        sig = (str(device), self._param_signature())
+        sig = (str(device), operand_dtype(self), self._param_signature())
         if getattr(self, "_pack_sig", None) != sig:
             self._packed = self._pack(device)
             self._pack_sig = sig
             self._ws = {}
         return self._packed
+
+    # ---- hand-off status of the persistent recurrence launches (csrc/lstm.hip): every spin is bounded and reports
+    #      through a status word per layer; a timed-out layer leaves NaN poison in its output, so whoever syncs checks.
+    def _status_offsets(self, B, T):
+        raise NotImplementedError
+
+    def raise_on_handoff_timeout(self, B=None, T=None, sync: bool = True):
+        """Raises MtError if a recurrence hand-off spin of any forward issued so far hit its bound.  sync=False: the
+        caller has already synchronised with the forwards it cares about (e.g. by copying their result to the host);
+        the check then costs one 4-byte-per-layer copy."""
+        if not getattr(self, "_ws", None):
+            return
+        if sync:
+            torch.cuda.synchronize()
+        words, names = [], []
+        for key, ws in self._ws.items():
+            if (B is not None and key[0] != B) or (T is not None and key[1] != T):
+                continue
+            offs = self._status_offsets(key[0], key[1])
+            idx = torch.tensor([o // 4 for _, o in offs], dtype=torch.int64, device=ws.device)
+            words.append(ws.view(torch.int32)[idx])
+            names += [n for n, _ in offs]
+        if not words:
+            return
+        vals = torch.cat(words).cpu().tolist()
+        for n, st in zip(names, vals):
+            if st != 0:
+                kind = "payload" if st & 0x40000000 else "flag"
+                raise _lib.MtError(f"LSTM {n}: inter-workgroup hand-off ({kind} spin) timed out at step {(st & 0x3fffffff) - (0 if st & 0x40000000 else 1)}: "
+                                   "the launch was not fully resident (too many persistent launches in flight on this GPU?)")
+
+    def _check_inflight_bound(self, key, bound, what):
+        """Co-residency rule of the persistent recurrence kernels: at most `bound` forwards of this
+        model in flight per GPU, i.e. at most `bound` caller streams."""
+        streams = {k[2] for k in self._ws} | {key[2]}
+        if len(streams) > bound:                       # forget the streams that have drained: nothing of theirs is in flight
+            for k in list(self._ws):
+                if k[2] != key[2] and torch.cuda.ExternalStream(k[2], device=self._ws[k].device).query():
+                    self._ws.pop(k)
+            streams = {k[2] for k in self._ws} | {key[2]}
+        if len(streams) > bound:
+            raise _lib.MtError(f"{what}: {len(streams)} caller streams > {bound}: the persistent recurrence launches of that many "
+                               "forwards cannot all be resident on one GPU (they would stall on each other)")
 
     @staticmethod
     def _require_cuda(x):
@@ -149,15 +210,16 @@ class CNNRNNModel(nn.Module, _HipForward):
         if L > _lib.MAX_LSTM_LAYERS:
             raise NotImplementedError(f"num_layers={L} > {_lib.MAX_LSTM_LAYERS}")
         dev = dict(device=device)
+        dt = operand_dtype(self)
         w1, b1 = _fold_bn(self.cnn[0].weight, self.cnn[0].bias, self.cnn[1])
         w2, b2 = _fold_bn(self.cnn[4].weight, self.cnn[4].bias, self.cnn[5])
         t = {"conv1_w": w1.reshape(32, 9).contiguous().to(**dev), "conv1_b": b1.contiguous().to(**dev),
-             "conv2_w": _bf16(w2.permute(0, 2, 3, 1).reshape(64, 9, 32)).to(**dev),   # [co][tap][ci]
+             "conv2_w": _h16(w2.permute(0, 2, 3, 1).reshape(64, 9, 32), dt).to(**dev),   # [co][tap][ci]
              "conv2_b": b2.contiguous().to(**dev)}
         K1 = _round_up(2 * H, 64)
         # reference feature index c*Fo2+f (cnn_rnn_model.py:60-62) -> kernel column f*64+c
         cols = (torch.arange(64)[None, :] * Fo2 + torch.arange(Fo2)[:, None]).reshape(-1)
-        wi, bg, wh = _pack_bilstm(self.rnn, L, H, cols, device)
+        wi, bg, wh = _pack_bilstm(self.rnn, L, H, cols, device, dt)
         for l in range(L):
             t[f"w_ih{l}"], t[f"b_g{l}"], t[f"w_hh{l}"] = wi[l], bg[l], wh[l]
         # layers > 0: W_ih in the layout of the fused input projection (mt_lstm_bidir_fwd_xproj): f32 [2][4Hp][2Hp],
@@ -171,10 +233,10 @@ class CNNRNNModel(nn.Module, _HipForward):
             t[f"w_ihx{l}"] = wx.reshape(2, 4 * Hp, 2 * Hp).contiguous()
         fw = torch.zeros(128, K1)
         fw[:88, :2 * H] = self.fc.weight.detach().float().cpu()
-        t["fc_w"] = _bf16(fw).to(**dev)
+        t["fc_w"] = _h16(fw, dt).to(**dev)
         t["fc_b"] = self.fc.bias.detach().float().contiguous().to(**dev)
         w = CnnRnnWeights()
-        w.n_mels, w.hidden, w.layers = self.n_mels, H, L
+        w.n_mels, w.hidden, w.layers, w.operand_dtype = self.n_mels, H, L, dt
         w.conv1_w, w.conv1_b, w.conv2_w, w.conv2_b = (ptr(t[k]) for k in ("conv1_w", "conv1_b", "conv2_w", "conv2_b"))
         for l in range(L):
             w.w_ih[l], w.b_gates[l], w.w_hh[l] = ptr(t[f"w_ih{l}"]), ptr(t[f"b_g{l}"]), ptr(t[f"w_hh{l}"])
@@ -204,7 +266,10 @@ class CNNRNNModel(nn.Module, _HipForward):
         logits = torch.empty(B, self.output_dim, T, dtype=torch.float32, device=x.device)
         # one workspace per (shape, stream): forwards issued on different streams may overlap on the GPU
         key = (B, T, torch.cuda.current_stream(x.device).cuda_stream)
+        env = os.environ.get("MT_LSTM_XPROJ")
+        fuse = (env == "1") if env in ("0", "1") else bool(getattr(self, "fuse_input_projection", False))
         if key not in self._ws:
+            self._check_inflight_bound(key, 3 if fuse else 6, "CNNRNNModel.forward")
             nbytes = lib.mt_cnnrnn_workspace_bytes(w, B, T)
             if nbytes == 0:
                 raise _lib.MtError("mt_cnnrnn_workspace_bytes: " + _lib.last_error())
@@ -223,8 +288,6 @@ class CNNRNNModel(nn.Module, _HipForward):
         # flight, a gain with several (the GEMMs are the shared resource then) -- so the caller decides.  MT_LSTM_XPROJ=0/1 forces it.
         # A fused recurrence workgroup fills a CU's register file (one per CU, 256 per GPU = two launches): keep at most THREE
         # forwards of this model in flight per GPU with it (see bench.py), at most six without.
-        env = os.environ.get("MT_LSTM_XPROJ")
-        fuse = (env == "1") if env in ("0", "1") else bool(getattr(self, "fuse_input_projection", False))
         for l in range(1, self.num_layers):
             w.w_ihx[l] = ptr(pk["tensors"][f"w_ihx{l}"]) if (fuse and self.hidden_size <= 512) else None
         with torch.cuda.device(x.device):
@@ -234,18 +297,9 @@ class CNNRNNModel(nn.Module, _HipForward):
             self.raise_on_handoff_timeout(B, T)
         return logits
 
-    def raise_on_handoff_timeout(self, B, T):
-        """Synchronises; raises if a recurrence hand-off spin hit its bound (see csrc/lstm.hip)."""
+    def _status_offsets(self, B, T):
         w = self._packed["struct"]
-        torch.cuda.synchronize()
-        for key, ws in self._ws.items():
-            if key[:2] != (B, T):
-                continue
-            for l in range(self.num_layers):
-                off = lib.mt_cnnrnn_status_offset(w, B, T, l)
-                st = int(ws[off:off + 4].view(torch.int32).item())
-                if st != 0:
-                    raise _lib.MtError(f"LSTM layer {l}: inter-workgroup hand-off timed out at step {st - 1}")
+        return [(f"layer {l}", lib.mt_cnnrnn_status_offset(w, B, T, l)) for l in range(self.num_layers)]
 
 
 class CNNRNNModelLarge(nn.Module, _HipForward):
@@ -316,6 +370,7 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
 
         w = CnnRnnLargeWeights()
         w.n_mels, w.hidden, w.layers, w.hidden_local = self.n_mels, H, L, Hl
+        dt = w.operand_dtype = operand_dtype(self)
         w.use_attention, w.use_heads = int(self.use_attention), int(self.use_onset_offset_heads)
         w1, b1 = _fold_bn(self.conv1[0].weight, self.conv1[0].bias, self.conv1[1])
         w.conv1_w, w.conv1_b = put("conv1_w", w1.reshape(32, 9)), put("conv1_b", b1)
@@ -327,15 +382,15 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
                 wsk = wsk.reshape(wsk.shape[0], -1)
             else:           # identity skip == 1x1 conv with the identity matrix (exact in bf16)
                 wsk, bsk = torch.eye(wb.shape[0]), torch.zeros(wb.shape[0])
-            setattr(w, name + "c1_w", put(name + "c1_w", _bf16(conv_cl(wa))))
+            setattr(w, name + "c1_w", put(name + "c1_w", _h16(conv_cl(wa), dt)))
             setattr(w, name + "c1_b", put(name + "c1_b", ba))
-            setattr(w, name + "c2_w", put(name + "c2_w", _bf16(torch.cat([conv_cl(wb), wsk], 1))))
+            setattr(w, name + "c2_w", put(name + "c2_w", _h16(torch.cat([conv_cl(wb), wsk], 1), dt)))
             setattr(w, name + "c2_b", put(name + "c2_b", bb + bsk))
         wf, bf_ = _fold_bn(self.freq_aware_conv[0].weight, self.freq_aware_conv[0].bias, self.freq_aware_conv[1])
-        w.fa_w, w.fa_b = put("fa_w", _bf16(conv_cl(wf))), put("fa_b", bf_)
+        w.fa_w, w.fa_b = put("fa_w", _h16(conv_cl(wf), dt)), put("fa_b", bf_)
         # reference feature index c*F3+f (cnn_rnn_model.py:292-294) -> kernel column f*256+c
         cols = (torch.arange(256)[None, :] * F3 + torch.arange(F3)[:, None]).reshape(-1)
-        wi, bg, wh = _pack_bilstm(self.rnn_main, L, H, cols, device)
+        wi, bg, wh = _pack_bilstm(self.rnn_main, L, H, cols, device, dt)
         Hp = _round_up(H, 16)
         for l in range(L):
             t[f"m_wi{l}"], t[f"m_b{l}"], t[f"m_wh{l}"] = wi[l], bg[l], wh[l]
@@ -346,7 +401,7 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
                 for di, suf in enumerate(("", "_reverse")):
                     wx[di, :, :H, :, :H] = getattr(self.rnn_main, f"weight_ih_l{l}{suf}").detach().to(device, torch.float32).reshape(4, H, 2, H)
                 t[f"m_wix{l}"] = wx.reshape(2, 4 * Hp, 2 * Hp).contiguous()
-        wi, bg, wh = _pack_bilstm(self.rnn_local, 1, Hl, cols, device)
+        wi, bg, wh = _pack_bilstm(self.rnn_local, 1, Hl, cols, device, dt)
         t["l_wi"], t["l_b"], t["l_wh"] = wi[0], bg[0], wh[0]
         w.local_w_ih, w.local_b, w.local_w_hh = ptr(wi[0]), ptr(bg[0]), ptr(wh[0])
         if self.use_attention:
@@ -358,23 +413,23 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
             qb = self.attention.qkv.bias.detach().float().cpu().reshape(3, heads, d)
             qwp = torch.zeros(3, heads, dp, Cp); qwp[:, :, :d, :comb] = qw
             qbp = torch.zeros(3, heads, dp); qbp[:, :, :d] = qb
-            w.qkv_w = put("qkv_w", _bf16(_pad2(qwp.reshape(3 * Ca, Cp), _round_up(3 * Ca, 128), Cp)))
+            w.qkv_w = put("qkv_w", _h16(_pad2(qwp.reshape(3 * Ca, Cp), _round_up(3 * Ca, 128), Cp), dt))
             w.qkv_b = put("qkv_b", qbp.reshape(-1))
             pw = self.attention.proj.weight.detach().float().cpu().reshape(comb, heads, d)
             pwp = torch.zeros(comb, heads, dp); pwp[:, :, :d] = pw
-            w.proj_w = put("proj_w", _bf16(_pad2(pwp.reshape(comb, Ca), _round_up(comb, 128), Ca)))
+            w.proj_w = put("proj_w", _h16(_pad2(pwp.reshape(comb, Ca), _round_up(comb, 128), Ca), dt))
             w.proj_b = put("proj_b", self.attention.proj.bias.detach().float().cpu())
             w.ln_g = put("ln_g", self.attention_norm.weight.detach().float().cpu())
             w.ln_b = put("ln_b", self.attention_norm.bias.detach().float().cpu())
         if self.use_onset_offset_heads:
             Hs = _round_up(H, 64)
-            w.shared_w = put("shared_w", _bf16(_pad2(self.shared_fc.weight.detach().float().cpu(), _round_up(H, 128), Cp)))
+            w.shared_w = put("shared_w", _h16(_pad2(self.shared_fc.weight.detach().float().cpu(), _round_up(H, 128), Cp), dt))
             w.shared_b = put("shared_b", self.shared_fc.bias.detach().float().cpu())
             hw = torch.cat([m.weight.detach().float().cpu() for m in (self.frame_head, self.onset_head, self.offset_head)], 0)
             hb = torch.cat([m.bias.detach().float().cpu() for m in (self.frame_head, self.onset_head, self.offset_head)], 0)
-            w.heads_w, w.heads_b = put("heads_w", _bf16(_pad2(hw, 384, Hs))), put("heads_b", hb)
+            w.heads_w, w.heads_b = put("heads_w", _h16(_pad2(hw, 384, Hs), dt)), put("heads_b", hb)
         else:
-            w.fc_w = put("fc_w", _bf16(_pad2(self.fc.weight.detach().float().cpu(), 128, Cp)))
+            w.fc_w = put("fc_w", _h16(_pad2(self.fc.weight.detach().float().cpu(), 128, Cp), dt))
             w.fc_b = put("fc_b", self.fc.bias.detach().float().cpu())
         return {"tensors": t, "struct": w}
 
@@ -396,6 +451,7 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
         out = torch.empty(3 if heads_out else 1, B, self.output_dim, T, dtype=torch.float32, device=x.device)
         key = (B, T, torch.cuda.current_stream(x.device).cuda_stream)
         if key not in self._ws:
+            self._check_inflight_bound(key, 3, "CNNRNNModelLarge.forward")      # main + local recurrence per forward
             nbytes = lib.mt_cnnrnn_large_workspace_bytes(w, B, T)
             if nbytes == 0:
                 raise _lib.MtError("mt_cnnrnn_large_workspace_bytes: " + _lib.last_error())
@@ -429,17 +485,10 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
             return {"frame": out[0], "onset": out[1], "offset": out[2]}
         return out[0]
 
-    def raise_on_handoff_timeout(self, B, T):
+    def _status_offsets(self, B, T):
         w = self._packed["struct"]
-        torch.cuda.synchronize()
-        for key, ws in self._ws.items():
-            if key[:2] != (B, T):
-                continue
-            for i in range(self.num_layers + 1):
-                off = lib.mt_cnnrnn_large_status_offset(w, B, T, i)
-                st = int(ws[off:off + 4].view(torch.int32).item())
-                if st != 0:
-                    raise _lib.MtError(f"LSTM {'local' if i == 0 else 'main layer %d' % (i - 1)}: hand-off timed out (status {st:#x})")
+        return [("local" if i == 0 else f"main layer {i - 1}", lib.mt_cnnrnn_large_status_offset(w, B, T, i))
+                for i in range(self.num_layers + 1)]
 
 
 class TranscriptionModel(nn.Module):

@@ -191,6 +191,7 @@ def transcribe_chunks(model: TranscriptionModel, chunks, threshold: float = THRE
         logits = net(mel, chunk_max_power=cmax)
         roll = ops.predict_from_logits(logits, threshold)                      # (b, 88, T)
         rolls.append(roll.permute(1, 0, 2).reshape(88, -1).cpu().numpy())      # combine_piano_rolls: concat along time
+        net.raise_on_handoff_timeout(sync=False)       # (the copy above synchronised with this batch's forward)
     return np.concatenate(rolls, axis=1)
 
 

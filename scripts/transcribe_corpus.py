@@ -127,6 +127,7 @@ def main():
         L = min(ref.shape[1], roll.shape[1])
         f1s.append(mta.framewise_f1(roll[None, :, :L].contiguous(), ref[None, :, :L].contiguous())[0])
     torch.cuda.synchronize()
+    model.model.raise_on_handoff_timeout(sync=False)     # a timed-out recurrence leaves NaN logits = all-zero rolls: fail loudly
     if world > 1:
         dist.barrier()
     wall = time.perf_counter() - t0

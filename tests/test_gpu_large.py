@@ -98,7 +98,7 @@ def test_large_small_configs_vs_reference_golden(mta, golden_dir, tag):
     with torch.no_grad():
         got = model(x.cuda(), return_all_heads=True)
         model.model.raise_on_handoff_timeout(B, T)
-        emu = R.cnnrnn_large_forward(sd, x, return_all_heads=True, o=R.Opts(gemm_bf16=True))
+        emu = R.cnnrnn_large_forward(sd, x, return_all_heads=True, o=R.Opts(gemm_f16=True))
         frame_only = model(x.cuda())
     assert torch.equal(frame_only, got["frame"])
     for k in ("frame", "onset", "offset"):

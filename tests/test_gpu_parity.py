@@ -152,7 +152,7 @@ def test_cnnrnn_small_vs_reference_golden(mta, golden_dir, tag):
     x = _mel_in(B, nm, T, xseed)
     with torch.no_grad():
         got = model.model(x.cuda(), check_status=True).cpu()
-        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_bf16=True))
+        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_f16=True))
     golden = torch.from_numpy(z[f"{tag}_logits"])
     assert got.shape == golden.shape
     assert (got - emu).abs().max().item() < 2e-3          # same bf16 input rounding: only fp32 ordering differs
@@ -409,9 +409,10 @@ def test_fused_input_projection_matches_goldens(mta, golden_dir, tag):
         plain = model.model(x.cuda(), check_status=True).cpu()
         model.model.fuse_input_projection = True
         fused = model.model(x.cuda(), check_status=True).cpu()
-        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_bf16=True))
-    assert not torch.equal(plain, fused)                                  # a different code path ...
-    assert (fused - plain).abs().max().item() < 2e-3                      # ... with the same answer
+        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_f16=True))
+    # a different code path with the same answer (with f16 operands both paths multiply the same values; the f16
+    # rounding of every published h absorbs the f32 summation-order noise, so they often agree bit for bit)
+    assert (fused - plain).abs().max().item() < 2e-3
     assert (fused - emu).abs().max().item() < 2e-3
     assert np.abs(fused.numpy() - z[f"{tag}_logits"]).max() < 3e-2
 
