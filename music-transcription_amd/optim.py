@@ -28,12 +28,15 @@ def flatten_parameters(params: Iterable[torch.nn.Parameter]):
     flat = torch.empty(n, dtype=torch.float32, device=dev)
     grads = torch.zeros(n, dtype=torch.float32, device=dev)
     o = 0
+    views = []
     for p in params:
         k = p.numel()
         flat[o:o + k].copy_(p.detach().reshape(-1))
         p.data = flat[o:o + k].view_as(p)
         p.grad = grads[o:o + k].view_as(p)
+        views.append((p, o, k))
         o += k
+    grads._mt_views = views          # FusedAdamClip.step() re-attaches p.grad views a caller has detached
     return flat, grads
 
 
@@ -56,14 +59,38 @@ class FusedAdamClip:
         self.p, self.g = flat_params, flat_grads
         self.m, self.v = torch.zeros_like(flat_params), torch.zeros_like(flat_params)
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
-        self.t = 0
+        self.t = 0                    # steps actually taken (a skipped step does not advance it: unskip())
+        self._views = getattr(flat_grads, "_mt_views", None)
         self.ws = torch.empty(lib.mt_adam_workspace_bytes(), dtype=torch.uint8, device=flat_params.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=flat_params.device)
 
     def zero_grad(self):
         self.g.zero_()
 
+    def _reattach_grad_views(self):
+        """`model.zero_grad()` (set_to_none=True, as the reference's loop calls it) or an assignment to p.grad detaches a
+        parameter from the flat gradient buffer; autograd then accumulates into a fresh tensor the fused step would never
+        see.  Fold such gradients back into the flat buffer and restore the views."""
+        if not self._views:
+            return
+        base = self.g.data_ptr()
+        for p, o, k in self._views:
+            view = self.g[o:o + k].view_as(p)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != base + 4 * o:
+                view.copy_(p.grad)
+            else:
+                continue
+            p.grad = view
+
+    def unskip(self):
+        """The device skipped the last step (non-finite gradient norm, stats[1] == 0): torch's Adam would not have been
+        called at all (train/train_transcriber.py:137-142), so its step count must not advance either."""
+        self.t = max(0, self.t - 1)
+
     def step(self, sync_grads: bool = True):
+        self._reattach_grad_views()
         if sync_grads:
             allreduce_mean_(self.g)
         self.t += 1

@@ -13,8 +13,13 @@ import math
 from typing import Iterable, List, Tuple
 
 import torch
+import torch.distributed as dist
 
 from .optim import FusedAdamClip, flatten_parameters
+
+
+def _world_size() -> int:
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
 def make_optimizer(model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-5,
@@ -40,15 +45,26 @@ def train_one_epoch(model, dataloader: Iterable, optimizer: FusedAdamClip, devic
         logits = model(mel)
         loss = model.compute_loss(logits, roll, lengths)
         step_loss = float(loss.item())
-        if math.isnan(step_loss) or math.isinf(step_loss):
+        bad = math.isnan(step_loss) or math.isinf(step_loss)
+        if _world_size() > 1:
+            # Data parallel: the skip must be COLLECTIVE.  optimizer.step() holds the gradient all-reduce, so a rank that
+            # skipped alone would leave the others waiting in it: every rank skips when any rank's loss is non-finite.
+            flag = torch.tensor([1.0 if bad else 0.0], device=loss.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            bad = bool(flag.item() > 0.0)
+        if bad:
             nan_count += 1
             if nan_count > 10:
                 raise RuntimeError("Too many NaN losses - training unstable!")
             continue
         loss.backward()
         stats = optimizer.step().tolist()              # {grad norm before clipping, 1.0 if the step was taken}
-        if stats[1] == 0.0:                            # non-finite gradient norm: step skipped on the device
-            nan_count += 1
+        net = getattr(model, "model", model)
+        if hasattr(net, "raise_on_train_handoff_timeout"):
+            net.raise_on_train_handoff_timeout()       # (the .tolist() above synchronised with the whole step)
+        if stats[1] == 0.0:                            # non-finite gradient norm (identical on every rank: it is taken after
+            nan_count += 1                             # the all-reduce): step skipped on the device, Adam's step count not advanced
+            optimizer.unskip()
             continue
         total += step_loss
         step_losses.append(step_loss)

@@ -4,7 +4,7 @@ train_one_epoch (train/train_transcriber.py:90-158) run on CPU in this container
 
     python tests/golden/make_golden_train.py        # needs /root/reference (build container only)
 
-Writes tests/golden/train_step.npz:
+Writes tests/golden/train_step.npz (CNNRNNModel) and tests/golden/train_step_large.npz (CNNRNNModelLarge):
   * cfg, seeds                       -- everything needed to regenerate weights (oracle.make_state_dict) and inputs
   * logits0, loss0, gradnorm0        -- train-mode forward / masked loss / global grad norm of step 1
   * grad::<key>                      -- every parameter's gradient of step 1 (before clipping)
@@ -32,6 +32,8 @@ from tests.golden.make_golden import mel_input, roll_input  # noqa: E402
 torch.set_num_threads(8)
 
 CFG = dict(n_mels=32, hidden=16, layers=2, B=3, T=40, seed_w=21, seed_x=31, lr=1e-4, n_batches=3)
+MODEL_TYPE = "cnn_rnn"
+OUT_NAME = "train_step.npz"
 
 
 def batches():
@@ -49,10 +51,15 @@ def batches():
 
 def fresh_model():
     from models.transcription_model import TranscriptionModel
-    m = TranscriptionModel(model_type="cnn_rnn", n_mels=CFG["n_mels"], hidden_size=CFG["hidden"],
+    m = TranscriptionModel(model_type=MODEL_TYPE, n_mels=CFG["n_mels"], hidden_size=CFG["hidden"],
                            num_layers=CFG["layers"], dropout=0.0, device="cpu")
-    sd = model_ref.make_state_dict("cnn_rnn", CFG["n_mels"], CFG["hidden"], CFG["layers"], CFG["seed_w"])
+    sd = model_ref.make_state_dict(MODEL_TYPE, CFG["n_mels"], CFG["hidden"], CFG["layers"], CFG["seed_w"])
     m.load_state_dict(sd, strict=True)
+    # CNNRNNModelLarge hard-codes its spatial dropouts (cnn_rnn_model.py:188,:192,:202); the golden step is
+    # deterministic, so their probabilities are configured to 0 like every other dropout (dropout=0.0 above)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout2d):
+            mod.p = 0.0
     return m
 
 
@@ -75,10 +82,10 @@ def main():
     loss.backward()
     out["logits0"] = logits.detach().numpy()
     out["loss0"] = np.array(loss.item())
-    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None))
     out["gradnorm0"] = np.array(gn.item())
-    for k, p in m.named_parameters():
-        out["grad::" + k] = p.grad.detach().numpy()
+    for k, p in m.named_parameters():                     # (the Large model's onset / offset heads get no gradient
+        out["grad::" + k] = (p.grad.detach() if p.grad is not None else torch.zeros_like(p)).numpy()   # from the reference's loop)
     for k, v in m.state_dict().items():
         if "running_" in k or "num_batches" in k:
             out["bn0::" + k] = v.detach().numpy()
@@ -91,9 +98,13 @@ def main():
     out["avg_loss"] = np.array(avg)
     for k, v in m.state_dict().items():
         out["post::" + k] = v.detach().numpy()
-    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **out)
-    print("train_step.npz: loss0 %.6f gradnorm0 %.4f losses %s" % (out["loss0"], out["gradnorm0"], losses))
+    np.savez_compressed(os.path.join(HERE, OUT_NAME), **out)
+    print("%s: loss0 %.6f gradnorm0 %.4f losses %s" % (OUT_NAME, out["loss0"], out["gradnorm0"], losses))
 
 
 if __name__ == "__main__":
+    main()
+    # the same through CNNRNNModelLarge (what the reference's canonical pipeline trains: example.sh:22)
+    MODEL_TYPE, OUT_NAME = "cnn_rnn_large", "train_step_large.npz"
+    CFG = dict(n_mels=32, hidden=16, layers=2, B=3, T=40, seed_w=23, seed_x=41, lr=1e-4, n_batches=3)
     main()

@@ -149,10 +149,11 @@ def test_manifest_key_names(golden_dir):
     assert man["cnn_rnn_large:320:512:3"]["n_params"] == 89494088
 
 
-def test_oracle_training_step_pinned_by_reference_golden(golden_dir):
+@pytest.mark.parametrize("model_type,fname", [("cnn_rnn", "train_step.npz"), ("cnn_rnn_large", "train_step_large.npz")])
+def test_oracle_training_step_pinned_by_reference_golden(golden_dir, model_type, fname):
     """oracle.model_ref.train_steps (train-mode forward, autograd, clip, Adam) against the REFERENCE's own gradients,
-    losses and post-step weights (tests/golden/train_step.npz, written by make_golden_train.py)."""
-    g = np.load(os.path.join(golden_dir, "train_step.npz"))
+    losses and post-step weights (tests/golden/train_step*.npz, written by make_golden_train.py)."""
+    g = np.load(os.path.join(golden_dir, fname))
     nm, H, L, B, T, sw, sx, nb = [int(v) for v in g["cfg"]]
 
     def mel_in(seed):
@@ -170,16 +171,19 @@ def test_oracle_training_step_pinned_by_reference_golden(golden_dir):
             mel[b, :, :, lengths[b]:] = 0.0
             roll[b, :, lengths[b]:] = 0.0
         data.append((mel, roll, lengths))
-    sd = R.make_state_dict("cnn_rnn", nm, H, L, sw)
-    losses, grads, gn, logits0 = R.train_steps(sd, data, lr=float(g["lr"]))
-    assert np.abs(np.array(losses) - g["losses"]).max() < 1e-6
-    assert abs(gn - float(g["gradnorm0"])) < 1e-6
+    sd = R.make_state_dict(model_type, nm, H, L, sw)
+    losses, grads, gn, logits0 = R.train_steps(sd, data, lr=float(g["lr"]), model_type=model_type)
+    assert np.abs(np.array(losses) - g["losses"]).max() < 2e-6
+    assert abs(gn - float(g["gradnorm0"])) < 5e-6 * max(1.0, float(g["gradnorm0"]))      # (the golden's norm is a float64 sum)
     assert np.abs(logits0.numpy() - g["logits0"]).max() < 1e-5
     for k, v in grads.items():
-        assert np.abs(v.numpy() - g["grad::" + k]).max() < 1e-7, k
+        assert np.abs(v.numpy() - g["grad::" + k]).max() < 2e-7 * max(1.0, float(np.abs(g["grad::" + k]).max())), k
     for k, v in sd.items():
         if not v.dtype.is_floating_point:
             assert int(v) == int(g["post::" + k]), k
             continue
-        tol = 3.5e-4 if k.endswith("cnn.0.bias") or k.endswith("cnn.4.bias") else 5e-6   # zero-gradient biases: Adam amplifies rounding noise
+        # conv biases in front of a BatchNorm have an analytically zero gradient: Adam amplifies their rounding noise
+        zero_grad_bias = k.endswith(".bias") and any(t in k for t in ("cnn.0.", "cnn.4.", "conv1.0.", ".conv1.bias", ".conv2.bias", "skip.0.", "freq_aware_conv.0."))
+        # (three Adam steps of lr 1e-4 move a weight by up to 3e-4; entries whose gradient is ~0 amplify rounding noise)
+        tol = 3.5e-4 if zero_grad_bias else (5e-6 if model_type == "cnn_rnn" else 2e-5)
         assert np.abs(v.numpy() - g["post::" + k]).max() < tol, k
