@@ -418,6 +418,75 @@ int    mt_lstm_hprev_t(const float* hx, void* HT, long long ld, int rows_per_dir
 int    mt_dlogits_pack(const float* dlogits, void* dL, void* dLT, long long ldt, int B, int P, int T,
                        mt_stream_t stream);
 
+/* ------------------------------------------------------------------ training step of CNNRNNModelLarge
+ * The pieces between the dense contractions of `loss.backward()` for models/cnn_rnn_model.py:262-348 in train mode
+ * (train/train_transcriber.py:104-131), orchestrated by music-transcription_amd/train_step_large.py.  All 16-bit
+ * tensors are bf16.                                                                                                  */
+/* mask[b*C + c] = keep ? 1/(1-p) : 0 -- nn.Dropout2d (cnn_rnn_model.py:188,:192,:202) zeroes whole channels of a sample. */
+int    mt_dropout2d_mask(float* mask, int B, int C, float p, unsigned seed, unsigned layer, mt_stream_t stream);
+/* out = Dropout2d(MaxPool2d((2,1))(ReLU(BN_a(za) [+ BN_b(zb)]))) with BATCH statistics (mean / rstd from mt_bn_finalize):
+ * ResidualBlock.forward (cnn_rnn_model.py:93-99: zb = the 1x1 skip branch, no pool / pool1 behind res_block1) and
+ * freq_aware_conv (:196-201).  za, zb [B][F][T][C] raw conv outputs (zb, mask2d may be NULL; relu, pool flags);
+ * out_mode 0: [B][Fo][T][C], 1: GEMM-A rows X[(t*B+b)*ldx + fo*C + c].  C in {32, 64, 128, 256}.                   */
+int    mt_bn_act_fwd(const void* za, const float* mean_a, const float* rstd_a, const float* gamma_a, const float* beta_a,
+                     const void* zb, const float* mean_b, const float* rstd_b, const float* gamma_b, const float* beta_b,
+                     const float* mask2d, void* out, int out_mode, int ldx, int B, int F, int T, int C, int relu, int pool,
+                     mt_stream_t stream);
+/* Backward of mt_bn_act_fwd.  Gradient of the output: dout_cl (bf16 [B][Fo][T][ldd_cl]) or dout_x (f32 GEMM-row
+ * layout, ldd_x) -- exactly one.  Outputs: dza [B][F][T][pitch_a] (+ optional second bf16 piece dza_lo), dzb
+ * [B][F][T][pitch_b] (when zb), parameter gradients (any may be NULL).  sums: 3*C doubles of scratch.
+ * Pool ties route to the first row, as nn.MaxPool2d does.                                                           */
+int    mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_x, int ldd_x,
+                     const void* za, const float* mean_a, const float* rstd_a, const float* gamma_a, const float* beta_a,
+                     const void* zb, const float* mean_b, const float* rstd_b, const float* gamma_b, const float* beta_b,
+                     const float* mask2d, double* sums, void* dza, int pitch_a, void* dza_lo, void* dzb, int pitch_b,
+                     float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
+                     int B, int F, int T, int C, int relu, int pool, mt_stream_t stream);
+/* Channels-last -> zero-padded position-major planes: dst[c*ld + (b*(F+2ph) + f+ph)*Tp + t + toff] = src[((b*F+f)*T+t)*pitch + c]
+ * (dst pre-zeroed by the caller).  With the gradient plane (toff = 1) and three activation planes (toff = 2, 1, 0 for
+ * kernel columns kw = 0, 1, 2) the weight gradient of a KH x 3 convolution is, per kw, one batched NT GEMM over the
+ * positions: tap kh is the pointer offset (kh - ph)*Tp into the activation plane, Tp % 8 == 0.                       */
+int    mt_cl_to_planar(const void* src, int pitch, int C, void* dst, long long ld, int B, int F, int T, int ph, int Tp,
+                       int toff, mt_stream_t stream);
+/* General form of mt_conv_cl_dt: A / S are channel slices (pitchA / pitchS elements between positions) and accum != 0
+ * adds the result to `out` -- the input gradient of freq_aware_conv (256 output channels) is two calls.              */
+int    mt_conv_cl_ex(const void* A, int pitchA, const void* S, int pitchS, const void* W, const float* bias, void* out,
+                     int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,
+                     int accum, int dt, mt_stream_t stream);
+int    mt_transpose_bf16_batched(const void* src, long long lds, long long sstride, int R, int C, void* dst, long long ldd,
+                                 long long dstride, int Cd, int batch, mt_stream_t stream);
+/* MultiHeadAttention in train mode (cnn_rnn_model.py:128-133): Pd = dropout_p(softmax(clamp(S*scale, +-clip))) as the
+ * bf16 GEMM operand; backward through dropout, softmax and clamp (no gradient where |S*scale| > clip):
+ * dPd f32 [rows][ldp] -> dS bf16 [rows][Tp].  P is recomputed from S.                                               */
+int    mt_attn_softmax_train(const float* S, int lds, void* P, int Tp, int T, long long rows, float scale, float clip,
+                             float p, unsigned seed, unsigned layer, mt_stream_t stream);
+int    mt_attn_clamped_bwd(const float* S, int lds, const float* dPd, int ldp, void* dS, int Tp, int T, long long rows,
+                           float scale, float clip, float p, unsigned seed, unsigned layer, mt_stream_t stream);
+/* LayerNorm(resid + proj) (cnn_rnn_model.py:322) with saved statistics stats[row] = {mean, rstd}, and its backward:
+ * dy f32 -> dx f32 (the gradient of resid AND of proj); part = [mt_layernorm_residual_bwd_slices()][2][n] partial
+ * column sums (row 0: dgamma, row 1: dbeta) for mt_sum_slices_f32.                                                  */
+int    mt_layernorm_residual_train(const float* resid, int ldr, const float* proj, int ldp, const float* gamma,
+                                   const float* beta, void* y, int ldy, float* stats, long long rows, int n, float eps,
+                                   mt_stream_t stream);
+int    mt_layernorm_residual_bwd_slices(void);
+int    mt_layernorm_residual_bwd(const float* resid, int ldr, const float* proj, int ldp, const float* gamma,
+                                 const float* stats, const float* dy, int ldd, float* dx, int ldx, float* part,
+                                 long long rows, int n, mt_stream_t stream);
+/* shared_fc backward through Dropout(ReLU(.)) given the layer's OUTPUT Y: dZ = (Y > 0) ? dY / (1-p) : 0 (bf16).      */
+int    mt_heads_relu_dropout_bwd(const float* dY, int ldd, const void* Y, int ldy, void* dZ, int ldz, long long M, int N,
+                                 float p, mt_stream_t stream);
+/* dlogits f32 [NH][B][P][T] (frame / onset / offset heads) -> dL[(t*B+b)*ldl + head*P + p], dLT[(head*P+p)*ldt + t*B+b] bf16
+ * (entries beyond NH*P are not written: the caller zeroes the buffers).                                             */
+int    mt_dlogits_pack_heads(const float* dlogits, void* dL, int ldl, void* dLT, long long ldt, int NH, int B, int P, int T,
+                             mt_stream_t stream);
+/* Element-wise helpers: f32 rows -> bf16 GEMM operand (scaled); in-place inverted dropout (counter-based hash of the
+ * element index m*N + n, or i); out = alpha*a + beta*b over rows.                                                   */
+int    mt_f32_to_bf16_rows(const float* src, int lds, void* dst, int ldd, long long M, int N, float alpha, mt_stream_t stream);
+int    mt_dropout_bf16_rows(void* X, int ld, long long M, int N, float p, unsigned seed, unsigned layer, mt_stream_t stream);
+int    mt_dropout_f32(float* x, long long n, float p, unsigned seed, unsigned layer, mt_stream_t stream);
+int    mt_axpby_rows_f32(const float* a, int lda, const float* b, int ldb, float* out, int ldo, long long M, int N,
+                         float alpha, float beta, mt_stream_t stream);
+
 /* ------------------------------------------------------------------ audio decode
  * PCM frames -> mono float at the target rate, replacing the host side of librosa.load(path, sr=16000, mono=True)
  * (main.py:76, data/dataset.py:124-130): channel mean + polyphase FIR, y[j] = sum_i x[i] h[(j+n_pre_remove)*down - i*up]

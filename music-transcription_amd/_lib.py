@@ -148,6 +148,23 @@ _SIGS = {
     "mt_lstm_dg_unpack": (i32, [vp, vp, i32, vp, ll, i32, i32, i32, vp]),
     "mt_lstm_hprev_t": (i32, [vp, vp, ll, i32, i32, i32, i32, vp]),
     "mt_dlogits_pack": (i32, [vp, vp, vp, ll, i32, i32, i32, vp]),
+    "mt_dropout2d_mask": (i32, [vp, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),
+    "mt_bn_act_fwd": (i32, [vp] * 12 + [i32] * 8 + [vp]),
+    "mt_bn_act_bwd": (i32, [vp, i32, vp, i32] + [vp] * 13 + [i32, vp, vp, i32] + [vp] * 4 + [i32] * 6 + [vp]),
+    "mt_cl_to_planar": (i32, [vp, i32, i32, vp, ll, i32, i32, i32, i32, i32, i32, vp]),
+    "mt_conv_cl_ex": (i32, [vp, i32, vp, i32, vp, vp, vp] + [i32] * 13 + [vp]),
+    "mt_transpose_bf16_batched": (i32, [vp, ll, ll, i32, i32, vp, ll, ll, i32, i32, vp]),
+    "mt_attn_softmax_train": (i32, [vp, i32, vp, i32, i32, ll, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_uint, vp]),
+    "mt_attn_clamped_bwd": (i32, [vp, i32, vp, i32, vp, i32, i32, ll, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_uint, vp]),
+    "mt_layernorm_residual_train": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, vp, ll, i32, C.c_float, vp]),
+    "mt_layernorm_residual_bwd_slices": (i32, []),
+    "mt_layernorm_residual_bwd": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, ll, i32, vp]),
+    "mt_heads_relu_dropout_bwd": (i32, [vp, i32, vp, i32, vp, i32, ll, i32, C.c_float, vp]),
+    "mt_dlogits_pack_heads": (i32, [vp, vp, i32, vp, ll, i32, i32, i32, i32, vp]),
+    "mt_f32_to_bf16_rows": (i32, [vp, i32, vp, i32, ll, i32, C.c_float, vp]),
+    "mt_dropout_bf16_rows": (i32, [vp, i32, ll, i32, C.c_float, C.c_uint, C.c_uint, vp]),
+    "mt_dropout_f32": (i32, [vp, ll, C.c_float, C.c_uint, C.c_uint, vp]),
+    "mt_axpby_rows_f32": (i32, [vp, i32, vp, i32, vp, i32, ll, i32, C.c_float, C.c_float, vp]),
     "mt_resample_poly": (i32, [vp, ll, i32, i32, vp, i32, i32, i32, ll, vp, ll, vp]),
     "mt_cnnrnn_workspace_bytes": (sz, [C.POINTER(CnnRnnWeights), i32, i32]),
     "mt_cnnrnn_status_offset": (sz, [C.POINTER(CnnRnnWeights), i32, i32, i32]),

@@ -29,6 +29,8 @@ struct ConvGArgs {
     const float* bias;    // [Cout]
     bf16_t* out;
     int B, F, T, C1, C2, Cout, KH, relu, ldx;
+    int pitchA, pitchS;   // elements between consecutive positions of A / S (>= C1 / C2: a channel slice of a wider tensor)
+    int accum;            // != 0: out += result (the output is read back and the sum stored)
 };
 
 constexpr int CG_TF = 16, CG_TT = 16;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
         const int ch = id % nc1, pos = id / nc1, col = pos % 18, row = pos / 18;
         const int f = f0 - ph + row, t = t0 - 1 + col;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (f >= 0 && f < a.F && t >= 0 && t < a.T) v = *(const uint4*)(a.A + (((size_t)b * a.F + f) * a.T + t) * C1 + ch * 8);
+        if (f >= 0 && f < a.F && t >= 0 && t < a.T) v = *(const uint4*)(a.A + (((size_t)b * a.F + f) * a.T + t) * a.pitchA + ch * 8);
         *(uint4*)(in1 + ((row * pitch1 + col) * nc1 + (ch ^ cg_swz(col, nc1_l2))) * 16) = v;
     }
     if (C2) {
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
             const int ch = id % nc2, pos = id / nc2, col = pos % CG_TT, row = pos / CG_TT;
             const int f = f0 + row, t = t0 + col;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (f < a.F && t < a.T) v = *(const uint4*)(a.S + (((size_t)b * a.F + f) * a.T + t) * C2 + ch * 8);
+            if (f < a.F && t < a.T) v = *(const uint4*)(a.S + (((size_t)b * a.F + f) * a.T + t) * a.pitchS + ch * 8);
             *(uint4*)(in2 + ((row * CG_TT + col) * nc2 + (ch ^ cg_swz(col, nc2_l2))) * 16) = v;
         }
     }
@@ -197,19 +199,19 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
                         if (fo >= Fo) continue;
                         float v = fmaxf(v0, v1);
                         if (a.relu) v = fmaxf(v, 0.0f);
-                        if (OUT == CG_OUT_CL) a.out[(((size_t)b * Fo + fo) * a.T + t) * a.Cout + co] = f32_to_h16<DT>(v);
-                        else a.out[((size_t)t * a.B + b) * a.ldx + (size_t)fo * a.Cout + co] = f32_to_h16<DT>(v);
+                        bf16_t* o = OUT == CG_OUT_CL ? a.out + (((size_t)b * Fo + fo) * a.T + t) * a.Cout + co
+                                                     : a.out + ((size_t)t * a.B + b) * a.ldx + (size_t)fo * a.Cout + co;
+                        if (a.accum) v += h16_to_f32<DT>(*o);
+                        *o = f32_to_h16<DT>(v);
                     } else {
                         const int f = f0 + 4 * wm + 2 * i;
                         float u0 = v0, u1 = v1;
                         if (a.relu) { u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
-                        if (OUT == CG_OUT_CL) {
-                            if (f < Fo) a.out[(((size_t)b * Fo + f) * a.T + t) * a.Cout + co] = f32_to_h16<DT>(u0);
-                            if (f + 1 < Fo) a.out[(((size_t)b * Fo + f + 1) * a.T + t) * a.Cout + co] = f32_to_h16<DT>(u1);
-                        } else {
-                            if (f < Fo) a.out[((size_t)t * a.B + b) * a.ldx + (size_t)f * a.Cout + co] = f32_to_h16<DT>(u0);
-                            if (f + 1 < Fo) a.out[((size_t)t * a.B + b) * a.ldx + (size_t)(f + 1) * a.Cout + co] = f32_to_h16<DT>(u1);
-                        }
+                        bf16_t* o0 = OUT == CG_OUT_CL ? a.out + (((size_t)b * Fo + f) * a.T + t) * a.Cout + co
+                                                      : a.out + ((size_t)t * a.B + b) * a.ldx + (size_t)f * a.Cout + co;
+                        bf16_t* o1 = OUT == CG_OUT_CL ? o0 + (size_t)a.T * a.Cout : o0 + a.Cout;
+                        if (f < Fo) { if (a.accum) u0 += h16_to_f32<DT>(*o0); *o0 = f32_to_h16<DT>(u0); }
+                        if (f + 1 < Fo) { if (a.accum) u1 += h16_to_f32<DT>(*o1); *o1 = f32_to_h16<DT>(u1); }
                     }
                 }
         }
@@ -260,17 +262,27 @@ static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStrea
 #undef CG_DISPATCH
 }
 
-extern "C" int mt_conv_cl_dt(const void* A, const void* S, const void* W, const float* bias, void* out,
+// The general form: A / S may be channel slices of wider channels-last tensors (pitchA / pitchS = elements between
+// positions), and accum != 0 adds the result to what `out` holds (the input gradient of a convolution with more than 128
+// output channels is the sum of two calls over channel halves of the output gradient).
+extern "C" int mt_conv_cl_ex(const void* A, int pitchA, const void* S, int pitchS, const void* W, const float* bias, void* out,
                              int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,
-                             int dt, mt_stream_t stream) {
+                             int accum, int dt, mt_stream_t stream) {
     MT_REQUIRE(A && W && bias && out, MT_EINVAL, "mt_conv_cl: null pointer");
+    MT_REQUIRE(pitchA >= C1 && pitchA % 8 == 0 && (C2 == 0 || (pitchS >= C2 && pitchS % 8 == 0)), MT_EINVAL, "mt_conv_cl: bad position pitch");
     MT_REQUIRE_DT(dt, "mt_conv_cl");
     MT_REQUIRE(B > 0 && F > 0 && T > 0 && (KH == 3 || KH == 7) && (C1 == 32 || C1 == 64 || C1 == 128) &&
                (C2 == 0 || C2 == 32 || C2 == 64 || C2 == 128) && (C2 == 0 || S) && (Cout % 64 == 0), MT_EUNSUPPORTED,
                "mt_conv_cl: unsupported shape C1=%d C2=%d Cout=%d KH=%d", C1, C2, Cout, KH);
-    ConvGArgs a{(const bf16_t*)A, (const bf16_t*)S, (const bf16_t*)W, bias, (bf16_t*)out, B, F, T, C1, C2, Cout, KH, relu, ldx};
+    ConvGArgs a{(const bf16_t*)A, (const bf16_t*)S, (const bf16_t*)W, bias, (bf16_t*)out, B, F, T, C1, C2, Cout, KH, relu, ldx,
+                pitchA, pitchS, accum};
     return dt == MT_DT_F16 ? conv_cl_dispatch<MT_DT_F16>(a, pool, out_mode, (hipStream_t)stream)
                            : conv_cl_dispatch<MT_DT_BF16>(a, pool, out_mode, (hipStream_t)stream);
+}
+extern "C" int mt_conv_cl_dt(const void* A, const void* S, const void* W, const float* bias, void* out,
+                             int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,
+                             int dt, mt_stream_t stream) {
+    return mt_conv_cl_ex(A, C1, S, C2, W, bias, out, B, F, T, C1, C2, Cout, KH, relu, pool, out_mode, ldx, 0, dt, stream);
 }
 extern "C" int mt_conv_cl_bf16(const void* A, const void* S, const void* W, const float* bias, void* out,
                                int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,

@@ -564,7 +564,9 @@ static int launch_dt(int epi, const bf16_t* a, int lda, const bf16_t* w, int ldw
 static int launch(int epi, int dt, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st, int batch = 1) {
     MT_REQUIRE(A && W && ep.out, MT_EINVAL, "gemm: null pointer");
     MT_REQUIRE_DT(dt, "gemm");
-    MT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda >= K && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MT_EINVAL,
+    // (lda < K is allowed: rows then overlap -- a 1x1 convolution over 32 channels-last channels runs as K = 64 with zero
+    //  weight columns for the second half, which reads the next position's channels)
+    MT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda > 0 && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MT_EINVAL,
                "gemm: bad dims M=%d N=%d K=%d lda=%d ldw=%d (K must be a multiple of %d)", M, N, K, lda, ldw, BK);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
     return dt == MT_DT_F16 ? launch_dt<MT_DT_F16>(epi, a, lda, w, ldw, M, N, K, ep, st, batch)

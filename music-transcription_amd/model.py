@@ -168,6 +168,18 @@ class _HipForward:
                 raise _lib.MtError(f"LSTM {n}: inter-workgroup hand-off ({kind} spin) timed out at step {(st & 0x3fffffff) - (0 if st & 0x40000000 else 1)}: "
                                    "the launch was not fully resident (too many persistent launches in flight on this GPU?)")
 
+    def raise_on_train_handoff_timeout(self):
+        """The same for the persistent launches of the last training step (forward and backward recurrences); the
+        caller has synchronised with the step (train.train_one_epoch reads the loss and the optimizer's statistics)."""
+        ts = getattr(self, "_train_sync", None)
+        if ts is None:
+            return
+        buf, stride = ts
+        vals = buf.view(torch.int32)[:: stride // 4].cpu().tolist()
+        for i, st in enumerate(vals):
+            if st != 0:
+                raise _lib.MtError(f"training step: persistent recurrence launch {i} timed out in its inter-workgroup hand-off (status {st:#x})")
+
     def _check_inflight_bound(self, key, bound, what):
         """Co-residency rule of the persistent recurrence kernels: at most `bound` forwards of this
         model in flight per GPU, i.e. at most `bound` caller streams."""
@@ -330,6 +342,9 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
         super().__init__()
         self.n_mels, self.hidden_size, self.num_layers, self.output_dim = n_mels, hidden_size, num_layers, 88
         self.use_attention, self.use_onset_offset_heads = use_attention, use_onset_offset_heads
+        # train-mode dropouts of the reference: LSTM inter-layer / attention probabilities p, heads 1.5 p
+        # (cnn_rnn_model.py:216,:238,:251), and its hard-coded spatial dropouts (:188,:192,:202)
+        self.dropout_p, self.dropout2d_p = float(dropout), (0.1, 0.1, 0.15)
         self.conv1 = nn.Sequential(nn.Conv2d(1, 32, (3, 3), padding=(1, 1)), nn.BatchNorm2d(32), nn.ReLU(), nn.MaxPool2d((2, 1)))
         self.res_block1 = self._Res(32, 64)
         self.res_block2 = self._Res(64, 128)
@@ -435,9 +450,8 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
 
     def forward(self, x, return_all_heads=False, chunk_max_power: Optional[torch.Tensor] = None, check_status: bool = False):
         self._require_cuda(x)
-        if self.training or (torch.is_grad_enabled() and x.requires_grad):
-            raise NotImplementedError("the HIP path implements the eval-mode forward; the training step "
-                                      "(backward kernels) is not built yet -- call model.eval() / torch.no_grad()")
+        if x.requires_grad:
+            raise NotImplementedError("gradients w.r.t. the input mel are not implemented (the reference never asks for them)")
         if x.dim() != 4 or x.shape[1] != 1 or x.shape[2] != self.n_mels:
             raise ValueError(f"expected (B, 1, {self.n_mels}, T), got {tuple(x.shape)}")
         B, _, _, T = x.shape
@@ -445,6 +459,15 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
         if T == 0:
             z = torch.zeros(B, self.output_dim, 1, device=x.device)
             return {"frame": z, "onset": z.clone(), "offset": z.clone()} if (heads_out and return_all_heads) else z
+        if self.training:
+            # train mode: BatchNorm batch statistics, every dropout of the reference, activations saved, autograd edge to
+            # the HIP backward pass (train_step_large.py); under torch.no_grad() the same kernels run without the edge
+            if self.hidden_size > 512:
+                raise NotImplementedError("training: the backward recurrence kernel supports hidden_size <= 512")
+            if len(self.res_block1.skip) == 0 or len(self.res_block2.skip) == 0:
+                raise NotImplementedError("training: identity skips are not implemented (the reference's blocks change width)")
+            from .train_step_large import train_forward_large
+            return train_forward_large(self, x, return_all_heads=return_all_heads)
         pk = self._ensure_packed(x.device)
         w = pk["struct"]
         x = x.contiguous().float()

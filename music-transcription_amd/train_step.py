@@ -157,8 +157,14 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
         # ---- LSTM layers
         Xs: List[torch.Tensor] = [X0]
         gates, cxs, hxs = [], [], []
-        sync = torch.empty(lib.mt_lstm_sync_bytes(B, Hp), device=dev, dtype=torch.uint8)
+        # one status slot per persistent launch of the step (L forward + L backward recurrences): a launch zeroes its own
+        # slot only, so the host can read every launch's hand-off status after the step (model.raise_on_train_handoff_timeout)
+        sstride = _ru(lib.mt_lstm_sync_bytes(B, Hp), 256)
+        sync_all = torch.zeros(2 * L * sstride, device=dev, dtype=torch.uint8)
+        model._train_sync = (sync_all, sstride)
+        sv["sync_all"], sv["sync_stride"] = sync_all, sstride
         for l in range(L):
+            sync = sync_all[l * sstride:(l + 1) * sstride]
             K = K0 if l == 0 else K1
             gx = torch.empty(lib.mt_lstm_gx_bytes(B, T, Hp) // 4, **f32)
             cx = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
@@ -176,6 +182,9 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
             gates.append(gx); cxs.append(cx); hxs.append(hx); Xs.append(Xn)
         logits = torch.empty(B, 88, T, **f32)
         check(lib.mt_gemm_logits(ptr(Xs[L]), K1, ptr(pk["fc_w"]), K1, ptr(pk["fc_b"]), ptr(logits), B, T, 88, K1, _st()), "mt_gemm_logits")
+        # the side stream's poison fill of parts[0] finishes under the recurrences above: joining here is free, and it
+        # keeps the allocator's stream ordering sound when backward_train never runs (no_grad, a skipped batch)
+        main.wait_event(ev_part0)
     sv.update(Xs=Xs, gates=gates, cxs=cxs, hxs=hxs)
     for bn in (bn1, bn2):
         bn.num_batches_tracked += 1
@@ -218,7 +227,7 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         # ---- LSTM layers, top to bottom.  dh (gradient of a layer's output in the backward recurrence's layout, with the
         #      layer's dropout mask) is written by the GEMM that produces it: the fc layer's dL W here, the layer above's
         #      dG W_ih below.  Padded units / chunks are never written and stay zero.
-        sync = torch.empty(lib.mt_lstm_sync_bytes(B, Hp), device=dev, dtype=torch.uint8)
+        sync_all, sstride = sv["sync_all"], sv["sync_stride"]
         dh = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
         check(lib.mt_gemm_lstm_dh(ptr(dL), 128, ptr(pk["fc_wT"]), 128, ptr(dh), B, T, Hp, H, 128, 0.0, sv["seed"], L - 1, _st()),
               "mt_gemm_lstm_dh (fc)")
@@ -264,6 +273,7 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
                     check(lib.mt_lstm_bwd_poison(ptr(parts[1 - it]), parts[1 - it].numel(), B, T, Hp, _st()), "mt_lstm_bwd_poison")
                     ev_part[1 - it] = torch.cuda.Event()
                     ev_part[1 - it].record(side)
+            sync = sync_all[(L + l) * sstride:(L + l + 1) * sstride]
             dgx = dgxs[it % len(dgxs)]
             if ev_unp[it % len(dgxs)] is not None:
                 main.wait_event(ev_unp[it % len(dgxs)])  # the side stream's unpack of this buffer's previous user is done

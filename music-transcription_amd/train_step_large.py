@@ -1,0 +1,681 @@
+"""Train-mode forward and backward of CNNRNNModelLarge on the HIP library.
+
+What `loss.backward()` does in the reference's training loop (train/train_transcriber.py:104-131) for
+models/cnn_rnn_model.py:262-348 in train mode -- the model the reference's canonical pipeline trains (example.sh:22):
+conv1, two ResidualBlocks and the 7x3 freq_aware_conv with BatchNorm BATCH statistics, Dropout2d, the 3-layer main and
+1-layer local bidirectional LSTMs, MultiHeadAttention with the +-10 clamp and probability dropout, LayerNorm(x + attn),
+shared_fc + dropout + the frame / onset / offset heads -- as a torch.autograd.Function whose forward and backward are
+sequences of libmt_hip.so launches (csrc/train_large.hip, train.hip, lstm.hip, lstm_bwd.hip, gemm.hip, convg.hip,
+attn.hip).  torch only owns the buffers and the autograd graph edge.
+
+Numerics: as train_step.py -- GEMM / conv operands bf16, accumulation f32, LSTM state f32, BatchNorm statistics
+f64-accumulated, dropout masks from a counter-based hash seeded from torch's CPU generator.
+
+Every dense contraction of the backward pass is an NT GEMM or a channels-last conv:
+  * conv input gradients  = mt_conv_cl_* with flipped / transposed weights (a residual block's 3x3 + 1x1-skip pair in one call);
+  * conv weight gradients = per kernel column one batched GEMM over zero-padded position-major planes (mt_cl_to_planar):
+    taps along frequency are pointer offsets, the contraction over positions is split over workgroups -- no im2col;
+  * attention: dPd = dO V^T, dV = Pd^T dO, dQ = dS K, dK = dS^T Q as per-(chunk, head) batched GEMMs around
+    mt_attn_clamped_bwd.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr
+from .train_step import _ru, _st, _gemm, _gather4, BN_EPS, BN_MOMENTUM
+
+LN_EPS, ATTN_CLIP = 1e-6, 10.0
+DROPOUT2D_P = (0.1, 0.1, 0.15)          # cnn_rnn_model.py:188,:192,:202 (hard-coded in the reference)
+LOCAL_LAYER_ID = 100                    # dropout / hash stream ids: main layers 0.., local LSTM, attention, heads
+ATTN_LAYER_ID, HEADS_LAYER_ID, D2D_LAYER_ID = 200, 300, 400
+
+
+# ---------------------------------------------------------------------------------------------------------------- packing
+def _conv_cl(w):            # [Cout][Cin][KH][KW] -> [Cout][(kh*KW + kw)*Cin + ci]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+def _conv_dgrad_w(w, rows_pad=None):
+    """Input-gradient weights of a KH x 3 convolution: [Cin (padded rows)][(kh'*3 + kw')*Cout + co] = w[co][ci][KH-1-kh'][2-kw']."""
+    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1)
+    if rows_pad and rows_pad > wd.shape[0]:
+        wd = torch.cat([wd, wd.new_zeros(rows_pad - wd.shape[0], wd.shape[1])], 0)
+    return wd
+
+
+def pack_train_large(model, dev) -> Dict[str, object]:
+    """bf16 operand layouts of the CURRENT parameters (redone every step: the optimizer moves them)."""
+    from .model import _pack_bilstm
+    H, L, Hl, F = model.hidden_size, model.num_layers, model.hidden_size // 2, model.n_mels
+    Hp, Hlp, K1 = _ru(H, 16), _ru(Hl, 16), _ru(2 * H, 64)
+    F1, F2, F3 = F // 2, F // 4, F // 8
+    K0 = F3 * 256
+    comb = 2 * H + 2 * Hl
+    Cp = _ru(comb, 64)
+    f32 = dict(device=dev, dtype=torch.float32)
+    bf = torch.bfloat16
+    t: Dict[str, object] = {}
+    d = dict(H=H, Hp=Hp, Hl=Hl, Hlp=Hlp, L=L, F=F, F1=F1, F2=F2, F3=F3, K0=K0, K1=K1, comb=comb, Cp=Cp)
+    g = lambda p: p.detach().to(**f32)
+    t["w1"], t["b1"] = g(model.conv1[0].weight).reshape(32, 9).contiguous(), g(model.conv1[0].bias).contiguous()
+    t["g1"], t["be1"] = g(model.conv1[1].weight).contiguous(), g(model.conv1[1].bias).contiguous()
+    for name, rb, cin, cout in (("rb1", model.res_block1, 32, 64), ("rb2", model.res_block2, 64, 128)):
+        w1, w2, ws = g(rb.conv1.weight), g(rb.conv2.weight), g(rb.skip[0].weight).reshape(cout, cin)
+        t[name + "c1_w"], t[name + "c1_b"] = _conv_cl(w1).to(bf).contiguous(), g(rb.conv1.bias).contiguous()
+        t[name + "c2_w"], t[name + "c2_b"] = _conv_cl(w2).to(bf).contiguous(), g(rb.conv2.bias).contiguous()
+        wsp = torch.zeros(128, 64 if cin < 64 else cin, **f32)             # the 1x1 skip as a GEMM (K padded to 64: see mt_gemm)
+        wsp[:cout, :cin] = ws
+        t[name + "s_w"], t[name + "s_b"] = wsp.to(bf), g(rb.skip[0].bias).contiguous()
+        t[name + "c2_wd"] = _conv_dgrad_w(w2).to(bf).contiguous()                                   # [cout][9*cout]
+        cin_p = max(cin, 64)                                                                        # conv_cl wants Cout % 64 == 0
+        wd = torch.zeros(cin_p, 9 * cout + cout, **f32)                                             # conv1 dgrad + skip^T in one call
+        wd[:cin, :9 * cout] = _conv_dgrad_w(w1)
+        wd[:cin, 9 * cout:] = ws.t()
+        t[name + "c1s_wd"] = wd.to(bf)
+        for bn, tag in ((rb.bn1, "bn1"), (rb.bn2, "bn2"), (rb.skip[1], "bns")):
+            t[f"{name}{tag}_g"], t[f"{name}{tag}_b"] = g(bn.weight).contiguous(), g(bn.bias).contiguous()
+    wf = g(model.freq_aware_conv[0].weight)
+    t["fa_w"], t["fa_b"] = _conv_cl(wf).to(bf).contiguous(), g(model.freq_aware_conv[0].bias).contiguous()
+    t["fa_wdA"] = _conv_dgrad_w(wf[:128]).to(bf).contiguous()             # input gradient in two halves of the 256 output channels
+    t["fa_wdB"] = _conv_dgrad_w(wf[128:]).to(bf).contiguous()
+    t["fa_g"], t["fa_be"] = g(model.freq_aware_conv[1].weight).contiguous(), g(model.freq_aware_conv[1].bias).contiguous()
+    t["zeros256"] = torch.zeros(256, **f32)
+    # LSTMs (layer-0 columns re-ordered: reference feature c*F3+f -> kernel column f*256+c)
+    cols = (torch.arange(256)[None, :] * F3 + torch.arange(F3)[:, None]).reshape(-1)
+    t["m_wih"], t["m_b"], t["m_whh"] = _pack_bilstm(model.rnn_main, L, H, cols, dev)
+    t["l_wih"], t["l_b"], t["l_whh"] = _pack_bilstm(model.rnn_local, 1, Hl, cols, dev)
+    t["m_wihT"] = [None]
+    for l in range(1, L):
+        wT = torch.zeros(_ru(K1, 128), 8 * Hp, device=dev, dtype=bf)
+        wT[:K1] = t["m_wih"][l][:8 * Hp].t()
+        t["m_wihT"].append(wT)
+    wcat = torch.zeros(_ru(K0, 128), 8 * Hp + 8 * Hlp, device=dev, dtype=bf)   # dX0 = [dG_main | dG_local] . [W_ih_main; W_ih_local]
+    wcat[:K0, :8 * Hp] = t["m_wih"][0][:8 * Hp].t()
+    wcat[:K0, 8 * Hp:] = t["l_wih"][0][:8 * Hlp].t()
+    t["ml_wihT"] = wcat
+    if model.use_attention:
+        heads, dh = model.attention.num_heads, model.attention.head_dim
+        dp = _ru(dh, 64)
+        Ca = heads * dp
+        d.update(heads=heads, dh=dh, dp=dp, Ca=Ca, ld3=3 * Ca, scale=float(dh) ** -0.5)
+        qw = g(model.attention.qkv.weight).reshape(3, heads, dh, comb)
+        qwp = torch.zeros(3, heads, dp, Cp, **f32); qwp[:, :, :dh, :comb] = qw
+        qbp = torch.zeros(3, heads, dp, **f32); qbp[:, :, :dh] = g(model.attention.qkv.bias).reshape(3, heads, dh)
+        qfull = torch.zeros(_ru(3 * Ca, 128), Cp, **f32); qfull[:3 * Ca] = qwp.reshape(3 * Ca, Cp)
+        t["qkv_w"], t["qkv_b"] = qfull.to(bf), qbp.reshape(-1).contiguous()
+        qT = torch.zeros(_ru(comb, 128), 3 * Ca, **f32); qT[:Cp] = qfull[:3 * Ca].t()
+        t["qkv_wT"] = qT.to(bf)
+        pw = g(model.attention.proj.weight).reshape(comb, heads, dh)
+        pwp = torch.zeros(_ru(comb, 128), heads, dp, **f32); pwp[:comb, :, :dh] = pw
+        t["proj_w"], t["proj_b"] = pwp.reshape(-1, Ca).to(bf), g(model.attention.proj.bias).contiguous()
+        pT = torch.zeros(_ru(Ca, 128), Cp, **f32); pT[:Ca, :comb] = pwp.reshape(-1, Ca)[:comb].t()
+        t["proj_wT"] = pT.to(bf)
+        t["ln_g"], t["ln_b"] = g(model.attention_norm.weight).contiguous(), g(model.attention_norm.bias).contiguous()
+    if model.use_onset_offset_heads:
+        Hs = _ru(H, 64)
+        d.update(Hs=Hs)
+        sw = torch.zeros(_ru(H, 128), Cp, **f32); sw[:H, :comb] = g(model.shared_fc.weight)
+        t["shared_w"], t["shared_b"] = sw.to(bf), g(model.shared_fc.bias).contiguous()
+        swT = torch.zeros(_ru(comb, 128), Hs, **f32); swT[:comb, :H] = g(model.shared_fc.weight).t()
+        t["shared_wT"] = swT.to(bf)
+        hw = torch.zeros(384, Hs, **f32)
+        hw[:264, :H] = torch.cat([g(m.weight) for m in (model.frame_head, model.onset_head, model.offset_head)], 0)
+        t["heads_w"] = hw.to(bf)
+        t["heads_b"] = torch.cat([g(m.bias) for m in (model.frame_head, model.onset_head, model.offset_head)], 0).contiguous()
+        hwT = torch.zeros(_ru(Hs, 128), 384, **f32); hwT[:Hs] = hw.t()
+        t["heads_wT"] = hwT.to(bf)
+    else:
+        fw = torch.zeros(128, Cp, **f32); fw[:88, :comb] = g(model.fc.weight)
+        t["fc_w"], t["fc_b"] = fw.to(bf), g(model.fc.bias).contiguous()
+        fwT = torch.zeros(_ru(comb, 128), 128, **f32); fwT[:comb] = fw[:, :comb].t()
+        t["fc_wT"] = fwT.to(bf)
+    t["dims"] = d
+    return t
+
+
+# ---------------------------------------------------------------------------------------------------------------- small wrappers
+def _conv(A, S, W, bias, out, B, F, T, C1, C2, Cout, KH, relu=0, pool=0, out_mode=0, ldx=0, pitchA=None, pitchS=None, accum=0):
+    check(lib.mt_conv_cl_ex(ptr(A), pitchA or C1, ptr(S), pitchS or C2, ptr(W), ptr(bias), ptr(out), B, F, T, C1, C2, Cout, KH, relu, pool,
+                            out_mode, ldx, accum, _lib.DT_BF16, _st()), "mt_conv_cl_ex")
+
+
+def _gemm_bf16out(A, lda, W, ldw, bias, C, ldc, M, N, K, relu=0):
+    check(lib.mt_gemm_batched_bf16out(ptr(A), lda, 0, 0, ptr(W), ldw, 0, 0, ptr(bias), ptr(C), ldc, 0, 0, M, N, K, 1, 1, relu, _st()),
+          "mt_gemm_batched_bf16out")
+
+
+def _bn_stats(z, N, C, bn, gamma, beta, dev):
+    """Batch statistics of a channels-last bf16 tensor [N][C]; updates bn's running statistics.  -> (mean, rstd)"""
+    sums = torch.empty(2 * C, device=dev, dtype=torch.float64)
+    mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    check(lib.mt_bn_stats_cl(ptr(z), N, C, ptr(sums), _st()), "mt_bn_stats_cl")
+    check(lib.mt_bn_finalize(ptr(sums), float(N), ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var), BN_MOMENTUM, BN_EPS,
+                             ptr(mean), ptr(rstd), C, None, None, None, None, 0, _st()), "mt_bn_finalize")
+    bn.num_batches_tracked += 1
+    return mean, rstd
+
+
+def _bn_act(za, sa, zb, sb, mask, out, out_mode, ldx, B, F, T, C, relu, pool):
+    """sa / sb = (mean, rstd, gamma, beta)"""
+    sb = sb or (None, None, None, None)
+    check(lib.mt_bn_act_fwd(ptr(za), *(ptr(v) for v in sa), ptr(zb), *(ptr(v) for v in sb), ptr(mask), ptr(out), out_mode, ldx,
+                            B, F, T, C, relu, pool, _st()), "mt_bn_act_fwd")
+
+
+def _bn_act_bwd(dcl, ldd_cl, dx, ldd_x, za, sa, zb, sb, mask, dza, dzb, grads, B, F, T, C, relu, pool, dev, dza_lo=None):
+    sb = sb or (None, None, None, None)
+    sums = torch.empty(3 * C, device=dev, dtype=torch.float64)
+    dga, dba, dgb, dbb = grads
+    check(lib.mt_bn_act_bwd(ptr(dcl), ldd_cl, ptr(dx), ldd_x, ptr(za), *(ptr(v) for v in sa), ptr(zb), *(ptr(v) for v in sb), ptr(mask),
+                            ptr(sums), ptr(dza), C, ptr(dza_lo), ptr(dzb), C, ptr(dga), ptr(dba), ptr(dgb), ptr(dbb), B, F, T, C, relu, pool,
+                            _st()), "mt_bn_act_bwd")
+    return sums
+
+
+class _Planes:
+    """Zero-padded position-major planes of a channels-last tensor [B][F][T][C] (see mt_cl_to_planar): the operands of the
+    convolution weight-gradient GEMMs.  geometry: Fp = F + 2 ph rows per chunk, Tp2 = roundup(T + 2, 8) columns per row."""
+
+    def __init__(self, B, F, T, ph, dev):
+        self.B, self.F, self.T, self.ph = B, F, T, ph
+        self.Tp2 = _ru(T + 2, 8)
+        self.npos = B * (F + 2 * ph) * self.Tp2
+        self.S = max(1, min(96, self.npos // 2048))                # K splits (workgroups along the contraction)
+        self.Ks = _ru(-(-self.npos // self.S), 64)
+        self.Kp = self.S * self.Ks
+        self.front = ph * self.Tp2
+        self.ld = _ru(self.front + self.Kp + ph * self.Tp2 + 64, 8)
+        self.dev = dev
+
+    def make(self, src, pitch, C, toffs):
+        """-> tensor [len(toffs)][roundup(C, 128)][ld]; plane k holds the source shifted by toffs[k] columns."""
+        rows = _ru(C, 128)
+        out = torch.zeros(len(toffs), rows, self.ld, device=self.dev, dtype=torch.bfloat16)
+        for k, toff in enumerate(toffs):
+            base = out[k].reshape(-1)[self.front:]
+            check(lib.mt_cl_to_planar(ptr(src), pitch, C, ptr(base), self.ld, self.B, self.F, self.T, self.ph, self.Tp2, toff, _st()),
+                  "mt_cl_to_planar")
+        return out
+
+
+def _conv_wgrad(pl: _Planes, dzP, xP, Cout, Cin, KH, kws, out):
+    """out (f32, reference layout [Cout][Cin][KH][len(kws)]) = sum over positions of dz[pos][co] * x[pos + tap][ci].
+    dzP: planes tensor [1][.][ld] (toff 1); xP: planes [3][.][ld] for kernel columns 0, 1, 2 (toffs 2, 1, 0);
+    kws: the kernel columns wanted ((0, 1, 2) for a KH x 3 conv, (1,) with KH = 1 for the 1x1 skip).  Tap kh is the pointer
+    offset (kh - KH // 2) * Tp2 into the activation plane."""
+    dev = pl.dev
+    nkw = len(kws)
+    part = torch.empty(nkw, pl.S, KH, Cout, Cin, device=dev, dtype=torch.float32)
+    red = torch.empty(nkw, KH, Cout, Cin, device=dev, dtype=torch.float32)
+    a = dzP[0].reshape(-1)[pl.front:]
+    for i, kw in enumerate(kws):
+        w = xP[kw].reshape(-1)[pl.front - (KH // 2) * pl.Tp2:]
+        check(lib.mt_gemm_batched_f32(ptr(a), pl.ld, pl.Ks, 0, ptr(w), pl.ld, pl.Ks, pl.Tp2, None, ptr(part[i]), Cin,
+                                      KH * Cout * Cin, Cout * Cin, Cout, Cin, pl.Ks, pl.S * KH, KH, _st()), "mt_gemm_batched_f32 (conv wgrad)")
+        check(lib.mt_sum_slices_f32(ptr(part[i]), KH * Cout * Cin, Cin, pl.S, ptr(red[i]), Cin, KH * Cout, Cin, _st()), "mt_sum_slices_f32")
+    _gather4(red, 0, out, (Cout, Cin, KH, nkw), (Cin, 1, Cout * Cin, KH * Cout * Cin))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- LSTM stack
+def _lstm_forward(X0, K0, w_ih, b_g, w_hh, L, Hp, Hv, K1, B, T, dropout, seed, layer_id0, dev, sync_slots):
+    """Train-mode bidirectional LSTM stack on GEMM-row input X0 [Mpad][K0].  Returns saved state; the last layer's hx is
+    left for the caller to re-lay out.  Inter-layer dropout p on the outputs of layers 0..L-2."""
+    M, Mpad = T * B, _ru(T * B, 128)
+    bf = dict(device=dev, dtype=torch.bfloat16)
+    Xs, gates, cxs, hxs = [X0], [], [], []
+    for l in range(L):
+        K = K0 if l == 0 else K1
+        gx = torch.empty(lib.mt_lstm_gx_bytes(B, T, Hp) // 4, device=dev)
+        cx = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, device=dev)
+        hx = torch.empty(lib.mt_lstm_hx_bytes(B, T, Hp) // 4, device=dev)
+        sync = sync_slots.pop(0)
+        check(lib.mt_gemm_lstm_gx(ptr(Xs[l]), K, ptr(w_ih[l]), K, ptr(b_g[l]), ptr(gx), B, T, Hp, K, _st()), "mt_gemm_lstm_gx")
+        check(lib.mt_lstm_bidir_fwd_train(ptr(gx), ptr(w_hh[l]), ptr(hx), ptr(cx), ptr(sync), sync.numel(), B, T, Hp, _st()),
+              "mt_lstm_bidir_fwd_train")
+        gates.append(gx); cxs.append(cx); hxs.append(hx)
+        if l < L - 1:
+            Xn = torch.zeros(Mpad, K1, **bf) if K1 != 2 * Hv else torch.empty(Mpad, K1, **bf)
+            if K1 == 2 * Hv:
+                Xn[M:].zero_()
+            check(lib.mt_lstm_relayout_train(ptr(hx), ptr(Xn), K1, B, T, Hp, Hv, float(dropout), seed, layer_id0 + l, _st()),
+                  "mt_lstm_relayout_train")
+            Xs.append(Xn)
+    return dict(Xs=Xs, gates=gates, cxs=cxs, hxs=hxs)
+
+
+def _lstm_backward(sv, dh, w_hh, w_ihT, L, Hp, Hv, K0, K1, B, T, dropout, seed, layer_id0, dev, sync_slots, dG0, ldg0, col0, names, g, rnn_prefix,
+                   k0_gather):
+    """BPTT through the stack.  dh: gradient of the top layer's output in the backward recurrence's layout.  Layer 0's gate
+    gradients go to dG0[:, col0 : col0 + 8 Hp] (row pitch ldg0): the caller turns them into the input gradient.  Parameter
+    gradients land in g under rnn_prefix; k0_gather(gwi, di) produces layer 0's W_ih gradient in the reference layout."""
+    M, Mpad = T * B, _ru(T * B, 128)
+    bf = dict(device=dev, dtype=torch.bfloat16)
+    f32 = dict(device=dev, dtype=torch.float32)
+    Hr = _ru(Hp, 128)
+    for l in range(L - 1, -1, -1):
+        K = K0 if l == 0 else K1
+        part = torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
+        dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
+        sync = sync_slots.pop(0)
+        check(lib.mt_lstm_bidir_bwd(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(w_hh[l]), ptr(dgx), ptr(part), part.numel(),
+                                    ptr(sync), sync.numel(), B, T, Hp, _st()), "mt_lstm_bidir_bwd")
+        if l == 0:
+            dG, ldg = dG0[:, col0:], ldg0
+            dGv = dG0.reshape(-1)[col0:]
+        else:
+            dGfull = torch.empty(Mpad, 8 * Hp, **bf)
+            dGfull[M:].zero_()
+            dGv, ldg = dGfull, 8 * Hp
+        dGT = torch.zeros(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
+        check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dGv), ldg, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
+        if l > 0:      # -> dh of layer l-1 (its output went through dropout in the forward pass)
+            dh = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
+            check(lib.mt_gemm_lstm_dh(ptr(dGv), 8 * Hp, ptr(w_ihT[l]), 8 * Hp, ptr(dh), B, T, Hp, Hv, 8 * Hp, float(dropout), seed,
+                                      layer_id0 + l - 1, _st()), "mt_gemm_lstm_dh")
+        # ---- weight gradients: dW_ih = dG^T X_l, dW_hh = dG^T H_prev, db = sum dG
+        XT = torch.empty(_ru(K, 128) * Mpad, **bf)
+        check(lib.mt_transpose_bf16(ptr(sv["Xs"][l]), K, M, K, ptr(XT), Mpad, K, _st()), "mt_transpose_bf16")
+        HT = torch.zeros(2 * Hr, Mpad, **bf)
+        check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HT), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
+        gb, gwi, gwh = torch.empty(8 * Hp, **f32), torch.empty(8 * Hp, K, **f32), torch.empty(2, 4 * Hp, Hp, **f32)
+        check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
+        _gemm(dGT, Mpad, XT, Mpad, gwi, K, 8 * Hp, K, Mpad)
+        for di in range(2):
+            _gemm(dGT[di * 4 * Hp:], Mpad, HT[di * Hr:], Mpad, gwh[di], Hp, 4 * Hp, Hp, Mpad)
+        for di, suf in enumerate(("", "_reverse")):
+            if l == 0:
+                wi = k0_gather(gwi, di)
+            else:
+                wi = torch.empty(4 * Hv, 2 * Hv, **f32)
+                _gather4(gwi, di * 4 * Hp * K, wi, (4, Hv, 1, 2 * Hv), (Hp * K, K, 0, 1))
+            wh, bb, bb2 = torch.empty(4 * Hv, Hv, **f32), torch.empty(4 * Hv, **f32), torch.empty(4 * Hv, **f32)
+            _gather4(gwh, di * 4 * Hp * Hp, wh, (4, Hv, 1, Hv), (Hp * Hp, Hp, 0, 1))
+            _gather4(gb, di * 4 * Hp, bb, (1, 1, 4, Hv), (0, 0, Hp, 1))
+            _gather4(gb, di * 4 * Hp, bb2, (1, 1, 4, Hv), (0, 0, Hp, 1))
+            g[f"{rnn_prefix}.weight_ih_l{l}{suf}"], g[f"{rnn_prefix}.weight_hh_l{l}{suf}"] = wi, wh
+            g[f"{rnn_prefix}.bias_ih_l{l}{suf}"], g[f"{rnn_prefix}.bias_hh_l{l}{suf}"] = bb, bb2
+
+
+# ---------------------------------------------------------------------------------------------------------------- forward
+def forward_train_large(model, x: torch.Tensor, p_drop: float, seed: int, p2d=DROPOUT2D_P):
+    """Returns (logits [NH][B][88][T] f32 (NH = 3 with the heads, else 1), saved state).  Updates BatchNorm running statistics."""
+    dev = x.device
+    B, _, F, T = x.shape
+    pk = pack_train_large(model, dev)
+    d = pk["dims"]
+    H, Hp, Hl, Hlp, L, F1, F2, F3, K0, K1, comb, Cp = (d[k] for k in ("H", "Hp", "Hl", "Hlp", "L", "F1", "F2", "F3", "K0", "K1", "comb", "Cp"))
+    M, Mpad = T * B, _ru(T * B, 128)
+    x = x.contiguous().float()
+    bf = dict(device=dev, dtype=torch.bfloat16)
+    f32 = dict(device=dev, dtype=torch.float32)
+    sv: Dict[str, object] = dict(pk=pk, x=x, B=B, T=T, p=p_drop, seed=seed, p2d=p2d)
+    nsync = 2 * (L + 1)
+    stride = _ru(max(lib.mt_lstm_sync_bytes(B, Hp), lib.mt_lstm_sync_bytes(B, Hlp)), 256)
+    sync_all = torch.zeros(nsync * stride, device=dev, dtype=torch.uint8)       # one status slot per persistent launch of the step
+    slots = [sync_all[i * stride:(i + 1) * stride] for i in range(nsync)]
+    sv["sync_all"], sv["sync_stride"], sv["sync_free"] = sync_all, stride, slots
+    with torch.cuda.device(dev):
+        # ---- conv1: statistics of the recomputed pre-BN activation, folded into the inference kernel's weights
+        bn1 = model.conv1[1]
+        sums = torch.zeros(64, device=dev, dtype=torch.float64)
+        mean1, rstd1 = torch.empty(32, **f32), torch.empty(32, **f32)
+        wf1, bf1 = torch.empty(32, 9, **f32), torch.empty(32, **f32)
+        check(lib.mt_conv1_stats(ptr(x), ptr(pk["w1"]), ptr(pk["b1"]), ptr(sums), B, F, T, _st()), "mt_conv1_stats")
+        check(lib.mt_bn_finalize(ptr(sums), float(B * F * T), ptr(pk["g1"]), ptr(pk["be1"]), ptr(bn1.running_mean), ptr(bn1.running_var),
+                                 BN_MOMENTUM, BN_EPS, ptr(mean1), ptr(rstd1), 32, ptr(pk["w1"]), ptr(pk["b1"]), ptr(wf1), ptr(bf1), 9, _st()),
+              "mt_bn_finalize")
+        bn1.num_batches_tracked += 1
+        # (rows past the B*F1*T positions: the 1x1 skip GEMM reads whole 128-row tiles, and K = 64 from 32-channel rows)
+        a1 = torch.empty(_ru(B * F1 * T, 128) + 1, 32, **bf)
+        a1[B * F1 * T:].zero_()
+        check(lib.mt_conv1_bn_relu_pool(ptr(x), None, ptr(wf1), ptr(bf1), ptr(a1), B, F, T, _st()), "mt_conv1_bn_relu_pool")
+        sv.update(mean1=mean1, rstd1=rstd1, a1=a1)
+        # ---- dropout2d mask tables
+        masks = []
+        for i, (C, p) in enumerate(zip((64, 128, 256), p2d)):
+            if p > 0.0:
+                m = torch.empty(B, C, **f32)
+                check(lib.mt_dropout2d_mask(ptr(m), B, C, float(p), seed, D2D_LAYER_ID + i, _st()), "mt_dropout2d_mask")
+                masks.append(m)
+            else:
+                masks.append(None)
+        sv["masks"] = masks
+        # ---- residual blocks
+        xin, Fin = a1, F1
+        for name, rb, cin, cout, pool, mask in (("rb1", model.res_block1, 32, 64, 1, masks[0]), ("rb2", model.res_block2, 64, 128, 0, masks[1])):
+            N = B * Fin * T
+            z1 = torch.empty(N, cout, **bf)
+            _conv(xin, None, pk[name + "c1_w"], pk[name + "c1_b"], z1, B, Fin, T, cin, 0, cout, 3)
+            s1 = _bn_stats(z1, N, cout, rb.bn1, pk[name + "bn1_g"], pk[name + "bn1_b"], dev) + (pk[name + "bn1_g"], pk[name + "bn1_b"])
+            y1 = torch.empty(N, cout, **bf)
+            _bn_act(z1, s1, None, None, None, y1, 0, 0, B, Fin, T, cout, 1, 0)
+            z2 = torch.empty(N, cout, **bf)
+            _conv(y1, None, pk[name + "c2_w"], pk[name + "c2_b"], z2, B, Fin, T, cout, 0, cout, 3)
+            zs = torch.empty(N, cout, **bf)
+            Ks = max(cin, 64)
+            _gemm_bf16out(xin, cin, pk[name + "s_w"], Ks, pk[name + "s_b"], zs, cout, N, cout, Ks)
+            s2 = _bn_stats(z2, N, cout, rb.bn2, pk[name + "bn2_g"], pk[name + "bn2_b"], dev) + (pk[name + "bn2_g"], pk[name + "bn2_b"])
+            ss = _bn_stats(zs, N, cout, rb.skip[1], pk[name + "bns_g"], pk[name + "bns_b"], dev) + (pk[name + "bns_g"], pk[name + "bns_b"])
+            Fo = Fin // 2 if pool else Fin
+            out = torch.empty(_ru(B * Fo * T, 128) + 1, cout, **bf)
+            out[B * Fo * T:].zero_()
+            _bn_act(z2, s2, zs, ss, mask, out, 0, 0, B, Fin, T, cout, 1, pool)
+            sv[name] = dict(xin=xin, Fin=Fin, z1=z1, s1=s1, y1=y1, z2=z2, zs=zs, s2=s2, ss=ss, cin=cin, cout=cout, pool=pool, mask=mask)
+            xin, Fin = out, Fo
+        r2 = xin
+        # ---- freq_aware_conv: 7x3 conv -> BN -> ReLU -> pool -> dropout2d, straight into the GEMM operand rows
+        N = B * F2 * T
+        zf = torch.empty(N, 256, **bf)
+        _conv(r2, None, pk["fa_w"], pk["fa_b"], zf, B, F2, T, 128, 0, 256, 7)
+        bnf = model.freq_aware_conv[1]
+        sf = _bn_stats(zf, N, 256, bnf, pk["fa_g"], pk["fa_be"], dev) + (pk["fa_g"], pk["fa_be"])
+        X0 = torch.empty(Mpad, K0, **bf)
+        X0[M:].zero_()
+        _bn_act(zf, sf, None, None, masks[2], X0, 1, K0, B, F2, T, 256, 1, 1)
+        sv.update(r2=r2, zf=zf, sf=sf)
+        # ---- LSTMs
+        pm = p_drop if L > 1 else 0.0
+        sv["main"] = _lstm_forward(X0, K0, pk["m_wih"], pk["m_b"], pk["m_whh"], L, Hp, H, K1, B, T, pm, seed, 0, dev, slots)
+        sv["local"] = _lstm_forward(X0, K0, pk["l_wih"], pk["l_b"], pk["l_whh"], 1, Hlp, Hl, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev, slots)
+        rb = torch.zeros(Mpad, Cp, **bf)
+        r32 = torch.empty(M, comb, **f32)
+        check(lib.mt_lstm_relayout_ex(ptr(sv["main"]["hxs"][-1]), ptr(rb), Cp, ptr(r32), comb, 0, B, T, Hp, H, _st()), "mt_lstm_relayout_ex")
+        check(lib.mt_lstm_relayout_ex(ptr(sv["local"]["hxs"][-1]), ptr(rb), Cp, ptr(r32), comb, 2 * H, B, T, Hlp, Hl, _st()), "mt_lstm_relayout_ex")
+        sv.update(rb=rb, r32=r32)
+        feat = rb
+        # ---- attention + LayerNorm
+        if model.use_attention:
+            heads, dp, Ca, ld3, scale = d["heads"], d["dp"], d["Ca"], d["ld3"], d["scale"]
+            Tr, Tp = _ru(T, 128), _ru(T, 64)
+            dpr = _ru(dp, 128)
+            qkv = torch.zeros(Tr * B, ld3, **bf)
+            _gemm_bf16out(rb, Cp, pk["qkv_w"], Cp, pk["qkv_b"], qkv, ld3, M, ld3, Cp)
+            S = torch.empty(B * heads, T, Tp, **f32)
+            qk = qkv.reshape(-1)
+            check(lib.mt_gemm_batched_f32(ptr(qk), B * ld3, ld3, dp, ptr(qk[Ca:]), B * ld3, ld3, dp, None, ptr(S), Tp, heads * T * Tp, T * Tp,
+                                          T, T, dp, B * heads, heads, _st()), "mt_gemm_batched_f32 (QK^T)")
+            Pd = torch.zeros(B * heads * T * Tp + Tr * Tp, **bf)           # (a head's GEMM reads whole 128-row tiles: tail slack)
+            check(lib.mt_attn_softmax_train(ptr(S), Tp, ptr(Pd), Tp, T, B * heads * T, scale, ATTN_CLIP, float(p_drop), seed, ATTN_LAYER_ID, _st()),
+                  "mt_attn_softmax_train")
+            VT = torch.empty(B * heads, dpr, Tp, **bf)
+            check(lib.mt_attn_transpose_v(ptr(qkv), ld3, 2 * Ca, ptr(VT), B, T, Tp, heads, dp, _st()), "mt_attn_transpose_v")
+            ao = torch.zeros(Mpad, Ca, **bf)
+            check(lib.mt_gemm_batched_bf16out(ptr(Pd), Tp, heads * T * Tp, T * Tp, ptr(VT), Tp, heads * dpr * Tp, dpr * Tp, None, ptr(ao), B * Ca,
+                                              Ca, dp, T, dp, Tp, B * heads, heads, 0, _st()), "mt_gemm_batched_bf16out (PV)")
+            proj = torch.empty(M, comb, **f32)
+            _gemm(ao, Ca, pk["proj_w"], Ca, proj, comb, M, comb, Ca, bias=pk["proj_b"])
+            ln = torch.zeros(Mpad, Cp, **bf)
+            stats = torch.empty(M, 2, **f32)
+            check(lib.mt_layernorm_residual_train(ptr(r32), comb, ptr(proj), comb, ptr(pk["ln_g"]), ptr(pk["ln_b"]), ptr(ln), Cp, ptr(stats), M, comb,
+                                                  LN_EPS, _st()), "mt_layernorm_residual_train")
+            sv.update(qkv=qkv, S=S, Pd=Pd, ao=ao, proj=proj, ln=ln, ln_stats=stats)
+            feat = ln
+        sv["feat"] = feat
+        # ---- heads
+        ph = 1.5 * p_drop
+        if model.use_onset_offset_heads:
+            Hs = d["Hs"]
+            sh = torch.zeros(Mpad, Hs, **bf)
+            _gemm_bf16out(feat, Cp, pk["shared_w"], Cp, pk["shared_b"], sh, Hs, M, H, Cp, relu=1)
+            check(lib.mt_dropout_bf16_rows(ptr(sh), Hs, M, H, float(ph), seed, HEADS_LAYER_ID, _st()), "mt_dropout_bf16_rows")
+            logits = torch.empty(3, B, 88, T, **f32)
+            check(lib.mt_gemm_logits(ptr(sh), Hs, ptr(pk["heads_w"]), Hs, ptr(pk["heads_b"]), ptr(logits), B, T, 264, Hs, _st()), "mt_gemm_logits")
+            sv["sh"] = sh
+        else:
+            logits = torch.empty(1, B, 88, T, **f32)
+            check(lib.mt_gemm_logits(ptr(feat), Cp, ptr(pk["fc_w"]), Cp, ptr(pk["fc_b"]), ptr(logits), B, T, 88, Cp, _st()), "mt_gemm_logits")
+            check(lib.mt_dropout_f32(ptr(logits), logits.numel(), float(ph), seed, HEADS_LAYER_ID, _st()), "mt_dropout_f32")
+    return logits, sv
+
+
+# ---------------------------------------------------------------------------------------------------------------- backward
+def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Gradients of every parameter (reference names without the `model.` prefix, reference shapes)."""
+    pk = sv["pk"]
+    d = pk["dims"]
+    H, Hp, Hl, Hlp, L, F, F1, F2, F3, K0, K1, comb, Cp = (d[k] for k in ("H", "Hp", "Hl", "Hlp", "L", "F", "F1", "F2", "F3", "K0", "K1", "comb", "Cp"))
+    B, T, x, p_drop, seed = sv["B"], sv["T"], sv["x"], sv["p"], sv["seed"]
+    dev = x.device
+    M, Mpad = T * B, _ru(T * B, 128)
+    bf = dict(device=dev, dtype=torch.bfloat16)
+    f32 = dict(device=dev, dtype=torch.float32)
+    g: Dict[str, torch.Tensor] = {}
+    dlogits = dlogits.contiguous().float()
+    slots = sv["sync_free"]
+    feat = sv["feat"]
+    ph = 1.5 * p_drop
+    with torch.cuda.device(dev):
+        featT = torch.empty(_ru(Cp, 128) * Mpad, **bf)
+        check(lib.mt_transpose_bf16(ptr(feat), Cp, M, Cp, ptr(featT), Mpad, Cp, _st()), "mt_transpose_bf16")
+        dfeat = torch.empty(M, comb, **f32)
+        # ---- heads
+        if model.use_onset_offset_heads:
+            Hs = d["Hs"]
+            dL, dLT = torch.zeros(Mpad, 384, **bf), torch.zeros(384, Mpad, **bf)
+            check(lib.mt_dlogits_pack_heads(ptr(dlogits), ptr(dL), 384, ptr(dLT), Mpad, 3, B, 88, T, _st()), "mt_dlogits_pack_heads")
+            sh = sv["sh"]
+            shT = torch.empty(_ru(Hs, 128) * Mpad, **bf)
+            check(lib.mt_transpose_bf16(ptr(sh), Hs, M, Hs, ptr(shT), Mpad, Hs, _st()), "mt_transpose_bf16")
+            gh = torch.empty(384, Hs, **f32)
+            _gemm(dLT, Mpad, shT, Mpad, gh, Hs, 264, Hs, Mpad)
+            ghb = torch.empty(264, **f32)
+            check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(ghb), 264, _st()), "mt_rowsum_bf16")
+            for i, n in enumerate(("frame", "onset", "offset")):
+                w = torch.empty(88, H, **f32)
+                _gather4(gh, i * 88 * Hs, w, (1, 1, 88, H), (0, 0, Hs, 1))
+                g[f"{n}_head.weight"], g[f"{n}_head.bias"] = w, ghb[i * 88:(i + 1) * 88].clone()
+            dsh = torch.empty(M, Hs, **f32)
+            _gemm(dL, 384, pk["heads_wT"], 384, dsh, Hs, M, Hs, 384)
+            dzs = torch.zeros(Mpad, Hs, **bf)
+            check(lib.mt_heads_relu_dropout_bwd(ptr(dsh), Hs, ptr(sh), Hs, ptr(dzs), Hs, M, H, float(ph), _st()), "mt_heads_relu_dropout_bwd")
+            dzsT = torch.empty(_ru(Hs, 128) * Mpad, **bf)
+            check(lib.mt_transpose_bf16(ptr(dzs), Hs, M, Hs, ptr(dzsT), Mpad, Hs, _st()), "mt_transpose_bf16")
+            gs = torch.empty(_ru(H, 128), Cp, **f32)
+            _gemm(dzsT, Mpad, featT, Mpad, gs, Cp, H, Cp, Mpad)
+            g["shared_fc.weight"], g["shared_fc.bias"] = torch.empty(H, comb, **f32), torch.empty(H, **f32)
+            _gather4(gs, 0, g["shared_fc.weight"], (1, 1, H, comb), (0, 0, Cp, 1))
+            check(lib.mt_rowsum_bf16(ptr(dzsT), Mpad, M, ptr(g["shared_fc.bias"]), H, _st()), "mt_rowsum_bf16")
+            _gemm(dzs, Hs, pk["shared_wT"], Hs, dfeat, comb, M, comb, Hs)
+        else:
+            if ph > 0.0:        # the dropout on the logits (cnn_rnn_model.py:346): same mask
+                dlogits = dlogits.clone()
+                check(lib.mt_dropout_f32(ptr(dlogits), dlogits.numel(), float(ph), seed, HEADS_LAYER_ID, _st()), "mt_dropout_f32")
+            dL, dLT = torch.zeros(Mpad, 128, **bf), torch.zeros(128, Mpad, **bf)
+            check(lib.mt_dlogits_pack(ptr(dlogits), ptr(dL), ptr(dLT), Mpad, B, 88, T, _st()), "mt_dlogits_pack")
+            gf = torch.empty(128, Cp, **f32)
+            _gemm(dLT, Mpad, featT, Mpad, gf, Cp, 88, Cp, Mpad)
+            g["fc.weight"], g["fc.bias"] = torch.empty(88, comb, **f32), torch.empty(88, **f32)
+            _gather4(gf, 0, g["fc.weight"], (1, 1, 88, comb), (0, 0, Cp, 1))
+            check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(g["fc.bias"]), 88, _st()), "mt_rowsum_bf16")
+            _gemm(dL, 128, pk["fc_wT"], 128, dfeat, comb, M, comb, 128)
+        # ---- LayerNorm + attention
+        if model.use_attention:
+            heads, dh_, dp, Ca, ld3, scale = d["heads"], d["dh"], d["dp"], d["Ca"], d["ld3"], d["scale"]
+            Tr, Tp = _ru(T, 128), _ru(T, 64)
+            dpr = _ru(dp, 128)
+            nsl = lib.mt_layernorm_residual_bwd_slices()
+            dxln = torch.empty(M, comb, **f32)
+            part = torch.zeros(nsl, 2, comb, **f32)
+            check(lib.mt_layernorm_residual_bwd(ptr(sv["r32"]), comb, ptr(sv["proj"]), comb, ptr(pk["ln_g"]), ptr(sv["ln_stats"]), ptr(dfeat), comb,
+                                                ptr(dxln), comb, ptr(part), M, comb, _st()), "mt_layernorm_residual_bwd")
+            lng = torch.empty(2, comb, **f32)
+            check(lib.mt_sum_slices_f32(ptr(part), 2 * comb, comb, nsl, ptr(lng), comb, 2, comb, _st()), "mt_sum_slices_f32")
+            g["attention_norm.weight"], g["attention_norm.bias"] = lng[0].clone(), lng[1].clone()
+            # proj
+            dpb = torch.zeros(Mpad, Cp, **bf)
+            check(lib.mt_f32_to_bf16_rows(ptr(dxln), comb, ptr(dpb), Cp, M, comb, 1.0, _st()), "mt_f32_to_bf16_rows")
+            dpT = torch.empty(_ru(Cp, 128) * Mpad, **bf)
+            check(lib.mt_transpose_bf16(ptr(dpb), Cp, M, Cp, ptr(dpT), Mpad, Cp, _st()), "mt_transpose_bf16")
+            aoT = torch.empty(_ru(Ca, 128) * Mpad, **bf)
+            check(lib.mt_transpose_bf16(ptr(sv["ao"]), Ca, M, Ca, ptr(aoT), Mpad, Ca, _st()), "mt_transpose_bf16")
+            gp = torch.empty(_ru(comb, 128), Ca, **f32)
+            _gemm(dpT, Mpad, aoT, Mpad, gp, Ca, comb, Ca, Mpad)
+            g["attention.proj.weight"], g["attention.proj.bias"] = torch.empty(comb, comb, **f32), torch.empty(comb, **f32)
+            _gather4(gp, 0, g["attention.proj.weight"], (1, comb, heads, dh_), (0, Ca, dp, 1))
+            check(lib.mt_rowsum_bf16(ptr(dpT), Mpad, M, ptr(g["attention.proj.bias"]), comb, _st()), "mt_rowsum_bf16")
+            dO = torch.zeros(Tr * B, Ca, **bf)
+            _gemm_bf16out(dpb, Cp, pk["proj_wT"], Cp, None, dO, Ca, M, Ca, Cp)
+            # dPd = dO V^T per (chunk, head)
+            qkv = sv["qkv"]
+            qk = qkv.reshape(-1)
+            dOf = dO.reshape(-1)
+            dPd = torch.empty(B * heads, T, Tp, **f32)
+            check(lib.mt_gemm_batched_f32(ptr(dOf), B * Ca, Ca, dp, ptr(qk[2 * Ca:]), B * ld3, ld3, dp, None, ptr(dPd), Tp, heads * T * Tp, T * Tp,
+                                          T, T, dp, B * heads, heads, _st()), "mt_gemm_batched_f32 (dO V^T)")
+            dS = torch.zeros(B * heads * T * Tp + Tr * Tp, **bf)
+            check(lib.mt_attn_clamped_bwd(ptr(sv["S"]), Tp, ptr(dPd), Tp, ptr(dS), Tp, T, B * heads * T, scale, ATTN_CLIP, float(p_drop), seed,
+                                          ATTN_LAYER_ID, _st()), "mt_attn_clamped_bwd")
+            dqkv = torch.zeros(Mpad, ld3, **bf)
+            dq = dqkv.reshape(-1)
+            # dV = Pd^T dO:  A = Pd^T [t'][t] per (chunk, head), W = dO^T [d][t]
+            PdT = torch.empty(B * heads, Tr, Tp, **bf)
+            check(lib.mt_transpose_bf16_batched(ptr(sv["Pd"]), Tp, T * Tp, T, Tp, ptr(PdT), Tp, Tr * Tp, Tr, B * heads, _st()), "mt_transpose_bf16_batched")
+            dOT = torch.empty(B * heads, dpr, Tp, **bf)
+            check(lib.mt_attn_transpose_v(ptr(dO), Ca, 0, ptr(dOT), B, T, Tp, heads, dp, _st()), "mt_attn_transpose_v")
+            check(lib.mt_gemm_batched_bf16out(ptr(PdT), Tp, heads * Tr * Tp, Tr * Tp, ptr(dOT), Tp, heads * dpr * Tp, dpr * Tp, None, ptr(dq[2 * Ca:]),
+                                              B * ld3, ld3, dp, T, dp, Tp, B * heads, heads, 0, _st()), "mt_gemm_batched_bf16out (dV)")
+            # dQ = dS K:  W = K^T [d][t']
+            KT = torch.empty(B * heads, dpr, Tp, **bf)
+            check(lib.mt_attn_transpose_v(ptr(qkv), ld3, Ca, ptr(KT), B, T, Tp, heads, dp, _st()), "mt_attn_transpose_v")
+            check(lib.mt_gemm_batched_bf16out(ptr(dS), Tp, heads * T * Tp, T * Tp, ptr(KT), Tp, heads * dpr * Tp, dpr * Tp, None, ptr(dq), B * ld3,
+                                              ld3, dp, T, dp, Tp, B * heads, heads, 0, _st()), "mt_gemm_batched_bf16out (dQ)")
+            # dK = dS^T Q:  A = dS^T [t'][t], W = Q^T [d][t]
+            dST = torch.empty(B * heads, Tr, Tp, **bf)
+            check(lib.mt_transpose_bf16_batched(ptr(dS), Tp, T * Tp, T, Tp, ptr(dST), Tp, Tr * Tp, Tr, B * heads, _st()), "mt_transpose_bf16_batched")
+            QT = torch.empty(B * heads, dpr, Tp, **bf)
+            check(lib.mt_attn_transpose_v(ptr(qkv), ld3, 0, ptr(QT), B, T, Tp, heads, dp, _st()), "mt_attn_transpose_v")
+            check(lib.mt_gemm_batched_bf16out(ptr(dST), Tp, heads * Tr * Tp, Tr * Tp, ptr(QT), Tp, heads * dpr * Tp, dpr * Tp, None, ptr(dq[Ca:]),
+                                              B * ld3, ld3, dp, T, dp, Tp, B * heads, heads, 0, _st()), "mt_gemm_batched_bf16out (dK)")
+            # qkv projection
+            dqT = torch.empty(_ru(ld3, 128) * Mpad, **bf)
+            check(lib.mt_transpose_bf16(ptr(dqkv), ld3, M, ld3, ptr(dqT), Mpad, ld3, _st()), "mt_transpose_bf16")
+            rbT = torch.empty(_ru(Cp, 128) * Mpad, **bf)
+            check(lib.mt_transpose_bf16(ptr(sv["rb"]), Cp, M, Cp, ptr(rbT), Mpad, Cp, _st()), "mt_transpose_bf16")
+            gq = torch.empty(_ru(ld3, 128), Cp, **f32)
+            _gemm(dqT, Mpad, rbT, Mpad, gq, Cp, ld3, Cp, Mpad)
+            g["attention.qkv.weight"] = torch.empty(3 * comb, comb, **f32)
+            for w3 in range(3):
+                _gather4(gq, w3 * Ca * Cp, g["attention.qkv.weight"][w3 * comb:(w3 + 1) * comb], (1, heads, dh_, comb), (0, dp * Cp, Cp, 1))
+            gqb = torch.empty(ld3, **f32)
+            check(lib.mt_rowsum_bf16(ptr(dqT), Mpad, M, ptr(gqb), ld3, _st()), "mt_rowsum_bf16")
+            g["attention.qkv.bias"] = torch.empty(3 * comb, **f32)
+            _gather4(gqb, 0, g["attention.qkv.bias"], (1, 3, heads, dh_), (0, Ca, dp, 1))
+            dra = torch.empty(M, comb, **f32)
+            _gemm(dqkv, ld3, pk["qkv_wT"], ld3, dra, comb, M, comb, ld3)
+            dr = torch.empty(M, comb, **f32)
+            check(lib.mt_axpby_rows_f32(ptr(dxln), comb, ptr(dra), comb, ptr(dr), comb, M, comb, 1.0, 1.0, _st()), "mt_axpby_rows_f32")
+        else:
+            dr = dfeat
+        # ---- LSTMs: main stack and the local layer; layer 0's gate gradients side by side -> one input-gradient GEMM
+        ldg = 8 * Hp + 8 * Hlp
+        dG0 = torch.zeros(Mpad, ldg, **bf)
+        drf = dr.reshape(-1)
+        dh_m = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
+        check(lib.mt_lstm_dh_relayout(ptr(drf), comb, ptr(dh_m), B, T, Hp, H, 0.0, seed, 0, _st()), "mt_lstm_dh_relayout")
+        dh_l = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hlp) // 4, **f32)
+        check(lib.mt_lstm_dh_relayout(ptr(drf[2 * H:]), comb, ptr(dh_l), B, T, Hlp, Hl, 0.0, seed, 0, _st()), "mt_lstm_dh_relayout")
+
+        def k0_gather(Hx, Hxp):
+            def f(gwi, di):
+                wi = torch.empty(4 * Hx, 256 * F3, **f32)
+                _gather4(gwi, di * 4 * Hxp * K0, wi, (4, Hx, 256, F3), (Hxp * K0, K0, 1, 256))
+                return wi
+            return f
+        pm = p_drop if L > 1 else 0.0
+        _lstm_backward(sv["main"], dh_m, pk["m_whh"], pk["m_wihT"], L, Hp, H, K0, K1, B, T, pm, seed, 0, dev, slots, dG0, ldg, 0, None, g,
+                       "rnn_main", k0_gather(H, Hp))
+        _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev, slots, dG0, ldg,
+                       8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp))
+        dX0 = torch.empty(M, K0, **f32)
+        _gemm(dG0, ldg, pk["ml_wihT"], ldg, dX0, K0, M, K0, ldg)
+        # ---- freq_aware_conv
+        masks = sv["masks"]
+        z256 = pk["zeros256"]
+        dzf = torch.empty(B * F2 * T, 256, **bf)
+        g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"] = torch.empty(256, **f32), torch.empty(256, **f32)
+        _bn_act_bwd(None, 0, dX0, K0, sv["zf"], sv["sf"], None, None, masks[2], dzf, None,
+                    (g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"], None, None), B, F2, T, 256, 1, 1, dev)
+        dr2 = torch.empty(B * F2 * T, 128, **bf)
+        _conv(dzf, None, pk["fa_wdA"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256)
+        _conv(dzf.reshape(-1)[128:], None, pk["fa_wdB"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256, accum=1)
+        pl = _Planes(B, F2, T, 3, dev)
+        g["freq_aware_conv.0.weight"] = torch.empty(256, 128, 7, 3, **f32)
+        _conv_wgrad(pl, pl.make(dzf, 256, 256, (1,)), pl.make(sv["r2"], 128, 128, (2, 1, 0)), 256, 128, 7, (0, 1, 2), g["freq_aware_conv.0.weight"])
+        g["freq_aware_conv.0.bias"] = torch.zeros(256, **f32)          # a conv bias in front of a BatchNorm: analytically zero
+        # ---- residual blocks, top down
+        dout = dr2
+        for name, mask_i in (("rb2", 1), ("rb1", 0)):
+            st = sv[name]
+            cin, cout, pool, Fin, xin = st["cin"], st["cout"], st["pool"], st["Fin"], st["xin"]
+            N = B * Fin * T
+            dz2, dzs = torch.empty(N, cout, **bf), torch.empty(N, cout, **bf)
+            gr = {k: torch.empty(cout, **f32) for k in ("bn2.weight", "bn2.bias", "skip.1.weight", "skip.1.bias", "bn1.weight", "bn1.bias")}
+            _bn_act_bwd(dout, cout, None, 0, st["z2"], st["s2"], st["zs"], st["ss"], st["mask"], dz2, dzs,
+                        (gr["bn2.weight"], gr["bn2.bias"], gr["skip.1.weight"], gr["skip.1.bias"]), B, Fin, T, cout, 1, pool, dev)
+            dy1 = torch.empty(N, cout, **bf)
+            _conv(dz2, None, pk[name + "c2_wd"], z256, dy1, B, Fin, T, cout, 0, cout, 3)
+            dz1 = torch.empty(N, cout, **bf)
+            _bn_act_bwd(dy1, cout, None, 0, st["z1"], st["s1"], None, None, None, dz1, None, (gr["bn1.weight"], gr["bn1.bias"], None, None),
+                        B, Fin, T, cout, 1, 0, dev)
+            cin_p = max(cin, 64)
+            dxin = torch.empty(N, cin_p, **bf)
+            _conv(dz1, dzs, pk[name + "c1s_wd"], z256, dxin, B, Fin, T, cout, cout, cin_p, 3)
+            # weight gradients
+            pl = _Planes(B, Fin, T, 1, dev)
+            xP = pl.make(xin, cin, cin, (2, 1, 0))
+            yP = pl.make(st["y1"], cout, cout, (2, 1, 0))
+            pfx = "res_block1" if name == "rb1" else "res_block2"
+            g[pfx + ".conv1.weight"] = _conv_wgrad(pl, pl.make(dz1, cout, cout, (1,)), xP, cout, cin, 3, (0, 1, 2), torch.empty(cout, cin, 3, 3, **f32))
+            g[pfx + ".conv2.weight"] = _conv_wgrad(pl, pl.make(dz2, cout, cout, (1,)), yP, cout, cout, 3, (0, 1, 2), torch.empty(cout, cout, 3, 3, **f32))
+            g[pfx + ".skip.0.weight"] = _conv_wgrad(pl, pl.make(dzs, cout, cout, (1,)), xP, cout, cin, 1, (1,), torch.empty(cout, cin, 1, 1, **f32))
+            for k in ("conv1.bias", "conv2.bias", "skip.0.bias"):
+                g[f"{pfx}.{k}"] = torch.zeros(cout, **f32)
+            for k, v in gr.items():
+                g[f"{pfx}.{k}"] = v
+            dout = dxin
+        # ---- conv1 (z1 recomputed from the input); dout = d a1, [B][F1][T][64] with channels 0..31 valid
+        g["conv1.0.weight"], g["conv1.0.bias"] = torch.empty(32, 1, 3, 3, **f32), torch.empty(32, **f32)
+        g["conv1.1.weight"], g["conv1.1.bias"] = torch.empty(32, **f32), torch.empty(32, **f32)
+        sums = torch.zeros(512, device=dev, dtype=torch.float64)
+        check(lib.mt_conv1_bwd(ptr(x), ptr(pk["w1"]), ptr(pk["b1"]), ptr(sv["mean1"]), ptr(sv["rstd1"]), ptr(pk["g1"]), ptr(pk["be1"]),
+                               ptr(dout), 64, ptr(sums[128:]), ptr(g["conv1.0.weight"]), ptr(g["conv1.0.bias"]), ptr(g["conv1.1.weight"]),
+                               ptr(g["conv1.1.bias"]), B, F, T, _st()), "mt_conv1_bwd")
+    return g
+
+
+class CnnRnnLargeTrainFn(torch.autograd.Function):
+    """logits [NH][B][88][T] = CNNRNNModelLarge(x) in train mode; backward returns the gradient of every parameter."""
+
+    @staticmethod
+    def forward(ctx, model, x, p_drop, seed, p2d, names, *params):
+        logits, sv = forward_train_large(model, x, p_drop, seed, p2d)
+        ctx.model, ctx.sv, ctx.names = model, sv, names
+        model._train_sync = (sv["sync_all"], sv["sync_stride"])
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        g = backward_train_large(ctx.model, ctx.sv, dlogits)
+        ctx.sv = None
+        return (None, None, None, None, None, None) + tuple(g[n] for n in ctx.names)
+
+
+def train_forward_large(model, x: torch.Tensor, return_all_heads: bool = False):
+    names = [n for n, _ in model.named_parameters()]
+    params = [p for _, p in model.named_parameters()]
+    p = float(getattr(model, "dropout_p", 0.0))
+    p2d = tuple(float(v) for v in getattr(model, "dropout2d_p", DROPOUT2D_P))
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (p > 0.0 or any(v > 0.0 for v in p2d)) else 0
+    if torch.is_grad_enabled():
+        out = CnnRnnLargeTrainFn.apply(model, x, p, seed, p2d, names, *params)
+    else:
+        out, sv = forward_train_large(model, x, p, seed, p2d)
+        model._train_sync = (sv["sync_all"], sv["sync_stride"])
+    if model.use_onset_offset_heads and return_all_heads:
+        return {"frame": out[0], "onset": out[1], "offset": out[2]}
+    return out[0]

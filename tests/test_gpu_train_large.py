@@ -1,0 +1,413 @@
+"""GPU parity of the CNNRNNModelLarge training step: the HIP train-mode forward / backward (through the
+C ABI) against the reference's own gradients (tests/golden/train_step_large.npz, written by make_golden_train.py from the
+reference's modules and its train_one_epoch), against torch autograd on the CPU oracle at other shapes / variants, and
+unit tests of the pieces (BatchNorm + activation forward / backward, convolution weight gradients over position planes,
+attention softmax backward with the clamp, LayerNorm backward) against torch autograd.
+
+Tolerances as tests/test_gpu_train.py: GEMM / conv operands are bf16 (f32 accumulate), so a gradient tensor is compared
+relative to its own largest entry and the whole flat gradient by its cosine to the reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model_ref as R
+
+GRAD_REL = 4e-2        # per tensor, against the oracle with the HIP path's bf16 rounding points
+GRAD_REL_FP32 = 1e-1   # ... against the fp32 reference
+GRAD_COS = 0.999
+GRAD_COS_FP32 = 0.995
+LOGIT_TOL = 3e-2
+# a conv bias in front of a BatchNorm has an analytically zero gradient (the reference's is rounding noise)
+ZERO_GRAD = ("conv1.0.bias", "res_block1.conv1.bias", "res_block1.conv2.bias", "res_block1.skip.0.bias", "res_block2.conv1.bias",
+             "res_block2.conv2.bias", "res_block2.skip.0.bias", "freq_aware_conv.0.bias")
+
+
+@pytest.fixture(scope="module")
+def mta():
+    import music_transcription_amd as m
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return m
+
+
+def _lib():
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    return lib, check, ptr, stream_ptr
+
+
+def _mel_in(B, nm, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(B, 1, nm, T, generator=g) * 60.0 - 70.0 + 10.0 * torch.randn(B, 1, nm, 1, generator=g))
+
+
+def _roll_in(B, T, seed, p=0.04):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(B, 88, T, generator=g) < p).float()
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+# ------------------------------------------------------------------------------------------------ kernel unit tests
+@pytest.mark.parametrize("C,F_,T,B,two,relu,pool,p2d,xrows", [(64, 6, 21, 2, True, 1, 1, 0.0, False), (128, 5, 17, 3, True, 1, 0, 0.3, False),
+                                                                (256, 7, 19, 2, False, 1, 1, 0.2, True), (32, 4, 70, 1, False, 1, 0, 0.0, False),
+                                                                (64, 8, 33, 2, False, 0, 0, 0.0, False)])
+def test_bn_act_forward_backward_vs_autograd(mta, C, F_, T, B, two, relu, pool, p2d, xrows):
+    lib, check, ptr, st = _lib()
+    g = torch.Generator().manual_seed(C + F_ + T)
+    za = _bf(torch.randn(B, F_, T, C, generator=g) * 1.5 + 0.3)
+    zb = _bf(torch.randn(B, F_, T, C, generator=g)) if two else None
+    par = lambda: (torch.randn(C, generator=g) * 0.2, 1.0 / (0.5 + torch.rand(C, generator=g)), 1.0 + 0.3 * torch.randn(C, generator=g),
+                   0.2 * torch.randn(C, generator=g))
+    # batch statistics (what makes the BN backward's mean terms right): mean / rstd of the tensors themselves
+    def stats(z):
+        m = z.mean(dim=(0, 1, 2))
+        v = z.var(dim=(0, 1, 2), unbiased=False)
+        return m, 1.0 / torch.sqrt(v + 1e-5)
+    ma, ra = stats(za)
+    _, _, ga, ba = par()
+    if two:
+        mb, rb_ = stats(zb)
+        _, _, gb, bb = par()
+    Fo = F_ // 2 if pool else F_
+    mask = None
+    if p2d > 0:
+        mask = torch.empty(B, C, device="cuda")
+        check(lib.mt_dropout2d_mask(ptr(mask), B, C, p2d, 123, 7, st()))
+        frac = float((mask == 0).float().mean())
+        assert abs(frac - p2d) < 0.15 and torch.all((mask == 0) | ((mask - 1 / (1 - p2d)).abs() < 1e-6))
+    dev = lambda t: None if t is None else t.cuda().contiguous()
+    zad, zbd = dev(za.bfloat16()), dev(zb.bfloat16() if two else None)
+    sa = [dev(v) for v in (ma, ra, ga, ba)]
+    sb = [dev(v) for v in (mb, rb_, gb, bb)] if two else [None] * 4
+    ldx = Fo * C + 8
+    out = torch.zeros(B * T if xrows else B * Fo * T, ldx if xrows else C, dtype=torch.bfloat16, device="cuda")
+    check(lib.mt_bn_act_fwd(ptr(zad), *(ptr(v) for v in sa), ptr(zbd), *(ptr(v) for v in sb), ptr(mask), ptr(out), 1 if xrows else 0, ldx,
+                            B, F_, T, C, relu, pool, st()), "fwd")
+    # reference with autograd (channels-first torch ops on the same bf16-rounded inputs)
+    zar = za.clone().requires_grad_(True)
+    zbr = zb.clone().requires_grad_(True) if two else None
+    gar, bar = ga.clone().requires_grad_(True), ba.clone().requires_grad_(True)
+    def bn(z, gam, bet):
+        m = z.mean(dim=(0, 1, 2)); v = z.var(dim=(0, 1, 2), unbiased=False)
+        return (z - m) / torch.sqrt(v + 1e-5) * gam + bet
+    y = bn(zar, gar, bar)
+    if two:
+        gbr, bbr = gb.clone().requires_grad_(True), bb.clone().requires_grad_(True)
+        y = y + bn(zbr, gbr, bbr)
+    if relu:
+        y = torch.relu(y)
+    if pool:
+        y = F.max_pool2d(y.permute(0, 3, 1, 2), kernel_size=(2, 1)).permute(0, 2, 3, 1)
+    if mask is not None:
+        y = y * mask.cpu()[:, None, None, :]
+    if xrows:
+        got = out.float().cpu()[:, :Fo * C].reshape(T, B, Fo, C).permute(1, 2, 0, 3)
+    else:
+        got = out.float().cpu().reshape(B, Fo, T, C)
+    assert (got - y.detach()).abs().max() < 2e-2 * max(1.0, float(y.abs().max()))
+    # backward
+    dout = torch.randn(B, Fo, T, C, generator=g)
+    y.backward(dout)
+    sums = torch.empty(3 * C, dtype=torch.float64, device="cuda")
+    dza = torch.empty(B * F_ * T, C, dtype=torch.bfloat16, device="cuda")
+    dzb = torch.empty_like(dza) if two else None
+    gr = [torch.empty(C, device="cuda") for _ in range(4)]
+    if xrows:
+        dx = torch.zeros(T * B, ldx, device="cuda")
+        dx[:, :Fo * C] = dout.permute(2, 0, 1, 3).reshape(T * B, Fo * C).cuda()
+        dcl = None
+    else:
+        dcl, dx = dout.bfloat16().cuda().contiguous(), None
+        dout = dcl.float().cpu()
+        # (the bf16 rounding of the incoming gradient is part of the contract: redo the reference backward with it)
+        for t_ in (zar, zbr, gar, bar) + ((gbr, bbr) if two else ()):
+            if t_ is not None:
+                t_.grad = None
+        y2 = bn(zar, gar, bar) + (bn(zbr, gbr, bbr) if two else 0.0)
+        y2 = torch.relu(y2) if relu else y2
+        y2 = F.max_pool2d(y2.permute(0, 3, 1, 2), kernel_size=(2, 1)).permute(0, 2, 3, 1) if pool else y2
+        y2 = y2 * mask.cpu()[:, None, None, :] if mask is not None else y2
+        y2.backward(dout)
+    check(lib.mt_bn_act_bwd(ptr(dcl), C, ptr(dx), ldx, ptr(zad), *(ptr(v) for v in sa), ptr(zbd), *(ptr(v) for v in sb), ptr(mask), ptr(sums),
+                            ptr(dza), C, None, ptr(dzb), C, ptr(gr[0]), ptr(gr[1]), ptr(gr[2]) if two else None, ptr(gr[3]) if two else None,
+                            B, F_, T, C, relu, pool, st()), "bwd")
+    sc = float(zar.grad.abs().max())
+    assert (dza.float().cpu().reshape(B, F_, T, C) - zar.grad).abs().max() < 1.5e-2 * sc
+    assert (gr[0].cpu() - gar.grad).abs().max() < 2e-3 * max(1.0, float(gar.grad.abs().max()))
+    assert (gr[1].cpu() - bar.grad).abs().max() < 2e-3 * max(1.0, float(bar.grad.abs().max()))
+    if two:
+        assert (dzb.float().cpu().reshape(B, F_, T, C) - zbr.grad).abs().max() < 1.5e-2 * float(zbr.grad.abs().max())
+        assert (gr[2].cpu() - gbr.grad).abs().max() < 2e-3 * max(1.0, float(gbr.grad.abs().max()))
+        assert (gr[3].cpu() - bbr.grad).abs().max() < 2e-3 * max(1.0, float(bbr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,F_,T,Cin,Cout,KH", [(2, 6, 21, 32, 64, 3), (1, 9, 70, 64, 128, 3), (2, 8, 33, 128, 256, 7), (3, 5, 17, 64, 64, 3)])
+def test_conv_weight_gradient_over_position_planes(mta, B, F_, T, Cin, Cout, KH):
+    """mt_cl_to_planar + batched GEMM == torch's conv2d weight gradient (and the 1x1 skip's), bf16 operands."""
+    from music_transcription_amd import train_step_large as TL
+    g = torch.Generator().manual_seed(B * 100 + T + Cin)
+    x = _bf(torch.randn(B, F_, T, Cin, generator=g))
+    dz = _bf(torch.randn(B, F_, T, Cout + 8, generator=g))              # with a position pitch wider than the channel count
+    ph = KH // 2
+    pl = TL._Planes(B, F_, T, ph, torch.device("cuda"))
+    with torch.cuda.device(0):
+        xP = pl.make(x.bfloat16().cuda().contiguous(), Cin, Cin, (2, 1, 0))
+        dP = pl.make(dz.bfloat16().cuda().contiguous(), Cout + 8, Cout, (1,))
+        out = TL._conv_wgrad(pl, dP, xP, Cout, Cin, KH, (0, 1, 2), torch.empty(Cout, Cin, KH, 3, device="cuda"))
+        out1 = TL._conv_wgrad(pl, dP, xP, Cout, Cin, 1, (1,), torch.empty(Cout, Cin, 1, 1, device="cuda")) if KH == 3 else None
+    w = torch.zeros(Cout, Cin, KH, 3, requires_grad=True)
+    xc, dzc = x.permute(0, 3, 1, 2), dz[..., :Cout].permute(0, 3, 1, 2)
+    F.conv2d(xc, w, padding=(ph, 1)).backward(dzc)
+    sc = float(w.grad.abs().max())
+    assert (out.cpu() - w.grad).abs().max() < 2e-3 * sc, ((out.cpu() - w.grad).abs().max(), sc)
+    if out1 is not None:
+        w1 = torch.zeros(Cout, Cin, 1, 1, requires_grad=True)
+        F.conv2d(xc, w1).backward(dzc)
+        assert (out1.cpu() - w1.grad).abs().max() < 2e-3 * float(w1.grad.abs().max())
+
+
+def test_conv_cl_channel_slices_and_accumulate(mta):
+    """mt_conv_cl_ex: the 256-channel input gradient of freq_aware_conv as two accumulating calls over channel halves."""
+    lib, check, ptr, st = _lib()
+    from music_transcription_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    B, F_, T = 2, 9, 37
+    dz = _bf(torch.randn(B, F_, T, 256, generator=g))
+    w = _bf(torch.randn(256, 128, 7, 3, generator=g) * 0.05)           # forward weights [co][ci][kh][kw]
+    from music_transcription_amd.train_step_large import _conv_dgrad_w
+    wa, wb = _conv_dgrad_w(w[:128]).bfloat16().cuda().contiguous(), _conv_dgrad_w(w[128:]).bfloat16().cuda().contiguous()
+    dzd = dz.bfloat16().cuda().contiguous()
+    out = torch.empty(B * F_ * T, 128, dtype=torch.bfloat16, device="cuda")
+    zero = torch.zeros(256, device="cuda")
+    check(lib.mt_conv_cl_ex(ptr(dzd), 256, None, 0, ptr(wa), ptr(zero), ptr(out), B, F_, T, 128, 0, 128, 7, 0, 0, 0, 0, 0, L.DT_BF16, st()))
+    check(lib.mt_conv_cl_ex(ptr(dzd.reshape(-1)[128:]), 256, None, 0, ptr(wb), ptr(zero), ptr(out), B, F_, T, 128, 0, 128, 7, 0, 0, 0, 0, 1,
+                            L.DT_BF16, st()))
+    xin = torch.zeros(B, 128, F_, T, requires_grad=True)
+    F.conv2d(xin, w, padding=(3, 1)).backward(dz.permute(0, 3, 1, 2))
+    ref = xin.grad.permute(0, 2, 3, 1)
+    assert (out.float().cpu().reshape(B, F_, T, 128) - ref).abs().max() < 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_attention_softmax_forward_backward_vs_autograd(mta, p):
+    lib, check, ptr, st = _lib()
+    g = torch.Generator().manual_seed(3)
+    rows, T, Tp = 10, 100, 128
+    S = torch.randn(rows, Tp, generator=g) * 40.0                       # scaled scores reach well beyond the +-10 clamp
+    scale, clip = 0.2, 10.0
+    Sd = S.cuda()
+    P = torch.empty(rows, Tp, dtype=torch.bfloat16, device="cuda")
+    check(lib.mt_attn_softmax_train(ptr(Sd), Tp, ptr(P), Tp, T, rows, scale, clip, p, 77, 200, st()))
+    Sr = S[:, :T].clone().requires_grad_(True)
+    A = torch.softmax(torch.clamp(Sr * scale, -clip, clip), dim=-1)
+    got = P.float().cpu()
+    assert torch.all(got[:, T:] == 0)
+    if p == 0.0:
+        assert (got[:, :T] - A.detach()).abs().max() < 4e-3 * float(A.max())
+        keep = torch.ones(rows, T)
+    else:
+        keep = (got[:, :T] != 0).float()                                # the kernel's mask (regenerated by the backward kernel)
+        assert abs(float(keep.mean()) - (1 - p)) < 0.08
+        assert (got[:, :T] - A.detach() * keep / (1 - p)).abs().max() < 8e-3 * float(A.max()) / (1 - p)
+    dPd = torch.randn(rows, Tp, generator=g)
+    (A * keep / (1 - p)).backward(dPd[:, :T])
+    dS = torch.empty(rows, Tp, dtype=torch.bfloat16, device="cuda")
+    check(lib.mt_attn_clamped_bwd(ptr(Sd), Tp, ptr(dPd.cuda()), Tp, ptr(dS), Tp, T, rows, scale, clip, p, 77, 200, st()))
+    gd = dS.float().cpu()
+    assert torch.all(gd[:, T:] == 0)
+    assert (gd[:, :T] - Sr.grad).abs().max() < 1e-2 * float(Sr.grad.abs().max())
+    outside = (Sr.detach() * scale).abs() > clip
+    assert outside.float().mean() > 0.1 and torch.all(gd[:, :T][outside] == 0)        # the clamp's zero-gradient region is exercised
+
+
+def test_layernorm_residual_forward_backward_vs_autograd(mta):
+    lib, check, ptr, st = _lib()
+    g = torch.Generator().manual_seed(9)
+    rows, n, ld = 300, 48, 64
+    a, pj = torch.randn(rows, n, generator=g), torch.randn(rows, n, generator=g) * 0.5
+    gam, bet = 1.0 + 0.2 * torch.randn(n, generator=g), 0.1 * torch.randn(n, generator=g)
+    y = torch.zeros(rows, ld, dtype=torch.bfloat16, device="cuda")
+    stats = torch.empty(rows, 2, device="cuda")
+    ad, pd_, gd, bd = a.cuda(), pj.cuda(), gam.cuda(), bet.cuda()
+    check(lib.mt_layernorm_residual_train(ptr(ad), n, ptr(pd_), n, ptr(gd), ptr(bd), ptr(y), ld, ptr(stats), rows, n, 1e-6, st()))
+    ar, gr, br = a.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    ref = F.layer_norm(ar + pj, (n,), gr, br, 1e-6)
+    assert (y.float().cpu()[:, :n] - ref.detach()).abs().max() < 2e-2
+    dy = torch.randn(rows, n, generator=g)
+    ref.backward(dy)
+    nsl = lib.mt_layernorm_residual_bwd_slices()
+    dx = torch.empty(rows, n, device="cuda")
+    part = torch.zeros(nsl, 2, n, device="cuda")
+    check(lib.mt_layernorm_residual_bwd(ptr(ad), n, ptr(pd_), n, ptr(gd), ptr(stats), ptr(dy.cuda()), n, ptr(dx), n, ptr(part), rows, n, st()))
+    assert (dx.cpu() - ar.grad).abs().max() < 1e-4 * max(1.0, float(ar.grad.abs().max()))
+    red = part.sum(0).cpu()
+    assert (red[0] - gr.grad).abs().max() < 1e-3 and (red[1] - br.grad).abs().max() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ whole training step
+def _golden_batches(g):
+    nm, H, L, B, T, sw, sx, nb = [int(v) for v in g["cfg"]]
+    out = []
+    for k in range(nb):
+        mel, roll = _mel_in(B, nm, T, sx + k), _roll_in(B, T, sx + 100 + k, 0.1)
+        lengths = torch.tensor([T, T - 7, T - 15][:B], dtype=torch.int64)
+        for b in range(B):
+            mel[b, :, :, lengths[b]:] = 0.0
+            roll[b, :, lengths[b]:] = 0.0
+        out.append((mel, roll, lengths))
+    return out
+
+
+def _hip_large(mta, nm, H, L, seed, dropout=0.0, p2d=(0.0, 0.0, 0.0), **kw):
+    m = mta.TranscriptionModel(model_type="cnn_rnn_large", n_mels=nm, hidden_size=H, num_layers=L, dropout=dropout, device="cuda", **kw)
+    sd = R.make_state_dict("cnn_rnn_large", nm, H, L, seed, use_attention=kw.get("use_attention", True),
+                           use_heads=kw.get("use_onset_offset_heads", True))
+    m.load_state_dict(sd, strict=True)
+    m.model.dropout2d_p = p2d
+    return m, sd
+
+
+def _compare_grads(named_grads, ref, prefix="model."):
+    flat_a, flat_b, worst = [], [], {}
+    for k, gr in ref.items():
+        a = named_grads[k].detach().float().cpu().numpy()
+        b = np.asarray(gr, dtype=np.float32)
+        assert a.shape == b.shape, (k, a.shape, b.shape)
+        short = k[len(prefix):] if k.startswith(prefix) else k
+        if short in ZERO_GRAD:
+            continue
+        scale = np.abs(b).max()
+        if scale == 0.0:                       # a head without gradient (frame-only loss): must be exactly zero here too
+            assert np.abs(a).max() == 0.0, k
+            continue
+        worst[k] = float(np.abs(a - b).max() / scale)
+        flat_a.append(a.ravel()); flat_b.append(b.ravel())
+    fa, fb = np.concatenate(flat_a), np.concatenate(flat_b)
+    return worst, float(fa @ fb / (np.linalg.norm(fa) * np.linalg.norm(fb)))
+
+
+def _oracle_grads(sd, mel, roll, lengths, emulate_bf16, all_heads=False):
+    sdo = {k: v.clone() for k, v in sd.items()}
+    keys = [k for k, v in sdo.items() if v.dtype.is_floating_point and "running_" not in k]
+    for k in keys:
+        sdo[k].requires_grad_(True)
+    lo = R.cnnrnn_large_forward(sdo, mel, return_all_heads=all_heads, o=R.Opts(gemm_bf16=emulate_bf16), train=True)
+    R.compute_loss(lo, roll, lengths).backward()
+    grads = {k: (sdo[k].grad.numpy() if sdo[k].grad is not None else np.zeros(tuple(sdo[k].shape), np.float32)) for k in keys}
+    return lo, grads
+
+
+def _report(tag, worst, cos):
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    print(f"\n[{tag}] cos={cos:.6f} worst: " + ", ".join(f"{k.replace('model.', '')}={v:.3g}" for k, v in top))
+
+
+def test_large_train_step_matches_reference_golden(mta, golden_dir):
+    g = np.load(os.path.join(golden_dir, "train_step_large.npz"))
+    nm, H, L, B, T, sw, sx, nb = [int(v) for v in g["cfg"]]
+    data = _golden_batches(g)
+    m, sd = _hip_large(mta, nm, H, L, sw)
+    m.train()
+    mel, roll, lengths = data[0]
+    logits = m(mel.cuda())
+    assert logits.requires_grad and logits.shape == (B, 88, T)
+    assert np.abs(logits.detach().cpu().numpy() - g["logits0"]).max() < LOGIT_TOL
+    loss = m.compute_loss(logits, roll.cuda(), lengths)
+    assert abs(loss.item() - float(g["loss0"])) < 2e-3
+    loss.backward()
+    m.model.raise_on_train_handoff_timeout()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    ref = {k[len("grad::"):]: g[k] for k in g.files if k.startswith("grad::")}
+    assert set(ref) == set(grads)
+    worst, cos = _compare_grads(grads, ref)
+    _report("large vs fp32 reference golden", worst, cos)
+    bad = {k: v for k, v in worst.items() if v > GRAD_REL_FP32}
+    assert not bad and cos > GRAD_COS_FP32, (bad, cos)
+    _, ref_emu = _oracle_grads(sd, mel, roll, lengths, True)
+    worst, cos = _compare_grads(grads, ref_emu)
+    _report("large vs bf16-emulating oracle", worst, cos)
+    bad = {k: v for k, v in worst.items() if v > GRAD_REL}
+    assert not bad and cos > GRAD_COS, (bad, cos)
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+    assert abs(gn - float(g["gradnorm0"])) < 3e-2 * float(g["gradnorm0"])
+    sdm = m.state_dict()
+    for k in g.files:                        # BatchNorm running statistics after the step's forward
+        if k.startswith("bn0::") and "num_batches" not in k:
+            a, b = sdm[k[len("bn0::"):]].cpu().numpy(), g[k]
+            assert np.abs(a - b).max() <= 3e-3 * max(np.abs(b).max(), 1.0), k
+        elif k.startswith("bn0::"):
+            assert int(sdm[k[len("bn0::"):]]) == int(g[k])
+
+
+def test_large_training_loop_matches_reference_losses(mta, golden_dir):
+    """train_one_epoch of this package over the golden's 3 batches, CNNRNNModelLarge (what example.sh:22 trains)."""
+    g = np.load(os.path.join(golden_dir, "train_step_large.npz"))
+    nm, H, L, B, T, sw, sx, nb = [int(v) for v in g["cfg"]]
+    data = [(a.cuda(), b.cuda(), c) for a, b, c in _golden_batches(g)]
+    m, _ = _hip_large(mta, nm, H, L, sw)
+    opt = mta.make_optimizer(m, lr=float(g["lr"]))
+    avg, losses = mta.train_one_epoch(m, data, opt, torch.device("cuda"), max_grad_norm=1.0)
+    assert np.abs(np.array(losses) - g["losses"]).max() < 3e-3, (losses, g["losses"])
+    assert abs(avg - float(g["avg_loss"])) < 3e-3
+    # the packed inference weights follow the optimizer, and eval mode agrees with the oracle on the trained weights
+    m.eval()
+    with torch.no_grad():
+        after = m(data[0][0]).cpu()
+        sdo = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+        ref = R.cnnrnn_large_forward(sdo, data[0][0].cpu())
+    assert (after - ref).abs().max() < LOGIT_TOL
+
+
+@pytest.mark.parametrize("kw,all_heads", [(dict(), True), (dict(use_attention=False), False), (dict(use_onset_offset_heads=False), False)])
+def test_large_variants_and_dict_loss_vs_oracle_autograd(mta, kw, all_heads):
+    """The dict loss path (frame / onset / offset, transcription_model.py:164-194) and the --no_attention / single-head
+    variants against torch autograd on the CPU oracle; other shapes than the golden (padded hidden sizes, odd T)."""
+    nm, H, L, B, T = 40, 24, 2, 2, 29
+    m, sd = _hip_large(mta, nm, H, L, seed=31, **kw)
+    m.train()
+    mel, roll = _mel_in(B, nm, T, 3), _roll_in(B, T, 4, 0.1)
+    lengths = torch.tensor([T, T - 6], dtype=torch.int64)
+    out = m(mel.cuda(), return_all_heads=all_heads)
+    loss = m.compute_loss(out, roll.cuda(), lengths)
+    loss.backward()
+    m.model.raise_on_train_handoff_timeout()
+    grads = {"model." + k: p.grad for k, p in m.model.named_parameters()}
+    lo, ref = _oracle_grads(sd, mel, roll, lengths, True, all_heads)
+    if all_heads:
+        for k in ("frame", "onset", "offset"):
+            assert (out[k].detach().cpu() - lo[k].detach()).abs().max() < 1e-2
+    else:
+        assert (out.detach().cpu() - lo.detach()).abs().max() < 1e-2
+    worst, cos = _compare_grads(grads, ref)
+    _report(f"variant {kw} all_heads={all_heads}", worst, cos)
+    bad = {k: v for k, v in worst.items() if v > GRAD_REL}
+    assert not bad and cos > GRAD_COS, (bad, cos)
+
+
+def test_large_train_with_dropout_runs_and_is_seeded(mta):
+    nm, H, L, B, T = 32, 16, 2, 3, 24
+    m, _ = _hip_large(mta, nm, H, L, seed=5, dropout=0.2, p2d=(0.1, 0.1, 0.15))
+    m.train()
+    mel, roll = _mel_in(B, nm, T, 1).cuda(), _roll_in(B, T, 2, 0.1).cuda()
+    outs = []
+    for seed in (1, 1, 2):
+        torch.manual_seed(seed)
+        for p in m.parameters():
+            p.grad = None
+        lg = m(mel)
+        m.compute_loss(lg, roll).backward()
+        gflat = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+        assert torch.isfinite(lg).all() and torch.isfinite(gflat).all()
+        outs.append((lg.detach().clone(), gflat.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-7)     # same seed, same masks
+    assert not torch.equal(outs[0][0], outs[2][0])                                                                # another seed, other masks
+    m.eval()
+    with torch.no_grad():
+        ev = m(mel)
+    assert not torch.equal(ev, outs[0][0])
