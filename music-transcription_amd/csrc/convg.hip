@@ -244,10 +244,18 @@ static int cg_launch(const ConvGArgs& a, hipStream_t st) {
 using namespace mt;
 
 // out_mode 0: channels-last activation [B][Fout][T][Cout] (16-bit, operand type dt); 1: GEMM-A rows X[(t*B+b)*ldx + fo*Cout + co].
+static size_t cg_lds_bytes(const ConvGArgs& a, int KC, int BN_) {
+    const int nc1 = a.C1 / 8, pr1 = 16 / nc1 > 0 ? 16 / nc1 : 1;
+    const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
+    return (size_t)(CG_TF + a.KH - 1) * pitch1 * a.C1 * 2 + (a.C2 ? (size_t)CG_TF * CG_TT * a.C2 * 2 : 0) + 2 * (size_t)BN_ * KC * 2;
+}
+
 template <int DT>
 static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStream_t st) {
-    const bool kc64 = (a.C1 % 64 == 0) && (a.C2 % 64 == 0);
-    const bool bn128 = (a.Cout % 128 == 0);
+    // 64-channel weight chunks and 128-channel tiles where they apply and the tile still fits the 160 KB of LDS (a 128 + 128
+    // channel input pair -- the fused input gradient of a residual block -- leaves room for 32-channel chunks only)
+    const bool bn128 = (a.Cout % 128 == 0) && cg_lds_bytes(a, 32, 128) <= 160 * 1024;
+    const bool kc64 = (a.C1 % 64 == 0) && (a.C2 % 64 == 0) && cg_lds_bytes(a, 64, bn128 ? 128 : 64) <= 160 * 1024;
 #define CG_DISPATCH(KC_, BN__)                                                                     \
     do {                                                                                           \
         if (pool && out_mode == 1) return cg_launch<KC_, BN__, true, CG_OUT_X, DT>(a, st);        \

@@ -133,9 +133,16 @@ class _HipForward:
     def _ensure_packed(self, device):
         sig = (str(device), operand_dtype(self), self._param_signature())
         if getattr(self, "_pack_sig", None) != sig:
+            # Once per weight change.  Forwards may be in flight on several caller streams (bench.py keeps three): the old
+            # packed tensors and workspaces must not go back to the allocator while a stream still reads them, and the new
+            # ones (packed by kernels on THIS stream) must be complete before another stream's forward uses them.
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(device)
             self._packed = self._pack(device)
             self._pack_sig = sig
             self._ws = {}
+            if torch.cuda.is_available():
+                torch.cuda.synchronize(device)
         return self._packed
 
     # ---- hand-off status of the persistent recurrence launches (csrc/lstm.hip): every spin is bounded and reports

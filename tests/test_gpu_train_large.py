@@ -21,7 +21,9 @@ GRAD_REL = 4e-2        # per tensor, against the oracle with the HIP path's bf16
 GRAD_REL_FP32 = 1e-1   # ... against the fp32 reference
 GRAD_COS = 0.999
 GRAD_COS_FP32 = 0.995
-LOGIT_TOL = 3e-2
+LOGIT_TOL = 3e-2       # eval-mode logits against the fp32 oracle
+LOGIT_TOL_TRAIN_FP32 = 6e-2   # train-mode logits (bf16 operands through 8 convolutions with batch statistics over a few hundred
+LOGIT_TOL_TRAIN_EMU = 1e-2    # positions at these tiny shapes) against the fp32 reference / the oracle with the same rounding points
 # a conv bias in front of a BatchNorm has an analytically zero gradient (the reference's is rounding noise)
 ZERO_GRAD = ("conv1.0.bias", "res_block1.conv1.bias", "res_block1.conv2.bias", "res_block1.skip.0.bias", "res_block2.conv1.bias",
              "res_block2.conv2.bias", "res_block2.skip.0.bias", "freq_aware_conv.0.bias")
@@ -317,7 +319,7 @@ def test_large_train_step_matches_reference_golden(mta, golden_dir):
     mel, roll, lengths = data[0]
     logits = m(mel.cuda())
     assert logits.requires_grad and logits.shape == (B, 88, T)
-    assert np.abs(logits.detach().cpu().numpy() - g["logits0"]).max() < LOGIT_TOL
+    assert np.abs(logits.detach().cpu().numpy() - g["logits0"]).max() < LOGIT_TOL_TRAIN_FP32
     loss = m.compute_loss(logits, roll.cuda(), lengths)
     assert abs(loss.item() - float(g["loss0"])) < 2e-3
     loss.backward()
@@ -329,7 +331,8 @@ def test_large_train_step_matches_reference_golden(mta, golden_dir):
     _report("large vs fp32 reference golden", worst, cos)
     bad = {k: v for k, v in worst.items() if v > GRAD_REL_FP32}
     assert not bad and cos > GRAD_COS_FP32, (bad, cos)
-    _, ref_emu = _oracle_grads(sd, mel, roll, lengths, True)
+    lo_emu, ref_emu = _oracle_grads(sd, mel, roll, lengths, True)
+    assert (logits.detach().cpu() - lo_emu.detach()).abs().max() < LOGIT_TOL_TRAIN_EMU
     worst, cos = _compare_grads(grads, ref_emu)
     _report("large vs bf16-emulating oracle", worst, cos)
     bad = {k: v for k, v in worst.items() if v > GRAD_REL}

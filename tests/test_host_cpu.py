@@ -128,6 +128,28 @@ def test_cache_format_roundtrip(mta, tmp_path):
         ds[1]
 
 
+def test_cache_written_here_is_what_the_reference_reader_reads(mta, golden_dir):
+    """tests/golden/cache_fixture/ was written by this package's writer and read by the REFERENCE's CachedMaestroDataset /
+    HybridMaestroDataset (make_golden_cache.py, build container); cache_fixture.json records what they returned.  This
+    package's reader must return the same, and the writer must still produce byte-identical tensors."""
+    rec = json.load(open(os.path.join(golden_dir, "cache_fixture.json")))
+    cache = os.path.join(golden_dir, "cache_fixture")
+    for split, ent in rec["splits"].items():
+        assert ent["hybrid_uses_cache"] and ent["hybrid_len"] == ent["len"]          # the reference's own acceptance test passed
+        ds = mta.CachedMaestroDataset(cache_dir=cache, split=split)
+        assert len(ds) == ent["len"] and sorted(ds.metadata.keys()) == ent["metadata_keys"]
+        assert {k: v for k, v in ds.metadata.items() if k != "chunks"} == ent["metadata"]
+        assert sorted(ds.metadata["chunks"][0].keys()) == ent["chunk_keys"]
+        for i, it in enumerate(ent["items"]):
+            mel, roll = ds[i]
+            assert list(mel.shape) == it["mel_shape"] and list(roll.shape) == it["roll_shape"]
+            assert str(mel.dtype) == it["mel_dtype"] and str(roll.dtype) == it["roll_dtype"]
+            assert float(mel.double().sum()) == it["mel_sum"] and float(mel.double().abs().sum()) == it["mel_abs_sum"]
+            assert float(roll.double().sum()) == it["roll_sum"]
+            assert float((roll.double() * torch.arange(roll.numel()).reshape(roll.shape)).sum()) == it["roll_checksum"]
+            assert mel.shape[-1] == roll.shape[-1]                                    # trimmed to min_len (data/dataset.py:159-161)
+
+
 def test_shard_and_lpt():
     from music_transcription_amd.parallel import shard_range, lpt_assign
     for n in (0, 1, 7, 8, 177):
