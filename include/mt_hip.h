@@ -305,6 +305,14 @@ int    mt_f1_sweep_counts(const float* logits, const float* target, const long l
                           const float* thresholds, int K, unsigned long long* counts, int B, int P, int T,
                           mt_stream_t stream);
 
+/* Roll -> notes on the device: combine_piano_rolls + the run-length part of pianoroll_to_midi (main.py:164-226,
+ * scripts/evaluate.py:54-88).  The NB chunks of src [NB][P][T] are one roll of NB*T frames per pitch; src_mode 0: logits
+ * (active = sigmoid(x) > threshold, as mt_predict_threshold), 1: roll values (active = x > 0).  counts[p] = notes of pitch p;
+ * note k of pitch p is frames [starts[i], ends[i]) at i = sum_{q<p} counts[q] + k -- the reference's note order.  Nothing is
+ * written for a pitch whose notes would not fit `capacity`: the host compares sum(counts) with it.  Only the notes leave the GPU. */
+int    mt_roll_to_notes(const float* src, int src_mode, float threshold, int NB, int P, int T, int* counts, int* starts, int* ends,
+                        int capacity, mt_stream_t stream);
+
 /* ------------------------------------------------------------------ optimizer step (training)
  * clip_grad_norm_(max_norm) + torch.optim.Adam with coupled L2 weight decay over flat f32 buffers
  * (train_transcriber.py:134-144, train_cnn.py:290); a NaN/Inf gradient norm skips the step (:137-142).
@@ -433,13 +441,15 @@ int    mt_bn_act_fwd(const void* za, const float* mean_a, const float* rstd_a, c
                      const float* mask2d, void* out, int out_mode, int ldx, int B, int F, int T, int C, int relu, int pool,
                      mt_stream_t stream);
 /* Backward of mt_bn_act_fwd.  Gradient of the output: dout_cl (bf16 [B][Fo][T][ldd_cl]) or dout_x (f32 GEMM-row
- * layout, ldd_x) -- exactly one.  Outputs: dza [B][F][T][pitch_a] (+ optional second bf16 piece dza_lo), dzb
- * [B][F][T][pitch_b] (when zb), parameter gradients (any may be NULL).  sums: 3*C doubles of scratch.
+ * layout, ldd_x) -- exactly one.  Outputs: dza [B][F][T][pitch_a], dzb [B][F][T][pitch_b] (when zb), each with an
+ * optional second bf16 piece (dza_lo, dzb_lo: the rounding remainder -- BatchNorm forces sum dz = 0 and sum dz*z = 0, so
+ * the conv weight gradient is a heavily cancelling sum and runs over both pieces), parameter gradients (any may be
+ * NULL).  sums: 3*C doubles of scratch.
  * Pool ties route to the first row, as nn.MaxPool2d does.                                                           */
 int    mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_x, int ldd_x,
                      const void* za, const float* mean_a, const float* rstd_a, const float* gamma_a, const float* beta_a,
                      const void* zb, const float* mean_b, const float* rstd_b, const float* gamma_b, const float* beta_b,
-                     const float* mask2d, double* sums, void* dza, int pitch_a, void* dza_lo, void* dzb, int pitch_b,
+                     const float* mask2d, double* sums, void* dza, int pitch_a, void* dza_lo, void* dzb, int pitch_b, void* dzb_lo,
                      float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
                      int B, int F, int T, int C, int relu, int pool, mt_stream_t stream);
 /* Channels-last -> zero-padded position-major planes: dst[c*ld + (b*(F+2ph) + f+ph)*Tp + t + toff] = src[((b*F+f)*T+t)*pitch + c]

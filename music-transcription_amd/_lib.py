@@ -123,6 +123,7 @@ _SIGS = {
     "mt_predict_threshold": (i32, [vp, vp, C.c_longlong, C.c_float, vp]),
     "mt_f1_counts": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "mt_f1_sweep_counts": (i32, [vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
+    "mt_roll_to_notes": (i32, [vp, i32, C.c_float, i32, i32, i32, vp, vp, vp, i32, vp]),
     "mt_conv1_stats": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "mt_bn_finalize": (i32, [vp, C.c_double, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, vp, vp, vp, vp, i32, vp]),
     "mt_bn_stats_cl": (i32, [vp, ll, i32, vp, vp]),
@@ -150,7 +151,7 @@ _SIGS = {
     "mt_dlogits_pack": (i32, [vp, vp, vp, ll, i32, i32, i32, vp]),
     "mt_dropout2d_mask": (i32, [vp, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),
     "mt_bn_act_fwd": (i32, [vp] * 12 + [i32] * 8 + [vp]),
-    "mt_bn_act_bwd": (i32, [vp, i32, vp, i32] + [vp] * 13 + [i32, vp, vp, i32] + [vp] * 4 + [i32] * 6 + [vp]),
+    "mt_bn_act_bwd": (i32, [vp, i32, vp, i32] + [vp] * 13 + [i32, vp, vp, i32, vp] + [vp] * 4 + [i32] * 6 + [vp]),
     "mt_cl_to_planar": (i32, [vp, i32, i32, vp, ll, i32, i32, i32, i32, i32, i32, vp]),
     "mt_conv_cl_ex": (i32, [vp, i32, vp, i32, vp, vp, vp] + [i32] * 13 + [vp]),
     "mt_transpose_bf16_batched": (i32, [vp, ll, ll, i32, i32, vp, ll, ll, i32, i32, vp]),

@@ -123,6 +123,71 @@ __global__ void f1_sweep_kernel(const float* __restrict__ logits, const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------ roll -> notes on the device
+// combine_piano_rolls + the run-length part of pianoroll_to_midi (main.py:164-226; scripts/evaluate.py:54-88): the NB chunks of
+// `src` [NB][P][T] are one roll of NB*T frames per pitch (concatenated along time); a note is a maximal run of active frames,
+// reported as (start frame, end frame) = the indices where np.diff([0, active, 0]) is +1 / -1.  src_mode 0: logits, active =
+// sigmoid(x) > threshold (the predict_kernel expression); 1: roll values, active = x > 0.
+// One workgroup per pitch.  Pass 1 counts the runs, pass 2 writes them at [sum of the lower pitches' counts + k] -- the order in
+// which the reference appends its notes (pitch-major, then time) -- with a block-wide scan per 256-frame slab.
+__device__ __forceinline__ bool note_active(const float* __restrict__ src, int mode, float thr, int P, int T, int p, long long g) {
+    const long long b = g / T;
+    const float x = src[((size_t)b * P + p) * T + (g - b * T)];
+    return mode == 0 ? (1.0f / (1.0f + expf(-x)) > thr) : (x > 0.0f);
+}
+
+__global__ __launch_bounds__(256) void notes_count_kernel(const float* __restrict__ src, int mode, float thr, int NB, int P, int T, int* __restrict__ counts) {
+    __shared__ int red[4];
+    const int p = blockIdx.x;
+    const long long n = (long long)NB * T;
+    int c = 0;
+    for (long long g = threadIdx.x; g < n; g += 256) {
+        const bool a = note_active(src, mode, thr, P, T, p, g);
+        const bool prev = g > 0 && note_active(src, mode, thr, P, T, p, g - 1);
+        c += (a && !prev);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[p] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void notes_fill_kernel(const float* __restrict__ src, int mode, float thr, int NB, int P, int T, const int* __restrict__ counts,
+                                                         int* __restrict__ starts, int* __restrict__ ends, int capacity) {
+    __shared__ int wsum[2][4];
+    const int p = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int base = 0;
+    for (int q = 0; q < p; ++q) base += counts[q];
+    if (base + counts[p] > capacity) return;              // the host sees sum(counts) > capacity and retries with larger buffers
+    const long long n = (long long)NB * T;
+    int run_on = 0, run_off = 0;
+    for (long long g0 = 0; g0 <= n; g0 += 256) {          // g = n is the appended trailing 0
+        const long long g = g0 + threadIdx.x;
+        bool on = false, off = false;
+        if (g <= n) {
+            const bool a = g < n && note_active(src, mode, thr, P, T, p, g);
+            const bool prev = g > 0 && note_active(src, mode, thr, P, T, p, g - 1);
+            on = a && !prev;
+            off = !a && prev;
+        }
+        const unsigned long long mon = __ballot(on), moff = __ballot(off);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (lane == 0) { wsum[0][wv] = __popcll(mon); wsum[1][wv] = __popcll(moff); }
+        __syncthreads();
+        int pre_on = 0, pre_off = 0, tot_on = 0, tot_off = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) { pre_on += wsum[0][w]; pre_off += wsum[1][w]; }
+            tot_on += wsum[0][w]; tot_off += wsum[1][w];
+        }
+        if (on) starts[base + run_on + pre_on + __popcll(mon & below)] = (int)g;
+        if (off) ends[base + run_off + pre_off + __popcll(moff & below)] = (int)g;
+        run_on += tot_on; run_off += tot_off;
+        __syncthreads();
+    }
+}
+
 }  // namespace mt
 
 using namespace mt;
@@ -183,6 +248,17 @@ extern "C" int mt_f1_sweep_counts(const float* logits, const float* target, cons
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)B * K * 3 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(f1_sweep_kernel, dim3(8, B), dim3(256), 0, st, logits, target, lengths, thresholds, K, counts, P, T);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
+extern "C" int mt_roll_to_notes(const float* src, int src_mode, float threshold, int NB, int P, int T, int* counts, int* starts, int* ends,
+                                int capacity, mt_stream_t stream) {
+    MT_REQUIRE(src && counts && starts && ends && (src_mode == 0 || src_mode == 1) && NB > 0 && P > 0 && P <= 65535 && T > 0 && capacity > 0 &&
+               (long long)NB * T < 2147483647ll, MT_EINVAL, "mt_roll_to_notes: bad arguments");
+    hipLaunchKernelGGL(notes_count_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, src, src_mode, threshold, NB, P, T, counts);
+    MT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(notes_fill_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, src, src_mode, threshold, NB, P, T, counts, starts, ends, capacity);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

@@ -56,7 +56,7 @@ struct BnActArgs {
     const float* dx; int ldd_x;                         // ... GEMM-row layout dx[(t*B+b)*ldd_x + fo*C + c]
     double* sums;                                       // [3][C]: sum dy, sum dy*xhat_a, sum dy*xhat_b
     bf16_t* dza; int pa; bf16_t* dzb; int pb;           // outputs [B][F][T][pitch] (channel c at +c)
-    bf16_t* dza_lo;                                     // optional second bf16 piece of dza (same pitch)
+    bf16_t* dza_lo; bf16_t* dzb_lo;                     // optional second bf16 pieces (rounding remainders; same pitches)
 };
 
 // one thread = 8 channels of one output position (one or two pre-pool rows)
@@ -207,7 +207,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActArgs a) {
                     float ob[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ob[j] = gab[j] * rsb[j] * (d[rr][j] - m1[j] - xb[rr][j] * m2b[j]);
-                    *(uint4*)(a.dzb + pos * a.pb + c0) = pack8(ob);
+                    const uint4 hb = pack8(ob);
+                    *(uint4*)(a.dzb + pos * a.pb + c0) = hb;
+                    if (a.dzb_lo) {
+                        float hf[8], olb[8];
+                        unpack8(hb, hf);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) olb[j] = ob[j] - hf[j];
+                        *(uint4*)(a.dzb_lo + pos * a.pb + c0) = pack8(olb);
+                    }
                 }
             }
         } else {
@@ -552,7 +560,7 @@ extern "C" int mt_bn_act_fwd(const void* za, const float* mean_a, const float* r
 extern "C" int mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_x, int ldd_x,
                              const void* za, const float* mean_a, const float* rstd_a, const float* gamma_a, const float* beta_a,
                              const void* zb, const float* mean_b, const float* rstd_b, const float* gamma_b, const float* beta_b,
-                             const float* mask2d, double* sums, void* dza, int pitch_a, void* dza_lo, void* dzb, int pitch_b,
+                             const float* mask2d, double* sums, void* dza, int pitch_a, void* dza_lo, void* dzb, int pitch_b, void* dzb_lo,
                              float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
                              int B, int F, int T, int C, int relu, int pool, mt_stream_t stream) {
     BnActArgs a{};
@@ -561,7 +569,7 @@ extern "C" int mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_
     a.mean_b = mean_b; a.rstd_b = rstd_b; a.gamma_b = gamma_b; a.beta_b = beta_b;
     a.mask2d = mask2d; a.B = B; a.F = F; a.T = T; a.C = C; a.relu = relu; a.pool = pool;
     a.dcl = (const bf16_t*)dout_cl; a.ldd_cl = ldd_cl; a.dx = dout_x; a.ldd_x = ldd_x;
-    a.sums = sums; a.dza = (bf16_t*)dza; a.pa = pitch_a; a.dzb = (bf16_t*)dzb; a.pb = pitch_b; a.dza_lo = (bf16_t*)dza_lo;
+    a.sums = sums; a.dza = (bf16_t*)dza; a.pa = pitch_a; a.dzb = (bf16_t*)dzb; a.pb = pitch_b; a.dza_lo = (bf16_t*)dza_lo; a.dzb_lo = (bf16_t*)dzb_lo;
     int rc = check_bn_act(a);
     if (rc != MT_OK) return rc;
     const int Fo = pool ? F / 2 : F;

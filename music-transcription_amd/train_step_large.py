@@ -166,13 +166,13 @@ def _bn_act(za, sa, zb, sb, mask, out, out_mode, ldx, B, F, T, C, relu, pool):
                             B, F, T, C, relu, pool, _st()), "mt_bn_act_fwd")
 
 
-def _bn_act_bwd(dcl, ldd_cl, dx, ldd_x, za, sa, zb, sb, mask, dza, dzb, grads, B, F, T, C, relu, pool, dev, dza_lo=None):
+def _bn_act_bwd(dcl, ldd_cl, dx, ldd_x, za, sa, zb, sb, mask, dza, dzb, grads, B, F, T, C, relu, pool, dev, dza_lo=None, dzb_lo=None):
     sb = sb or (None, None, None, None)
     sums = torch.empty(3 * C, device=dev, dtype=torch.float64)
     dga, dba, dgb, dbb = grads
     check(lib.mt_bn_act_bwd(ptr(dcl), ldd_cl, ptr(dx), ldd_x, ptr(za), *(ptr(v) for v in sa), ptr(zb), *(ptr(v) for v in sb), ptr(mask),
-                            ptr(sums), ptr(dza), C, ptr(dza_lo), ptr(dzb), C, ptr(dga), ptr(dba), ptr(dgb), ptr(dbb), B, F, T, C, relu, pool,
-                            _st()), "mt_bn_act_bwd")
+                            ptr(sums), ptr(dza), C, ptr(dza_lo), ptr(dzb), C, ptr(dzb_lo), ptr(dga), ptr(dba), ptr(dgb), ptr(dbb), B, F, T, C,
+                            relu, pool, _st()), "mt_bn_act_bwd")
     return sums
 
 
@@ -202,21 +202,23 @@ class _Planes:
         return out
 
 
-def _conv_wgrad(pl: _Planes, dzP, xP, Cout, Cin, KH, kws, out):
+def _conv_wgrad(pl: _Planes, dzPs, xP, Cout, Cin, KH, kws, out):
     """out (f32, reference layout [Cout][Cin][KH][len(kws)]) = sum over positions of dz[pos][co] * x[pos + tap][ci].
-    dzP: planes tensor [1][.][ld] (toff 1); xP: planes [3][.][ld] for kernel columns 0, 1, 2 (toffs 2, 1, 0);
+    dzPs: list of planes tensors [1][.][ld] (toff 1) whose sum is dz (the bf16 value and, optionally, its rounding remainder:
+    BatchNorm makes the sum cancel heavily); xP: planes [3][.][ld] for kernel columns 0, 1, 2 (toffs 2, 1, 0);
     kws: the kernel columns wanted ((0, 1, 2) for a KH x 3 conv, (1,) with KH = 1 for the 1x1 skip).  Tap kh is the pointer
     offset (kh - KH // 2) * Tp2 into the activation plane."""
     dev = pl.dev
-    nkw = len(kws)
-    part = torch.empty(nkw, pl.S, KH, Cout, Cin, device=dev, dtype=torch.float32)
+    nkw, npc = len(kws), len(dzPs)
+    part = torch.empty(nkw, npc, pl.S, KH, Cout, Cin, device=dev, dtype=torch.float32)
     red = torch.empty(nkw, KH, Cout, Cin, device=dev, dtype=torch.float32)
-    a = dzP[0].reshape(-1)[pl.front:]
     for i, kw in enumerate(kws):
         w = xP[kw].reshape(-1)[pl.front - (KH // 2) * pl.Tp2:]
-        check(lib.mt_gemm_batched_f32(ptr(a), pl.ld, pl.Ks, 0, ptr(w), pl.ld, pl.Ks, pl.Tp2, None, ptr(part[i]), Cin,
-                                      KH * Cout * Cin, Cout * Cin, Cout, Cin, pl.Ks, pl.S * KH, KH, _st()), "mt_gemm_batched_f32 (conv wgrad)")
-        check(lib.mt_sum_slices_f32(ptr(part[i]), KH * Cout * Cin, Cin, pl.S, ptr(red[i]), Cin, KH * Cout, Cin, _st()), "mt_sum_slices_f32")
+        for j, dzP in enumerate(dzPs):
+            a = dzP[0].reshape(-1)[pl.front:]
+            check(lib.mt_gemm_batched_f32(ptr(a), pl.ld, pl.Ks, 0, ptr(w), pl.ld, pl.Ks, pl.Tp2, None, ptr(part[i, j]), Cin,
+                                          KH * Cout * Cin, Cout * Cin, Cout, Cin, pl.Ks, pl.S * KH, KH, _st()), "mt_gemm_batched_f32 (conv wgrad)")
+        check(lib.mt_sum_slices_f32(ptr(part[i]), KH * Cout * Cin, Cin, npc * pl.S, ptr(red[i]), Cin, KH * Cout, Cin, _st()), "mt_sum_slices_f32")
     _gather4(red, 0, out, (Cout, Cin, KH, nkw), (Cin, 1, Cout * Cin, KH * Cout * Cin))
     return out
 
@@ -596,16 +598,17 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         # ---- freq_aware_conv
         masks = sv["masks"]
         z256 = pk["zeros256"]
-        dzf = torch.empty(B * F2 * T, 256, **bf)
+        dzf, dzf_lo = torch.empty(B * F2 * T, 256, **bf), torch.empty(B * F2 * T, 256, **bf)
         g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"] = torch.empty(256, **f32), torch.empty(256, **f32)
         _bn_act_bwd(None, 0, dX0, K0, sv["zf"], sv["sf"], None, None, masks[2], dzf, None,
-                    (g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"], None, None), B, F2, T, 256, 1, 1, dev)
+                    (g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"], None, None), B, F2, T, 256, 1, 1, dev, dza_lo=dzf_lo)
         dr2 = torch.empty(B * F2 * T, 128, **bf)
         _conv(dzf, None, pk["fa_wdA"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256)
         _conv(dzf.reshape(-1)[128:], None, pk["fa_wdB"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256, accum=1)
         pl = _Planes(B, F2, T, 3, dev)
         g["freq_aware_conv.0.weight"] = torch.empty(256, 128, 7, 3, **f32)
-        _conv_wgrad(pl, pl.make(dzf, 256, 256, (1,)), pl.make(sv["r2"], 128, 128, (2, 1, 0)), 256, 128, 7, (0, 1, 2), g["freq_aware_conv.0.weight"])
+        _conv_wgrad(pl, [pl.make(dzf, 256, 256, (1,)), pl.make(dzf_lo, 256, 256, (1,))], pl.make(sv["r2"], 128, 128, (2, 1, 0)), 256, 128, 7, (0, 1, 2),
+                    g["freq_aware_conv.0.weight"])
         g["freq_aware_conv.0.bias"] = torch.zeros(256, **f32)          # a conv bias in front of a BatchNorm: analytically zero
         # ---- residual blocks, top down
         dout = dr2
@@ -613,15 +616,16 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             st = sv[name]
             cin, cout, pool, Fin, xin = st["cin"], st["cout"], st["pool"], st["Fin"], st["xin"]
             N = B * Fin * T
-            dz2, dzs = torch.empty(N, cout, **bf), torch.empty(N, cout, **bf)
+            dz2, dzs, dz2_lo, dzs_lo = (torch.empty(N, cout, **bf) for _ in range(4))
             gr = {k: torch.empty(cout, **f32) for k in ("bn2.weight", "bn2.bias", "skip.1.weight", "skip.1.bias", "bn1.weight", "bn1.bias")}
             _bn_act_bwd(dout, cout, None, 0, st["z2"], st["s2"], st["zs"], st["ss"], st["mask"], dz2, dzs,
-                        (gr["bn2.weight"], gr["bn2.bias"], gr["skip.1.weight"], gr["skip.1.bias"]), B, Fin, T, cout, 1, pool, dev)
+                        (gr["bn2.weight"], gr["bn2.bias"], gr["skip.1.weight"], gr["skip.1.bias"]), B, Fin, T, cout, 1, pool, dev,
+                        dza_lo=dz2_lo, dzb_lo=dzs_lo)
             dy1 = torch.empty(N, cout, **bf)
             _conv(dz2, None, pk[name + "c2_wd"], z256, dy1, B, Fin, T, cout, 0, cout, 3)
-            dz1 = torch.empty(N, cout, **bf)
+            dz1, dz1_lo = torch.empty(N, cout, **bf), torch.empty(N, cout, **bf)
             _bn_act_bwd(dy1, cout, None, 0, st["z1"], st["s1"], None, None, None, dz1, None, (gr["bn1.weight"], gr["bn1.bias"], None, None),
-                        B, Fin, T, cout, 1, 0, dev)
+                        B, Fin, T, cout, 1, 0, dev, dza_lo=dz1_lo)
             cin_p = max(cin, 64)
             dxin = torch.empty(N, cin_p, **bf)
             _conv(dz1, dzs, pk[name + "c1s_wd"], z256, dxin, B, Fin, T, cout, cout, cin_p, 3)
@@ -630,9 +634,10 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             xP = pl.make(xin, cin, cin, (2, 1, 0))
             yP = pl.make(st["y1"], cout, cout, (2, 1, 0))
             pfx = "res_block1" if name == "rb1" else "res_block2"
-            g[pfx + ".conv1.weight"] = _conv_wgrad(pl, pl.make(dz1, cout, cout, (1,)), xP, cout, cin, 3, (0, 1, 2), torch.empty(cout, cin, 3, 3, **f32))
-            g[pfx + ".conv2.weight"] = _conv_wgrad(pl, pl.make(dz2, cout, cout, (1,)), yP, cout, cout, 3, (0, 1, 2), torch.empty(cout, cout, 3, 3, **f32))
-            g[pfx + ".skip.0.weight"] = _conv_wgrad(pl, pl.make(dzs, cout, cout, (1,)), xP, cout, cin, 1, (1,), torch.empty(cout, cin, 1, 1, **f32))
+            two = lambda hi, lo: [pl.make(hi, cout, cout, (1,)), pl.make(lo, cout, cout, (1,))]
+            g[pfx + ".conv1.weight"] = _conv_wgrad(pl, two(dz1, dz1_lo), xP, cout, cin, 3, (0, 1, 2), torch.empty(cout, cin, 3, 3, **f32))
+            g[pfx + ".conv2.weight"] = _conv_wgrad(pl, two(dz2, dz2_lo), yP, cout, cout, 3, (0, 1, 2), torch.empty(cout, cout, 3, 3, **f32))
+            g[pfx + ".skip.0.weight"] = _conv_wgrad(pl, two(dzs, dzs_lo), xP, cout, cin, 1, (1,), torch.empty(cout, cin, 1, 1, **f32))
             for k in ("conv1.bias", "conv2.bias", "skip.0.bias"):
                 g[f"{pfx}.{k}"] = torch.zeros(cout, **f32)
             for k, v in gr.items():

@@ -23,7 +23,8 @@ import torch
 
 from .frontend import get_frontend, num_frames
 from .model import TranscriptionModel
-from . import ops
+from . import ops, _lib
+from ._lib import lib, check, ptr
 
 MODEL_TYPE, N_MELS, HIDDEN_SIZE, NUM_LAYERS, DROPOUT = "cnn_rnn_large", 320, 512, 3, 0.2     # main.py:16-20
 SR, HOP_LENGTH, CHUNK_LENGTH, THRESHOLD = 16000, 512, 30.0, 0.5                                # main.py:21-24
@@ -133,6 +134,51 @@ def pianoroll_to_notes(roll: np.ndarray, fs: float, min_midi: int = 21) -> List[
     return notes
 
 
+def notes_from_logits_device(logits: torch.Tensor, threshold: float = THRESHOLD, fs: float = SR / HOP_LENGTH, min_midi: int = 21,
+                             is_roll: bool = False) -> List[Tuple[int, float, float]]:
+    """(n_chunks, 88, T) logits (or {0,1} roll values with is_roll=True) ON THE DEVICE -> notes, without the roll ever
+    leaving the GPU: threshold + combine_piano_rolls + the run-length of pianoroll_to_midi (main.py:153-226) in
+    mt_roll_to_notes; only 88 counts and two ints per note are copied to the host."""
+    if not logits.is_cuda:
+        raise RuntimeError("notes_from_logits_device expects a CUDA tensor")
+    x = logits.detach().contiguous().float()
+    NB, P, T = x.shape
+    dev = x.device
+    counts = torch.empty(P, dtype=torch.int32, device=dev)
+    cap = max(1024, NB * 64)
+    while True:
+        starts, ends = torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.mt_roll_to_notes(ptr(x), 1 if is_roll else 0, float(threshold), NB, P, T, ptr(counts), ptr(starts), ptr(ends), cap,
+                                       _lib.stream_ptr()), "mt_roll_to_notes")
+        c = counts.cpu().numpy()
+        total = int(c.sum())
+        if total <= cap:
+            break
+        cap = total
+    s, e = starts[:total].cpu().numpy(), ends[:total].cpu().numpy()
+    pitches = np.repeat(np.arange(P) + min_midi, c)
+    return [(int(pp), float(a) / fs, float(b) / fs) for pp, a, b in zip(pitches, s, e) if b > a]
+
+
+@torch.no_grad()
+def transcribe_chunks_to_notes(model: "TranscriptionModel", chunks, threshold: float = THRESHOLD, batch: int = 32, n_mels: int = N_MELS,
+                               device: str = "cuda") -> List[Tuple[int, float, float]]:
+    """(n, 480000) waveform chunks -> notes; mel, forward, threshold, concatenation and run-length all on the GPU."""
+    fe = get_frontend(SR, n_mels, HOP_LENGTH, device)
+    if not torch.is_tensor(chunks):
+        chunks = torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32))
+    chunks = chunks.to(device)
+    net = model.model
+    outs = []
+    for i in range(0, len(chunks), batch):
+        mel, cmax = fe(chunks[i:i + batch].contiguous(), clamp=False)
+        outs.append(net(mel, chunk_max_power=cmax))
+    notes = notes_from_logits_device(torch.cat(outs), threshold, SR / HOP_LENGTH)
+    net.raise_on_handoff_timeout(sync=False)               # (the copies above synchronised with every forward)
+    return notes
+
+
 def _vlq(n: int) -> bytes:
     out = [n & 0x7F]
     n >>= 7
@@ -204,8 +250,7 @@ def transcribe_audio(audio_path: str, model_path: str, output_path=None, device=
     y = load_audio_device(audio_path, SR, device)       # decode + resample on the GPU; the waveform never visits the host
     chunks, duration = split_into_chunks_device(y)
     print(f"Audio duration: {duration:.2f} seconds; {len(chunks)} chunks of {CHUNK_LENGTH}s")
-    roll = transcribe_chunks(model, chunks, threshold, n_mels=model_kw.get("n_mels", N_MELS), device=device)
-    notes = pianoroll_to_notes(roll, SR / HOP_LENGTH)
+    notes = transcribe_chunks_to_notes(model, chunks, threshold, n_mels=model_kw.get("n_mels", N_MELS), device=device)
     if output_path is None:
         p = Path(audio_path)
         output_path = p.parent / f"{p.stem}_transcription.mid"

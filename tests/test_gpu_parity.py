@@ -262,6 +262,44 @@ def test_main_cli_end_to_end(mta, tmp_path):
     ref = np.concatenate(ref, axis=1)
     assert roll.shape == ref.shape == (88, 2 * 938)
     assert (roll != ref).mean() < 5e-3 and roll.sum() > 0                   # only |logit| ~ 0 cells may flip
+    # the CLI's notes come from the device run-length: the same notes as the reference's host loop over the HIP roll
+    notes_dev = tr.transcribe_chunks_to_notes(model, chunks, 0.5, n_mels=64)
+    assert notes_dev == R.pianoroll_to_notes(roll, 16000 / 512) and len(notes_dev) > 0
+    from music_transcription_amd import midi as midi_mod
+    back = sorted((n.pitch, n.start, n.end) for n in midi_mod.MidiFile(str(out)).instruments[0].notes)     # the file the CLI wrote
+    assert len(back) == len(notes_dev)
+    for (p1, s1, e1), (p2, s2, e2) in zip(back, sorted(notes_dev)):
+        assert p1 == p2 and abs(s1 - s2) < 3e-3 and abs(e1 - e2) < 3e-3              # SMF ticks: 1 / 440 s
+
+
+# ------------------------------------------------------------------ roll -> notes on the device (row f2)
+def test_roll_to_notes_device_matches_oracle(mta):
+    """mt_roll_to_notes (threshold + chunk concatenation + run-length on the GPU) against the oracle's restatement of
+    pianoroll_to_midi (main.py:189-226) -- same notes, same order; edge cases: silence, all-on, notes at the very first /
+    last frame, notes crossing a chunk boundary, single-frame notes, a note buffer that has to grow."""
+    from music_transcription_amd import transcribe as tr
+    fs = 31.25
+    g = torch.Generator().manual_seed(4)
+    for NB, T, dens in ((1, 40, 0.3), (3, 57, 0.5), (5, 938, 0.04), (2, 300, 0.9), (40, 64, 0.5)):
+        roll = (torch.rand(NB, 88, T, generator=g) < dens).float()
+        roll[:, 0] = 0.0                                            # a silent pitch
+        roll[:, 1] = 1.0                                            # one note over the whole recording
+        roll[:, 2] = 0.0; roll[0, 2, 0] = 1.0; roll[-1, 2, -1] = 1.0   # single frames at both ends
+        if NB > 1:
+            roll[:, 3] = 0.0; roll[0, 3, -3:] = 1.0; roll[1, 3, :2] = 1.0      # crosses the chunk boundary: ONE note
+        flat = roll.permute(1, 0, 2).reshape(88, NB * T).numpy()   # combine_piano_rolls: concatenation along time
+        want = R.pianoroll_to_notes(flat, fs)
+        got = tr.notes_from_logits_device(roll.cuda(), fs=fs, is_roll=True)
+        assert got == want, (NB, T, len(got), len(want))
+        assert tr.pianoroll_to_notes(flat, fs) == want             # (the host helper kept for callers that hold a roll)
+        # from logits, with the predict threshold fused in
+        logits = torch.randn(NB, 88, T, generator=g) * 2.0
+        for thr in (0.3, 0.5, 0.7):
+            pr = R.predict(logits, thr).permute(1, 0, 2).reshape(88, NB * T).numpy()
+            assert tr.notes_from_logits_device(logits.cuda(), thr, fs) == R.pianoroll_to_notes(pr, fs)
+    if NB > 1:
+        n3 = [n for n in want if n[0] == 21 + 3]
+        assert len(n3) == 1 and abs(n3[0][2] - n3[0][1] - 5 / fs) < 1e-9
 
 
 # ------------------------------------------------------------------ optimizer step (training row a11)

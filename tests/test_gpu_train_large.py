@@ -18,9 +18,13 @@ pytestmark = pytest.mark.gpu
 from oracle import model_ref as R
 
 GRAD_REL = 4e-2        # per tensor, against the oracle with the HIP path's bf16 rounding points
-GRAD_REL_FP32 = 1e-1   # ... against the fp32 reference
 GRAD_COS = 0.999
-GRAD_COS_FP32 = 0.995
+# Against the fp32 reference golden the bar is set by bf16 itself, not by the kernels: at the golden's toy shapes (a few
+# hundred positions per BatchNorm channel, random labels) the CPU oracle with bf16-rounded activations and EXACT f32
+# autograd is already cos 0.992 / up to 45 % per tensor away from the fp32 reference (ReLU / max-pool decisions flip, and
+# BatchNorm makes the conv weight gradients heavily cancelling sums) -- measured in the test and printed.  The HIP path
+# must be no further from fp32 than that oracle plus GRAD_REL, tensor by tensor.
+GRAD_COS_FP32 = 0.99
 LOGIT_TOL = 3e-2       # eval-mode logits against the fp32 oracle
 LOGIT_TOL_TRAIN_FP32 = 6e-2   # train-mode logits (bf16 operands through 8 convolutions with batch statistics over a few hundred
 LOGIT_TOL_TRAIN_EMU = 1e-2    # positions at these tiny shapes) against the fp32 reference / the oracle with the same rounding points
@@ -137,7 +141,7 @@ def test_bn_act_forward_backward_vs_autograd(mta, C, F_, T, B, two, relu, pool, 
         y2 = y2 * mask.cpu()[:, None, None, :] if mask is not None else y2
         y2.backward(dout)
     check(lib.mt_bn_act_bwd(ptr(dcl), C, ptr(dx), ldx, ptr(zad), *(ptr(v) for v in sa), ptr(zbd), *(ptr(v) for v in sb), ptr(mask), ptr(sums),
-                            ptr(dza), C, None, ptr(dzb), C, ptr(gr[0]), ptr(gr[1]), ptr(gr[2]) if two else None, ptr(gr[3]) if two else None,
+                            ptr(dza), C, None, ptr(dzb), C, None, ptr(gr[0]), ptr(gr[1]), ptr(gr[2]) if two else None, ptr(gr[3]) if two else None,
                             B, F_, T, C, relu, pool, st()), "bwd")
     sc = float(zar.grad.abs().max())
     assert (dza.float().cpu().reshape(B, F_, T, C) - zar.grad).abs().max() < 1.5e-2 * sc
@@ -161,8 +165,8 @@ def test_conv_weight_gradient_over_position_planes(mta, B, F_, T, Cin, Cout, KH)
     with torch.cuda.device(0):
         xP = pl.make(x.bfloat16().cuda().contiguous(), Cin, Cin, (2, 1, 0))
         dP = pl.make(dz.bfloat16().cuda().contiguous(), Cout + 8, Cout, (1,))
-        out = TL._conv_wgrad(pl, dP, xP, Cout, Cin, KH, (0, 1, 2), torch.empty(Cout, Cin, KH, 3, device="cuda"))
-        out1 = TL._conv_wgrad(pl, dP, xP, Cout, Cin, 1, (1,), torch.empty(Cout, Cin, 1, 1, device="cuda")) if KH == 3 else None
+        out = TL._conv_wgrad(pl, [dP], xP, Cout, Cin, KH, (0, 1, 2), torch.empty(Cout, Cin, KH, 3, device="cuda"))
+        out1 = TL._conv_wgrad(pl, [dP], xP, Cout, Cin, 1, (1,), torch.empty(Cout, Cin, 1, 1, device="cuda")) if KH == 3 else None
     w = torch.zeros(Cout, Cin, KH, 3, requires_grad=True)
     xc, dzc = x.permute(0, 3, 1, 2), dz[..., :Cout].permute(0, 3, 1, 2)
     F.conv2d(xc, w, padding=(ph, 1)).backward(dzc)
@@ -306,7 +310,7 @@ def _oracle_grads(sd, mel, roll, lengths, emulate_bf16, all_heads=False):
 
 
 def _report(tag, worst, cos):
-    top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:12]
     print(f"\n[{tag}] cos={cos:.6f} worst: " + ", ".join(f"{k.replace('model.', '')}={v:.3g}" for k, v in top))
 
 
@@ -327,14 +331,17 @@ def test_large_train_step_matches_reference_golden(mta, golden_dir):
     grads = {k: p.grad for k, p in m.named_parameters()}
     ref = {k[len("grad::"):]: g[k] for k in g.files if k.startswith("grad::")}
     assert set(ref) == set(grads)
-    worst, cos = _compare_grads(grads, ref)
-    _report("large vs fp32 reference golden", worst, cos)
-    bad = {k: v for k, v in worst.items() if v > GRAD_REL_FP32}
-    assert not bad and cos > GRAD_COS_FP32, (bad, cos)
+    worst32, cos32 = _compare_grads(grads, ref)
+    _report("large vs fp32 reference golden", worst32, cos32)
     lo_emu, ref_emu = _oracle_grads(sd, mel, roll, lengths, True)
-    assert (logits.detach().cpu() - lo_emu.detach()).abs().max() < LOGIT_TOL_TRAIN_EMU
+    print("logits vs emulating oracle:", float((logits.detach().cpu() - lo_emu.detach()).abs().max()))
     worst, cos = _compare_grads(grads, ref_emu)
     _report("large vs bf16-emulating oracle", worst, cos)
+    we, ce = _compare_grads({k: torch.from_numpy(v) for k, v in ref_emu.items()}, ref)
+    _report("(bf16-emulating oracle vs fp32 reference golden)", we, ce)
+    bad = {k: (v, we[k]) for k, v in worst32.items() if v > we[k] + GRAD_REL}
+    assert not bad and cos32 > GRAD_COS_FP32 and cos32 > ce - 2e-3, (bad, cos32, ce)
+    assert (logits.detach().cpu() - lo_emu.detach()).abs().max() < LOGIT_TOL_TRAIN_EMU
     bad = {k: v for k, v in worst.items() if v > GRAD_REL}
     assert not bad and cos > GRAD_COS, (bad, cos)
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
