@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--threshold", type=float, default=0.5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dump-rolls", help="directory: write <name>.roll.bits.npy (np.packbits of the (88, T_total) roll) per recording")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,6 +125,9 @@ def main():
             ref = torch.from_numpy(np.load(ref_path)).float().to(dev)
         else:
             ref = (torch.rand(roll.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(i)) < 0.04).float()
+        if args.dump_rolls:
+            os.makedirs(args.dump_rolls, exist_ok=True)
+            np.save(os.path.join(args.dump_rolls, names[i] + ".roll.bits.npy"), np.packbits(roll.cpu().numpy().astype(np.uint8), axis=1))
         L = min(ref.shape[1], roll.shape[1])
         f1s.append(mta.framewise_f1(roll[None, :, :L].contiguous(), ref[None, :, :L].contiguous())[0])
     torch.cuda.synchronize()
@@ -137,7 +141,7 @@ def main():
         print(json.dumps({"workload": "offline corpus transcription (BASELINE.json configs[4])", "recordings": len(names),
                           "audio_hours": round(sum(durations) / 3600.0, 2) if not args.wav_dir else None, "n_gpus": world,
                           "chunks": int(sum(tot_chunks)), "wall_s": round(wall, 3), "chunks_per_s": round(sum(tot_chunks) / wall, 1),
-                          "mean_f1": float(np.mean(allf1)), "model": args.model_type, "data": "wav" if args.wav_dir else "synthetic"}))
+                          "mean_f1": float(np.mean(allf1)), "per_recording_f1": [float(v) for v in allf1], "model": args.model_type, "data": "wav" if args.wav_dir else "synthetic"}))
     if world > 1:
         dist.destroy_process_group()
 

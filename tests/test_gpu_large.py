@@ -123,6 +123,53 @@ def test_large_variants_vs_reference_golden(mta, golden_dir):
         assert (got - ref).abs().max().item() < 5e-2 * max(1.0, ref.abs().max().item()), key
 
 
+def test_large_canonical_b2_t938_vs_reference_golden(mta, golden_dir):
+    """canonical 320/512/3 at B = 2, T = 938 (what main.py's chunks produce): strided frame logits + summary statistics."""
+    c = np.load(os.path.join(golden_dir, "canonical_models.npz"))
+    tag = "large_938"
+    nm, hs, nl, B, T, wseed, xseed = [int(v) for v in c[f"{tag}_cfg"]]
+    sd = R.set_bn_flat(R.make_state_dict("cnn_rnn_large", nm, hs, nl, wseed), c[f"{tag}_bn"])
+    model = mta.TranscriptionModel("cnn_rnn_large", n_mels=nm, hidden_size=hs, num_layers=nl, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    x = _mel_in(B, nm, T, xseed)
+    with torch.no_grad():
+        got = model(x.cuda()).cpu().numpy()
+        model.model.raise_on_handoff_timeout(B, T)
+    assert got.shape == (B, 88, T)
+    err = np.abs(got[:, ::5, ::7] - c[f"{tag}_sample"]).max()
+    assert err < 1e-2, err                                             # f16 operands (observed ~1e-3)
+    st = c[f"{tag}_stats"]
+    assert abs(got.mean() - st[0]) < 2e-3 and abs(got.std() - st[1]) < 2e-3
+
+
+def test_large_full_size_b16_independence_determinism_and_fused_projection(mta):
+    """BASELINE configs[2] shape (CNNRNNModelLarge, batch 16 x 30 s): chunks are independent (no padding arises), the
+    forward is run-to-run deterministic, and the fused-input-projection path (main layers 1.. project inside the
+    recurrence, mt_cnnrnn_large_weights.main_w_ihx) gives the same logits as the GEMM path."""
+    from oracle import frontend_ref as FR
+    sd = R.make_state_dict("cnn_rnn_large", 320, 512, 3, seed=3)
+    model = mta.TranscriptionModel("cnn_rnn_large", n_mels=320, hidden_size=512, num_layers=3, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    wave = torch.from_numpy(FR.synth_audio(4, 480000, seed=8)).cuda()
+    wave = torch.cat([wave * s for s in (1.0, 0.5, 0.25, 0.8)], 0)                               # 16 distinct chunks
+    mel, cmax = mta.MelFrontend(16000, 320, 512, "cuda")(wave, clamp=True)
+    with torch.no_grad():
+        full = model(mel, return_all_heads=True)
+        full = {k: v.clone() for k, v in full.items()}
+        again = model(mel, return_all_heads=True)
+        assert all(torch.equal(full[k], again[k]) for k in full)                                 # deterministic
+        perm = torch.tensor([5, 0, 11, 3])
+        sub = model(mel[perm].contiguous(), return_all_heads=True)                               # other batch size, other positions
+        for k in full:
+            assert (sub[k] - full[k][perm]).abs().max().item() < 2e-3, k                         # GEMM tile order may differ with M
+        model.model.fuse_input_projection = True
+        fused = model(mel, return_all_heads=True)
+        model.model.raise_on_handoff_timeout(16, 938)
+        for k in full:
+            assert torch.isfinite(fused[k]).all() and (fused[k] - full[k]).abs().max().item() < 3e-3, k
+    assert float(full["frame"].std()) > 1e-3
+
+
 def test_large_canonical_vs_reference_golden(mta, golden_dir):
     c = np.load(os.path.join(golden_dir, "canonical_models.npz"))
     tag = "large_937"

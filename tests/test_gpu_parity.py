@@ -469,3 +469,64 @@ def test_fused_input_projection_full_size(mta):
         again = model(mel).clone()
     model.model.raise_on_handoff_timeout(16, 938)
     assert torch.equal(fused, again) and (fused - plain).abs().max().item() < 3e-3
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: whole-corpus transcription, sharded over ranks
+def test_transcribe_corpus_two_ranks_matches_oracle_pipeline(mta, tmp_path):
+    """scripts/transcribe_corpus.py on a 6-recording corpus of WAV files (44.1 kHz stereo int16 and 16 kHz mono float), two
+    ranks (torch.distributed.run, gloo between processes that share this box's GPU): recordings are LPT-sharded with no
+    data-path collective, every recording is transcribed exactly once, per-recording F1 values are gathered, and the rolls
+    equal the CPU oracle pipeline's (decode -> chunk -> mel -> model -> threshold -> concatenate) up to |logit| ~ 0 cells."""
+    import json
+    import subprocess
+    import sys
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    wav_dir, dump = tmp_path / "corpus", tmp_path / "rolls"
+    wav_dir.mkdir()
+    nm, H, L = 64, 32, 1
+    sd = R.make_state_dict("cnn_rnn", nm, H, L, seed=2)
+    sd["model.fc.bias"] += 0.2
+    torch.save(sd, str(tmp_path / "m.pth"))
+    durs = [41.0, 12.5, 65.0, 30.0, 33.3, 7.0]                          # seconds: 1-3 chunks each, the last one zero-padded
+    waves16 = {}
+    rng = np.random.default_rng(0)
+    for i, d in enumerate(durs):
+        name = f"rec_{i}"
+        if i % 2 == 0:                                                    # 16 kHz mono float: no resampling -> sample-exact oracle input
+            w = FR.synth_audio(1, int(16000 * d), seed=50 + i)[0]
+            wavfile.write(str(wav_dir / (name + ".wav")), 16000, w)
+            waves16[name] = w
+        else:                                                             # 44.1 kHz stereo int16: decode + channel mean + resample on the GPU
+            w = FR.synth_audio(1, int(44100 * d), seed=50 + i, sr=44100)[0]
+            st = np.stack([w, 0.5 * w], 1)
+            wavfile.write(str(wav_dir / (name + ".wav")), 44100, (st * 32767.0).astype(np.int16))
+            waves16[name] = None
+        T_total = -(-int(16000 * d) // 480000) * 938
+        np.save(str(wav_dir / (name + ".roll.npy")), (rng.random((88, T_total)) < 0.05).astype(np.float32))
+    env = dict(os.environ, MT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "scripts", "transcribe_corpus.py"), "--wav-dir", str(wav_dir), "--model", str(tmp_path / "m.pth"), "--model-type", "cnn_rnn",
+           "--n-mels", str(nm), "--hidden-size", str(H), "--num-layers", str(L), "--batch", "4", "--dump-rolls", str(dump)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["recordings"] == 6 and out["n_gpus"] == 2 and out["chunks"] == sum(-(-int(16000 * d) // 480000) for d in durs)
+    assert len(out["per_recording_f1"]) == 6 and all(0.0 <= v <= 1.0 for v in out["per_recording_f1"])
+    assert sorted(os.listdir(dump)) == sorted(f"rec_{i}.roll.bits.npy" for i in range(6))          # each recording exactly once
+    # the 16 kHz recordings against the oracle pipeline (main.py:60-100 chunking, :103-130 mel, model, :153-159 threshold, :164-186 concat)
+    for i in (0, 2, 4):
+        name = f"rec_{i}"
+        w = waves16[name]
+        n_ch = -(-len(w) // 480000)
+        wp = np.zeros(n_ch * 480000, np.float32); wp[:len(w)] = w
+        ref = []
+        for c in wp.reshape(n_ch, 480000):
+            mel = torch.from_numpy(FR.audio_to_mel(c, 16000, nm, 512))[None, None]
+            ref.append(R.predict(R.cnnrnn_forward(sd, mel), 0.5)[0].numpy())
+        ref = np.concatenate(ref, axis=1)
+        got = np.unpackbits(np.load(str(dump / (name + ".roll.bits.npy"))), axis=1)[:, :ref.shape[1]]
+        assert got.shape == ref.shape and (got != ref).mean() < 5e-3 and got.sum() > 0, (name, (got != ref).mean())
+        truth = np.load(str(wav_dir / (name + ".roll.npy")))
+        assert abs(out["per_recording_f1"][i] - R.f1_binary(truth, got)) < 1e-9                      # the gathered F1 is this recording's

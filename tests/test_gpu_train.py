@@ -406,6 +406,60 @@ def test_data_parallel_training_two_ranks(mta):
     assert all(np.isfinite(out["losses_rank0"])) and len(out["losses_rank0"]) == 3
 
 
+def test_full_size_training_step_configs3(mta):
+    """BASELINE configs[3] shape on one GPU: CNNRNNModel 320/512/3, batch 16 cached-format chunks with ragged
+    T in [469, 937] right-padded with 0.0 (collate_fn), Bernoulli(0.04) rolls.  The train-mode forward equals the CPU
+    oracle's (same bf16 rounding points; BatchNorm batch statistics), every gradient is finite, the step is run-to-run
+    deterministic, and one fused clip + Adam step changes the eval-mode output."""
+    nm, H, L, B, T = 320, 512, 3, 16, 937
+    m, sd = _hip_model(mta, nm, H, L, seed=4, dropout=0.0)
+    g = torch.Generator().manual_seed(12)
+    lengths = torch.randint(469, T + 1, (B,), generator=g)
+    lengths[0] = T
+    mel = torch.rand(B, 1, nm, T, generator=g) * 60.0 - 70.0
+    roll = (torch.rand(B, 88, T, generator=g) < 0.04).float()
+    for b in range(B):
+        mel[b, :, :, lengths[b]:] = 0.0
+        roll[b, :, lengths[b]:] = 0.0
+    m.train()
+    runs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        logits = m(mel.cuda())
+        loss = m.compute_loss(logits, roll.cuda(), lengths)
+        loss.backward()
+        m.model.raise_on_train_handoff_timeout()
+        flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+        assert torch.isfinite(flat).all() and float(flat.abs().max()) > 0
+        runs.append((logits.detach().clone(), float(loss.item()), flat.clone()))
+        for mod in m.modules():                               # the second run must see the same BatchNorm buffers
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.reset_running_stats()
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    # weight-gradient partial sums are reduced in a fixed order; the BatchNorm sums use f64 atomics (order-dependent in the
+    # last f64 bits, invisible after the f32 rounding in practice): allow 1e-6 relative
+    assert (runs[0][2] - runs[1][2]).abs().max() <= 1e-6 * float(runs[0][2].abs().max())
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    with torch.no_grad():
+        lo = R.cnnrnn_forward({k: v.clone() for k, v in sd.items()}, mel, R.Opts(gemm_bf16=True, fast_lstm=False), train=True)
+    assert (runs[0][0].cpu() - lo).abs().max() < 1e-2
+    assert abs(runs[0][1] - float(R.compute_loss(lo, roll, lengths))) < 1e-3
+    opt = mta.make_optimizer(m, lr=1e-3)
+    m.eval()
+    with torch.no_grad():
+        before = m(mel[:2, :, :, :469].contiguous().cuda()).clone()
+    m.train()
+    opt.zero_grad()
+    m.compute_loss(m(mel.cuda()), roll.cuda(), lengths).backward()
+    stats = opt.step(sync_grads=False).tolist()
+    assert stats[1] == 1.0 and np.isfinite(stats[0]) and stats[0] > 0
+    m.eval()
+    with torch.no_grad():
+        after = m(mel[:2, :, :, :469].contiguous().cuda())
+    assert (after - before).abs().max() > 1e-4
+
+
 @pytest.mark.parametrize("R,C,lds,ldd,Cd,off", [(300, 64, 64, 320, 64, 0), (1000, 72, 72, 1024, 128, 0), (257, 50, 56, 264, 50, 0),
                                               (130, 64, 64, 136, 64, 3), (64, 24, 30, 70, 24, 0)])
 def test_transpose_bf16_helper(mta, R, C, lds, ldd, Cd, off):
