@@ -284,7 +284,7 @@ def main():
     if NS > 6:
         raise SystemExit("--streams: at most 6 forwards in flight per GPU (co-residency of the persistent recurrence launches)")
     # with several batches in flight the projection GEMMs are the shared resource: let layers 1.. project inside the recurrence
-    net.fuse_input_projection = 2 <= NS <= 3
+    net.fuse_input_projection = NS == 2
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
     cmax = [torch.empty(B, device=dev) for _ in range(NS)]

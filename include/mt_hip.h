@@ -14,7 +14,15 @@
  *     message of the last error on the calling thread is at mt_last_error();
  *   - no entry point allocates device memory or synchronises the device: scratch
  *     comes in as (workspace, workspace_bytes), sizes come from the *_bytes queries;
- *   - thread-compatible (one stream per caller thread), no mutable global state.
+ *   - thread-compatible (one stream per caller thread); the only mutable global state is the mutex-protected table of
+ *     persistent launches in flight (below).
+ *
+ * Persistent launches.  The LSTM recurrence kernels (mt_lstm_bidir_fwd*, mt_lstm_bidir_bwd*) wait on their own
+ * workgroups, so all workgroups of all such launches in flight on a GPU must be resident together.  Launches on one
+ * stream run in order; for launches on DIFFERENT streams the library checks at launch time that their CUs (workgroups /
+ * occupancy per CU) fit the device and otherwise returns MT_EUNSUPPORTED at once -- it never queues a launch that could
+ * stall the others (every in-kernel spin is bounded as well and reports through the status word of its sync workspace).
+ * At hidden 512, batch <= 32: six plain forward recurrences, two with the fused input projection.
  */
 #ifndef MT_HIP_H
 #define MT_HIP_H
@@ -139,14 +147,18 @@ int    mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sy
  * units), bias [2][4H] = b_ih + b_hh.  H <= 512.                                                                       */
 int    mt_lstm_bidir_fwd_xproj(const float* hx_prev, const float* w_ihx, const float* bias, const float* w_hh, float* hx,
                                void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream);
-/* mode 0: as above (agent-scope hand-off, correct under any workgroup placement).  mode 1: XCD-local
- * hand-off: each (direction, batch group) runs on workgroups that read their hardware XCC id and share one
- * XCD's L2 (about 2x shorter steps).  It needs the dispatcher to deal the launch's workgroups evenly over the
- * 8 XCDs (liveness only; bounded spins report otherwise in the status word): check once with
- * mt_xcd_census (host array of 8 counts; scratch32 = 32 device bytes; synchronises the stream).          */
+/* mode 0: as above (agent-scope hand-off, correct under any workgroup placement).  mode 2: XCD-local hand-off with
+ * 16 hidden units per workgroup: the H/16 workgroups of a (direction, batch group) read their hardware XCC id, gather
+ * on ONE XCD and exchange h through that XCD's L2 (plain stores, L1-bypassing loads: an L2 round trip per step instead
+ * of a trip through the fabric).  It needs the dispatcher to deal the launch's workgroups evenly over the 8 XCDs
+ * (liveness only; bounded spins report otherwise in the status word): check once with mt_xcd_census (host array of 8
+ * counts; scratch32 = 32 device bytes; synchronises the stream).  (Mode 1, the same with 8 units per workgroup, lost to
+ * both and is gone.)                                                                                                    */
 int    mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                             int B, int T, int H, int mode, mt_stream_t stream);
 int    mt_xcd_census(int* counts_host, void* scratch32, int nwg, mt_stream_t stream);
+/* CUs held by persistent launches still pending on streams other than `stream` on the current device (see above). */
+int    mt_persistent_cus_in_flight(mt_stream_t stream);
 /* hx -> X[(t*B+b)*ldx + dir*H + j] bf16 (next GEMM's A) / y[b][t][dir*H + j] f32 (torch layout). */
 int    mt_lstm_relayout_bf16(const float* hx, void* X, int ldx, int B, int T, int H, mt_stream_t stream);
 int    mt_lstm_unpack_f32(const float* hx, float* y, int B, int T, int H, mt_stream_t stream);
@@ -160,7 +172,7 @@ typedef struct {
     int n_mels;                              /* input mel bins                                    */
     int hidden;                              /* LSTM hidden size (1..1024); laid out padded to 16 */
     int layers;                              /* LSTM layers (<= MT_MAX_LSTM_LAYERS)               */
-    int lstm_mode;                           /* 0 agent-scope hand-off, 1 XCD-local (mt_lstm_bidir_fwd_ex) */
+    int lstm_mode;                           /* 0 agent-scope hand-off, 2 XCD-local (mt_lstm_bidir_fwd_ex) */
     int operand_dtype;                       /* MT_DT_BF16 / MT_DT_F16: type of every 16-bit weight below and of the */
                                              /*   activations between the kernels (model.py packs f16 for inference) */
     const float* conv1_w;                    /* [32][9]  BN-folded                                */
@@ -250,7 +262,7 @@ typedef struct {
     int n_mels, hidden, layers, hidden_local;     /* real sizes (hidden_local = hidden / 2)            */
     int use_attention, use_heads, heads, head_dim_pad;  /* head_dim padded to a multiple of 64         */
     float attn_scale;                             /* (real head_dim)^-1/2                              */
-    int lstm_mode;                                /* 0 agent-scope hand-off, 1 XCD-local               */
+    int lstm_mode;                                /* 0 agent-scope hand-off, 2 XCD-local               */
     int operand_dtype;                            /* MT_DT_BF16 / MT_DT_F16 (as mt_cnnrnn_weights)     */
     const float* conv1_w; const float* conv1_b;   /* [32][9], [32]                                     */
     const void*  rb1c1_w; const float* rb1c1_b;   /* bf16 [64][9*32]                                   */

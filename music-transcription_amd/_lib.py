@@ -102,6 +102,7 @@ _SIGS = {
     "mt_lstm_bidir_fwd_xproj": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "mt_lstm_bidir_fwd_ex": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
     "mt_xcd_census": (i32, [vp, vp, i32, vp]),
+    "mt_persistent_cus_in_flight": (i32, [vp]),
     "mt_lstm_relayout_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "mt_lstm_unpack_f32": (i32, [vp, vp, i32, i32, i32, vp]),
     "mt_conv_cl_bf16": (i32, [vp, vp, vp, vp, vp] + [i32] * 11 + [vp]),

@@ -367,15 +367,21 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
 #endif
 }
 
-// XCD-local variant with FATTER workgroups: 16 hidden units (64 gate rows = two MFMA M-tiles) per workgroup, so a
-// (direction, batch group) lane has H/16 workgroups, all on one XCD, and that XCD's L2 carries half the all-gather
-// copies (the XCD-local hand-off of lstm_rec_kernel<.., true> lost at H = 512 because 64 copies of h per step went
-// through one L2).  A workgroup's 16 units are exactly one 16-wide k-step of the published layout, so it writes
-// one whole hi block and one whole lo block per step.  Everything else (row order, split-precision product,
-// poison check, bounded spins) is as in lstm_rec_kernel.
+// XCD-local variant with FATTER workgroups (mode 2): 16 hidden units (64 gate rows = two MFMA M-tiles) per workgroup, so
+// a (direction, batch group) lane is H/16 workgroups that all sit on ONE XCD (hardware XCC id + arrival ticket, as above)
+// and that XCD's L2 is the coherence point of the whole exchange:
+//   * h_t is published with PLAIN stores (they stay in this XCD's L2) and gathered with sc1 loads (L1 bypass, L2 hit):
+//     a hand-off is an L2 round trip (~0.2 us) instead of a trip through the fabric to the memory side and back (~1 us);
+//   * no flags: as in the agent-scope kernel the payload loads are the poll (poison pattern = not yet published);
+//   * half the workgroups per lane means half the all-gather copies through that one L2 (32 x 32 KB per step at H = 512;
+//     the 8-unit XCD-local variant lost to the agent-scope kernel because 64 copies per step saturated it).
+// A workgroup's 16 units are exactly one 16-wide k-step of the published layout, so it writes one whole 1-KB block per step.
+// Which XCD a workgroup lands on is the dispatcher's choice (round-robin over the 8 XCDs); that is a liveness matter only,
+// checked once by mt_xcd_census, and every spin is bounded.
+constexpr int X16_POLL_SLEEP = 2;            // s_sleep units (64 clocks) before a step's first payload poll
 template <int NKSW>
 __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4][32][64];       // [k-slice wave][M-tile*16 + reg][lane]
+    __shared__ __attribute__((aligned(16))) float red[4][64][36];       // [k-slice wave][lane][2 tiles x 16 regs + pad]: 144-B lane stride, conflict-free b128
     __shared__ __attribute__((aligned(16))) f16_t hs[64][8];            // [(unit>>3)*32 + batch][unit & 7]
     __shared__ int abort_s;
     __shared__ int ident_s[2];
@@ -414,7 +420,6 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
     const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
     char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
-    unsigned* flags = a.flags + ((size_t)g * 2 + d) * FLAG_REPL * nkb;   // replica 0 of the lane's flags; the first nwg words are used
 
     for (int s = 0; s < T; ++s) {
         const int t = d ? (T - 1 - s) : s;
@@ -432,44 +437,25 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
         if (s > 0) {
-            if (wv == 0) {
-                const unsigned* p1 = flags + (lane < nwg ? lane : nwg - 1);
-                long long t0 = 0;
-                bool ok = false;
-                for (unsigned it = 0;; ++it) {
-                    const unsigned v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned v2 = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__any(v2 != 0)) break;
-                    if (__all(v1 >= (unsigned)s)) { ok = true; break; }
-                    if ((it & 255u) == 255u) {
-                        const long long now = __builtin_amdgcn_s_memrealtime();
-                        if (t0 == 0) t0 = now;
-                        else if (now - t0 > LSTM_SPIN_LIMIT_TICKS) {
-                            if (lane == 0) __hip_atomic_store(a.status, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-                if (!ok && lane == 0) abort_s = 1;
-            }
-            __syncthreads();
-            if (abort_s) return;
+            __builtin_amdgcn_s_sleep(X16_POLL_SLEEP);
+            // gather h_{t-1} from this XCD's L2 and run the f16 MFMA chain; a word that still holds the poison pattern has not
+            // been published: redo (bounded)
             const int hbase = ((tprev * 2 + d) * nkb) * 512 + lane * 16;
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
                 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-                u32x4 rh[NKSW];
+                u32x4 rhv[NKSW];
 #pragma unroll
                 for (int i = 0; i < NKSW; ++i) {
                     const int ks = wv * NKSW + i;
-                    rh[i] = (ks < nks) ? __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 1024, 0, 16 /*sc1: bypass L1, served by this XCD's L2*/)
-                                       : u32x4{0, 0, 0, 0};
+                    rhv[i] = (ks < nks) ? __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 1024, 0, 16 /*sc1: bypass L1, served by this XCD's L2*/)
+                                        : u32x4{0, 0, 0, 0};
                 }
                 unsigned worst = 0;
 #pragma unroll
                 for (int i = 0; i < NKSW; ++i) {
-                    worst = max(max(worst, max(rh[i][0], rh[i][1])), max(rh[i][2], rh[i][3]));
-                    const f16x8 hv = __builtin_bit_cast(f16x8, rh[i]);
+                    worst = max(max(worst, max(rhv[i][0], rhv[i][1])), max(rhv[i][2], rhv[i][3]));
+                    const f16x8 hv = __builtin_bit_cast(f16x8, rhv[i]);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[m][i], hv, acc[m], 0, 0, 0);
                 }
@@ -478,6 +464,10 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+                if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
+                    break;
+                }
                 if ((it & 255u) == 255u) {
                     const long long now = __builtin_amdgcn_s_memrealtime();
                     if (t1 == 0) t1 = now;
@@ -491,33 +481,32 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
                 }
             }
         }
+        // ---- sum the four K-slices through LDS (b128 both ways); wave wv finishes gate rows 8wv + 4h + p of both tiles
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) red[wv][m * 16 + e][lane] = acc[m][e];
+            for (int e4 = 0; e4 < 4; ++e4)
+                *(f32x4*)(&red[wv][lane][m * 16 + 4 * e4]) = f32x4{acc[m][4 * e4], acc[m][4 * e4 + 1], acc[m][4 * e4 + 2], acc[m][4 * e4 + 3]};
         __syncthreads();
         if (abort_s) return;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
+            const f32x4 r0 = *(const f32x4*)(&red[0][lane][m * 16 + 4 * wv]), r1 = *(const f32x4*)(&red[1][lane][m * 16 + 4 * wv]);
+            const f32x4 r2 = *(const f32x4*)(&red[2][lane][m * 16 + 4 * wv]), r3 = *(const f32x4*)(&red[3][lane][m * 16 + 4 * wv]);
             float pre[4];
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const int e = m * 16 + 4 * wv + pp;
-                pre[pp] = ((red[0][e][lane] + red[1][e][lane]) + (red[2][e][lane] + red[3][e][lane])) + gxv[m][pp];
-            }
+            for (int pp = 0; pp < 4; ++pp) pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + gxv[m][pp];
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
             c[m] = fmaf(fg, c[m], ig * gg);
             const float hval = og * tanhf_(c[m]);
             hs[m * 32 + b][jl] = (f16_t)hval;            // block lane = (k half = m)*32 + batch, element = unit & 7
         }
-        __syncthreads();
+        __syncthreads();                                 // block assembled; every wave is done with `red`
         if (wv == 0) {
             typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
             const u32x4 ph = *(const u32x4*)(&hs[lane][0]);
             const int hoff = ((t * 2 + d) * nkb) * 512 + wg * 1024 + lane * 16;
             __builtin_amdgcn_raw_buffer_store_b128(ph, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) *(volatile unsigned*)(flags + wg) = (unsigned)(s + 1);
         }
     }
 }
@@ -569,19 +558,37 @@ __global__ void lstm_unpack_kernel(const f16_t* __restrict__ hx, float* __restri
     }
 }
 
+int persistent_admit(const void* kernel, int block, size_t smem, int nwg, hipStream_t st, const char* who);   // residency.hip
+int persistent_mark(hipStream_t st);
+
+// every workgroup of a persistent launch must be resident: admission check first (fails fast), completion event behind it
+#define MT_PERSISTENT_LAUNCH(kernel, grid, who)                                                                   \
+    do {                                                                                                          \
+        const dim3 g_ = (grid);                                                                                   \
+        int rc_ = persistent_admit((const void*)(kernel), 256, 0, (int)(g_.x * g_.y * g_.z), st, who);            \
+        if (rc_ != MT_OK) return rc_;                                                                             \
+        hipLaunchKernelGGL((kernel), g_, dim3(256), 0, st, a);                                                    \
+        MT_CHECK_LAUNCH();                                                                                        \
+        if ((rc_ = persistent_mark(st)) != MT_OK) return rc_;                                                     \
+    } while (0)
+
 template <int NKSW>
 static int launch_rec16(const LstmArgs& a, hipStream_t st) {
+    // (6 of the 8 XCDs' workgroups leave at once when the launch has one batch group: only the lanes' 2 x H/16 stay)
+    const int stay = a.nlanes * (a.H >> 4);
+    int rc = persistent_admit((const void*)lstm_rec16_kernel<NKSW>, 256, 0, stay, st, "mt_lstm_bidir_fwd (XCD-local)");
+    if (rc != MT_OK) return rc;
     hipLaunchKernelGGL((lstm_rec16_kernel<NKSW>), dim3(8 * (a.H >> 4)), dim3(256), 0, st, a);
-    return 0;
+    MT_CHECK_LAUNCH();
+    return persistent_mark(st);
 }
 
 template <int NKSW>
-static int launch_rec(const LstmArgs& a, int ngroups, bool xcd, hipStream_t st) {
-    if (a.w_ihx) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false, false, true>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
-    else if (a.cx) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
-    else if (xcd) hipLaunchKernelGGL((lstm_rec_kernel<NKSW, true>), dim3(8 * (a.H >> 3)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((lstm_rec_kernel<NKSW, false>), dim3(a.H >> 3, 2, ngroups), dim3(256), 0, st, a);
-    return 0;
+static int launch_rec(const LstmArgs& a, int ngroups, hipStream_t st) {
+    if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
+    else if (a.cx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_train");
+    else MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd");
+    return MT_OK;
 }
 
 }  // namespace mt
@@ -640,19 +647,19 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
         a.nlanes = 2 * n;
         a.xcd_off = xcd_local ? (int)(rotate.fetch_add(2 * n) & 7) : 0;
         if (xcd_local && g0 > 0) MT_CHECK_HIP(hipMemsetAsync((char*)sync_ws + 32, 0, 32, st));   // fresh tickets per launch
-        const bool x = xcd_local != 0;
+        int rc;
         if (xcd_local == 2) {                  // XCD-local, 16 units per workgroup
-            if (nksw <= 1) launch_rec16<1>(a, st);
-            else if (nksw <= 2) launch_rec16<2>(a, st);
-            else if (nksw <= 4) launch_rec16<4>(a, st);
-            else if (nksw <= 8) launch_rec16<8>(a, st);
-            else launch_rec16<16>(a, st);
-        } else if (nksw <= 1) launch_rec<1>(a, n, x, st);
-        else if (nksw <= 2) launch_rec<2>(a, n, x, st);
-        else if (nksw <= 4) launch_rec<4>(a, n, x, st);
-        else if (nksw <= 8) launch_rec<8>(a, n, x, st);
-        else launch_rec<16>(a, n, x, st);
-        MT_CHECK_LAUNCH();
+            if (nksw <= 1) rc = launch_rec16<1>(a, st);
+            else if (nksw <= 2) rc = launch_rec16<2>(a, st);
+            else if (nksw <= 4) rc = launch_rec16<4>(a, st);
+            else if (nksw <= 8) rc = launch_rec16<8>(a, st);
+            else rc = launch_rec16<16>(a, st);
+        } else if (nksw <= 1) rc = launch_rec<1>(a, n, st);
+        else if (nksw <= 2) rc = launch_rec<2>(a, n, st);
+        else if (nksw <= 4) rc = launch_rec<4>(a, n, st);
+        else if (nksw <= 8) rc = launch_rec<8>(a, n, st);
+        else rc = launch_rec<16>(a, n, st);
+        if (rc != MT_OK) return rc;
     }
     return MT_OK;
 }
@@ -684,7 +691,7 @@ extern "C" int mt_lstm_bidir_fwd_train(float* gx_inout, const float* w_hh, float
 // (see lstm_rec_kernel); mode 2: XCD-local, 16 units per workgroup (lstm_rec16_kernel).
 extern "C" int mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                                     int B, int T, int H, int mode, mt_stream_t stream) {
-    MT_REQUIRE(mode >= 0 && mode <= 2, MT_EINVAL, "mt_lstm_bidir_fwd_ex: mode must be 0, 1 or 2");
+    MT_REQUIRE(mode == 0 || mode == 2, MT_EINVAL, "mt_lstm_bidir_fwd_ex: mode must be 0 (agent-scope hand-off) or 2 (XCD-local, 16 units per workgroup)");
     return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, mode, stream);
 }
 

@@ -326,6 +326,10 @@ __global__ void dlogits_pack_kernel(const float* __restrict__ dl, bf16_t* __rest
 
 }  // namespace mt
 
+namespace mt {
+int persistent_admit(const void* kernel, int block, size_t smem, int nwg, hipStream_t st, const char* who);   // residency.hip
+int persistent_mark(hipStream_t st);
+}
 using namespace mt;
 
 extern "C" size_t mt_lstm_dgx_bytes(int B, int T, int H) {
@@ -364,10 +368,14 @@ extern "C" int mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const f
     LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, part_ws, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
     dim3 grid(NW, 2, NG);
     MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);
+    // every workgroup of this persistent launch must be resident: admission check (residency.hip), completion event behind it
+    const void* kern = NW <= 8 ? (const void*)lstm_bptt_kernel<1> : (const void*)lstm_bptt_kernel<2>;
+    int rc = persistent_admit(kern, 512, 0, NW * 2 * NG, st, "mt_lstm_bidir_bwd");
+    if (rc != MT_OK) return rc;
     if (NW <= 8) hipLaunchKernelGGL(lstm_bptt_kernel<1>, grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(512), 0, st, a);
     MT_CHECK_LAUNCH();
-    return MT_OK;
+    return persistent_mark(st);
 }
 
 extern "C" int mt_lstm_bidir_bwd(const float* gates, const float* cx, const float* dh, const float* w_hh, void* dgx, void* part_ws,

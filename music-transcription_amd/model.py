@@ -30,15 +30,14 @@ _LSTM_MODE: Dict[int, int] = {}
 
 def lstm_mode(device) -> int:
     """Hand-off protocol of the recurrence kernel on this device: 0 = agent-scope (default; correct under any
-    workgroup placement), 1 = XCD-local (csrc/lstm.hip; experimental: measured SLOWER at H = 512, B = 32 because a
-    lane's whole all-gather then goes through one XCD's L2 -- 5.0 vs 4.4 us/step).  MT_LSTM_MODE=1 opts in, and
-    only takes effect if a census launch shows the dispatcher dealing workgroups evenly over the 8 XCDs."""
+    workgroup placement), 2 = XCD-local with 16 units per workgroup (csrc/lstm.hip).  MT_LSTM_MODE=2 opts in, and only
+    takes effect if a census launch shows the dispatcher dealing workgroups evenly over the 8 XCDs."""
     import os
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx not in _LSTM_MODE:
         env = os.environ.get("MT_LSTM_MODE", "0")
-        if env != "1":
+        if env != "2":
             _LSTM_MODE[idx] = 0
         else:
             import ctypes
@@ -49,7 +48,7 @@ def lstm_mode(device) -> int:
                 for nwg in (512, 256, 128):
                     check(lib.mt_xcd_census(counts, ptr(scratch), nwg, _lib.stream_ptr()), "mt_xcd_census")
                     ok = ok and all(c == nwg // 8 for c in counts)
-            _LSTM_MODE[idx] = 1 if ok else 0
+            _LSTM_MODE[idx] = int(env) if ok else 0
     return _LSTM_MODE[idx]
 
 
@@ -288,7 +287,7 @@ class CNNRNNModel(nn.Module, _HipForward):
         env = os.environ.get("MT_LSTM_XPROJ")
         fuse = (env == "1") if env in ("0", "1") else bool(getattr(self, "fuse_input_projection", False))
         if key not in self._ws:
-            self._check_inflight_bound(key, 3 if fuse else 6, "CNNRNNModel.forward")
+            self._check_inflight_bound(key, 2 if fuse else 6, "CNNRNNModel.forward")
             nbytes = lib.mt_cnnrnn_workspace_bytes(w, B, T)
             if nbytes == 0:
                 raise _lib.MtError("mt_cnnrnn_workspace_bytes: " + _lib.last_error())
@@ -305,8 +304,8 @@ class CNNRNNModel(nn.Module, _HipForward):
         # Layers > 0 can take their input projection inside the recurrence (no GEMM, no gx buffer, no re-layout between LSTM
         # layers; csrc/lstm.hip, XP).  It lengthens the latency-bound recurrence and removes GEMM work: a loss with one batch in
         # flight, a gain with several (the GEMMs are the shared resource then) -- so the caller decides.  MT_LSTM_XPROJ=0/1 forces it.
-        # A fused recurrence workgroup fills a CU's register file (one per CU, 256 per GPU = two launches): keep at most THREE
-        # forwards of this model in flight per GPU with it (see bench.py), at most six without.
+        # A fused recurrence workgroup fills a CU's register file (one per CU, 256 per GPU = two launches): at most TWO forwards
+        # of this model in flight per GPU with it, at most six without (the library refuses more: csrc/residency.hip).
         for l in range(1, self.num_layers):
             w.w_ihx[l] = ptr(pk["tensors"][f"w_ihx{l}"]) if (fuse and self.hidden_size <= 512) else None
         with torch.cuda.device(x.device):
