@@ -41,6 +41,7 @@
 // timeout the workgroup raises the abort word, which every other workgroup's spin also watches, and all leave.
 #include "mt_common.h"
 #include <atomic>
+#include <stdlib.h>
 
 namespace mt {
 
@@ -65,7 +66,14 @@ struct LstmArgs {
     const float* w_ihx;   // [2][4H][2H] f32, column = direction' * H + unit of the previous layer (zero columns for padded units)
     const float* bias;    // [2][4H] = b_ih + b_hh
     const float* hx_prev; // the previous layer's hx (complete: written by an earlier launch)
+    // poll pacing (units of 64 clocks): delay before a step's first payload poll, delay before every retry; tuning knobs
+    // (MT_LSTM_POLL_FIRST / MT_LSTM_POLL_RETRY in the environment, read once)
+    int sleep_first, sleep_retry;
 };
+
+__device__ __forceinline__ void sleep64(int n) {
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each): absolute error ~1e-7, saturate cleanly for |x| large
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
                 // the producers' stores become visible instead of two (flag, then payload): 2.45 -> 1.88 us/step.  The short
                 // sleep keeps the first, certain-to-fail attempt (issued right behind this workgroup's own publish) off the
                 // fabric; every wave polls its own k-steps, the only workgroup barrier left is the LDS reduce.
-                __builtin_amdgcn_s_sleep(PAYLOAD_POLL_SLEEP);
+                sleep64(a.sleep_first);
             }
             // ---- gather h_{t-1} (one 16-B sc1 load per lane per k-step) and run the f16 MFMA chain (f32 accumulate).
             //      A word still holding the poison pattern means its store has not landed: redo (rare, bounded).
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
                 if (!__any(worst == H_POISON)) break;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                sleep64(a.sleep_retry);
                 if (!XCD && (it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
                     break;
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
         if (s > 0) {
-            __builtin_amdgcn_s_sleep(X16_POLL_SLEEP);
+            sleep64(a.sleep_first);
             // gather h_{t-1} from this XCD's L2 and run the f16 MFMA chain; a word that still holds the poison pattern has not
             // been published: redo (bounded)
             const int hbase = ((tprev * 2 + d) * nkb) * 512 + lane * 16;
@@ -464,6 +473,7 @@ __global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
+                sleep64(a.sleep_retry);
                 if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
                     break;
@@ -633,8 +643,11 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
     MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
     // sync_ws: [0] status word, [32..64) XCD tickets, [256..) flags (own cache lines, away from the polled status word)
+    static const int env_first = getenv("MT_LSTM_POLL_FIRST") ? atoi(getenv("MT_LSTM_POLL_FIRST")) : -1;
+    static const int env_retry = getenv("MT_LSTM_POLL_RETRY") ? atoi(getenv("MT_LSTM_POLL_RETRY")) : -1;
     LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, 0, (unsigned*)((char*)sync_ws + 32), 0, 0,
-               cx ? const_cast<float*>(gx) : nullptr, cx, w_ihx, bias, hx_prev};
+               cx ? const_cast<float*>(gx) : nullptr, cx, w_ihx, bias, hx_prev,
+               env_first >= 0 ? env_first : (xcd_local ? X16_POLL_SLEEP : PAYLOAD_POLL_SLEEP), env_retry >= 0 ? env_retry : 0};
     // every workgroup of a launch must be resident (they wait on each other).  Agent-scope variant: at most 256
     // workgroups (one per CU) per launch; XCD-local variant: at most 8 lanes = 4 batch groups per launch, each lane's
     // H/8 workgroups share one XCD (H/8 <= 128 -> at most 4 per CU).  Further groups run as further launches.
