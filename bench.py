@@ -44,7 +44,7 @@ def stage_table(B, T, n_mels, H, L, fused=False):
     M = B * T
     st = [("mel_kernel", "hbm", B * (4 * N_SAMPLES + 4 * n_mels * T), "B"),
           ("conv1_kernel", "hbm", B * (4 * n_mels * T + 2 * 32 * F1 * T), "B"),
-          ("conv2_kernel", "mfma", 2.0 * B * (2 * Fo2) * T * 64 * 288, "FLOP")]
+          ("conv2_kernel", "mfma", 2.0 * B * (2 * Fo2) * T * 64 * 288, "FLOP")]        # "mfma": f16 operands (inference)
     for l in range(L):
         K = Fo2 * 64 if l == 0 else 2 * H
         proj = 2.0 * M * 8 * H * K
@@ -220,6 +220,234 @@ def bench_train(args):
         dist.destroy_process_group()
 
 
+def _roofline_from_stages(stages, share_of=None):
+    """Dominant kernel = largest total time; launches of one kernel (its per-layer stages) are averaged."""
+    groups = {}
+    for s in stages:
+        key = s["kernel"].rsplit("_l", 1)[0] if ("_l" in s["kernel"] and s["kernel"].rsplit("_l", 1)[1].isdigit()) else s["kernel"]
+        g = groups.setdefault(key, {"ms": 0.0, "work": 0.0, "n": 0, "ref": s})
+        if s["ms"] > 0 and s["work_per_launch"] > 0:
+            g["ms"] += s["ms"]; g["work"] += s["work_per_launch"]; g["n"] += 1
+    groups = {k: g for k, g in groups.items() if g["n"]}
+    dom_key = max(groups, key=lambda k: groups[k]["ms"])
+    g = groups[dom_key]
+    avg_ms, avg_work = g["ms"] / g["n"], g["work"] / g["n"]
+    ref = g["ref"]
+    ach = avg_work / (avg_ms * 1e-3) / (1e9 if ref["work_unit"] == "B" else 1e12)
+    total = share_of if share_of else sum(s["ms"] for s in stages)
+    return dom_key, {"kernel": dom_key, "bound": ref["bound"], "achieved": round(ach, 2), "peak": ref["peak"], "unit": ref["unit"],
+                     "frac": round(ach / ref["peak"], 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": g["n"],
+                     "share_of_step": round(g["ms"] / total, 3), "mfma_dtype": ref["mfma_dtype"]}
+
+
+def _stage_rows(table, ms):
+    stages = []
+    for (name, bound, work, unit), t_ms in zip(table, ms):
+        if unit == "B":
+            ach, peak, u = work / (max(t_ms, 1e-6) * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
+        else:
+            ach = work / (max(t_ms, 1e-6) * 1e-3) / 1e12
+            peak, u = PEAK_BF16_TFLOPS, "TFLOP/s"                         # f16 peak = bf16 peak
+        stages.append({"kernel": name, "bound": "hbm" if bound == "hbm" else "mfma", "ms": round(t_ms, 4), "achieved": round(ach, 2),
+                       "peak": peak, "unit": u, "frac": round(ach / peak, 4), "work_per_launch": work, "work_unit": unit,
+                       "mfma_dtype": {"mfma": "f16", "mfma_bf16": "bf16", "mfma_f16": "f16"}.get(bound)})
+    return stages
+
+
+def large_stage_table(B, T, n_mels, H, L):
+    """Stages of mt_cnnrnn_large_forward_ev in order, with their algorithmic work (SURVEY 8d / BASELINE.md section 4)."""
+    F1, F2, F3 = n_mels // 2, n_mels // 4, n_mels // 8
+    N1, N2, M, Hl = B * F1 * T, B * F2 * T, B * T, H // 2
+    K0, comb, heads = F3 * 256, 2 * H + 2 * (H // 2), 8
+    dh = comb // heads
+    st = [("conv1_kernel", "hbm", B * (4 * n_mels * T + 2 * 32 * F1 * T), "B"),
+          ("convg_res_block1", "mfma", 2.0 * N1 * 64 * (9 * 32) + 2.0 * N1 * 64 * (9 * 64 + 32), "FLOP"),
+          ("convg_res_block2", "mfma", 2.0 * N2 * 128 * (9 * 64) + 2.0 * N2 * 128 * (9 * 128 + 64), "FLOP"),
+          ("convg_freq_aware_7x3", "mfma", 2.0 * N2 * 256 * (21 * 128), "FLOP"),
+          ("gemm_lstm_gx_local", "mfma", 2.0 * M * 8 * Hl * K0, "FLOP"),
+          ("lstm_rec_local", "mfma_f16", 2.0 * M * 8 * Hl * Hl, "FLOP"),
+          ("lstm_relayout_local", "hbm", M * 2 * Hl * (2 + 2 + 4), "B")]
+    for l in range(L):
+        K = K0 if l == 0 else 2 * H
+        st += [(f"gemm_lstm_gx_l{l}", "mfma", 2.0 * M * 8 * H * K, "FLOP"), (f"lstm_rec_l{l}", "mfma_f16", 2.0 * M * 8 * H * H, "FLOP"),
+               (f"lstm_relayout_l{l}", "hbm", M * 2 * H * (2 + 2 + (4 if l == L - 1 else 0)), "B")]
+    st += [("attention_layernorm", "mfma", 2.0 * M * comb * 3 * comb + 2 * 2.0 * B * heads * T * T * dh + 2.0 * M * comb * comb, "FLOP"),
+           ("heads", "mfma", 2.0 * M * comb * H + 2.0 * M * H * 264, "FLOP")]
+    return st
+
+
+def cpu_baseline_small(model, wave, logits, cores):
+    """The CPU oracle (port of the reference path) on this node's host cores: batch 1 (the reference's main.py:258 loop) on a
+    bounded sample, and batch 8 on one batch."""
+    import numpy as np
+    import torch
+    from oracle import frontend_ref, model_ref      # the CPU port of the reference path: used ONLY in this leg
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    w1 = wave[:1].cpu().numpy()
+
+    def run(w_np):
+        m = frontend_ref.audio_to_mel_batch(w_np, SR, N_MELS, HOP)          # main.py:117-125
+        with torch.no_grad():
+            return model_ref.cnnrnn_forward(sd, torch.from_numpy(m), model_ref.Opts(fast_lstm=True))
+    t1 = time.perf_counter(); ref_logits = run(w1); first = time.perf_counter() - t1
+    log(f"cpu baseline: first chunk {first:.2f} s on {cores} threads")
+    n = int(max(2, min(16, 8.0 / max(first, 1e-3))))
+    t1 = time.perf_counter()
+    for _ in range(n):
+        run(w1)
+    dt = time.perf_counter() - t1
+    cpu = {"value": round(n / dt, 3), "unit": "chunks/s", "cores": cores, "kind": "port",
+           "sample": f"{n} chunks, batch 1 (the reference's main.py:258 loop): numpy STFT/mel/dB + fp32 torch-CPU CNNRNNModel forward "
+                     f"(oracle/frontend_ref.py + oracle/model_ref.py), {cores} threads",
+           "max_abs_logit_diff_vs_gpu": round(float((logits[0].cpu() - ref_logits[0]).abs().max()), 5)}
+    w8 = wave[:8].cpu().numpy()
+    t1 = time.perf_counter(); run(w8); dt8 = time.perf_counter() - t1
+    cpu["batch8"] = {"value": round(8 / dt8, 3), "unit": "chunks/s", "sample": "1 batch of 8 chunks, same path"}
+    return cpu
+
+
+def section_large(mta, dev, cores, do_cpu):
+    """BASELINE.json configs[2]: CNNRNNModelLarge (89M), batch 16, 1 GPU: throughput with 3 batches in flight, an un-overlapped
+    1-stream pass for per-kernel efficiencies, the CPU oracle beside it."""
+    import numpy as np
+    import torch
+    B, NS, K, K1 = 16, 3, 30, 4
+    T = mta.num_frames(N_SAMPLES, HOP)
+    base = synth_audio(4, N_SAMPLES, seed=1234)
+    wave = torch.from_numpy(np.concatenate([base] * 4)[:B].copy()).to(dev)
+    model = seeded_model(mta, "cnn_rnn_large", str(dev)).eval()
+    net = model.model
+    fe = mta.MelFrontend(SR, N_MELS, HOP, dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
+    cmax = [torch.empty(B, device=dev) for _ in range(NS)]
+
+    def step(j, events=None, s=None):
+        s = j % NS if s is None else s
+        with torch.cuda.stream(streams[s]), torch.no_grad():
+            fe(wave, clamp=False, out=mel[s], chunk_max=cmax[s])
+            return net(mel[s], chunk_max_power=cmax[s], events=events)
+    for j in range(NS + 1):
+        step(j)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(K):
+        out = step(j)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    net.raise_on_handoff_timeout(B, T)
+    nst = lib_stages = None
+    from music_transcription_amd._lib import lib
+    nst = lib.mt_cnnrnn_large_num_stages(LAYERS)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K1)]
+    with torch.cuda.stream(streams[0]):
+        for row in evs:
+            for e in row:
+                e.record()
+    torch.cuda.synchronize()
+    for i in range(K1):
+        step(i, events=evs[i], s=0)
+    torch.cuda.synchronize()
+    ms = [float(np.mean([evs[i][k].elapsed_time(evs[i][k + 1]) for i in range(K1)])) for k in range(nst)]
+    stages = _stage_rows(large_stage_table(B, T, N_MELS, HIDDEN, LAYERS), ms)
+    _, roof = _roofline_from_stages(stages)
+    roof["traffic_source"] = None
+    sec = {"workload": "CNNRNNModelLarge inference, batch=16 (BASELINE.json configs[2])", "value": round(B * K / el, 2), "unit": "chunks/s",
+           "ms_per_step": round(1e3 * el / K, 3), "steps": K, "streams_per_gpu": NS, "dtype": "f16 MFMA operands, f32 accumulate / LSTM state",
+           "model_tflops_per_s": round(326.47e9 * B * T / 938.0 * K / el / 1e12, 1), "one_stream_ms_per_step": round(sum(ms), 3),
+           "roofline": roof, "stages_one_stream": stages, "finite": bool(torch.isfinite(out).all())}
+    if do_cpu:
+        from oracle import frontend_ref, model_ref
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        w1 = wave[:1].cpu().numpy()
+        n = 2
+        t1 = time.perf_counter()
+        for _ in range(n):
+            m = frontend_ref.audio_to_mel_batch(w1, SR, N_MELS, HOP)
+            with torch.no_grad():
+                ref = model_ref.cnnrnn_large_forward(sd, torch.from_numpy(m), o=model_ref.Opts(fast_lstm=True))
+        dt = time.perf_counter() - t1
+        with torch.no_grad():
+            got = step(0, s=0)
+        torch.cuda.synchronize()
+        sec["cpu_baseline"] = {"value": round(n / dt, 3), "unit": "chunks/s", "cores": cores, "kind": "port",
+                               "sample": f"{n} chunks, batch 1, numpy frontend + fp32 torch-CPU CNNRNNModelLarge forward (oracle), {cores} threads",
+                               "max_abs_logit_diff_vs_gpu": round(float((got[0].cpu() - ref[0]).abs().max()), 5)}
+    return sec
+
+
+def section_train(mta, dev, cores, do_cpu):
+    """BASELINE.json configs[3] on one GPU: CNNRNNModel training step, batch 16 cached-format chunks (ragged T in [469, 937],
+    Bernoulli(0.04) rolls): train-mode forward + masked BCE + backward + fused clip/Adam.  (The 8-GPU form adds one all-reduce of the
+    flat gradient per step: `bench.py --mode train` under torchrun.)"""
+    import numpy as np
+    import torch
+    B, K, W, T = 16, 6, 2, 937
+    g = torch.Generator().manual_seed(1234)
+    model = seeded_model(mta, "cnn_rnn", str(dev), dropout=0.3)
+    opt = mta.make_optimizer(model, lr=1e-4)
+    lengths = torch.randint(469, T + 1, (B,), generator=g)
+    lengths[0] = T
+    mel = torch.rand(B, 1, N_MELS, T, generator=g) * 60.0 - 70.0
+    roll = (torch.rand(B, 88, T, generator=g) < 0.04).float()
+    for b in range(B):
+        mel[b, :, :, lengths[b]:] = 0.0
+        roll[b, :, lengths[b]:] = 0.0
+    meld, rolld = mel.to(dev), roll.to(dev)
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        loss = model.compute_loss(model(meld), rolld, lengths)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    model.model.raise_on_train_handoff_timeout()
+    # per-launch times of the persistent recurrences and the projection GEMMs (events on the launch stream)
+    model.model._profile = []
+    step()
+    torch.cuda.synchronize()
+    spans = {}
+    for name, a, b in model.model._profile:
+        spans.setdefault(name, []).append(a.elapsed_time(b))
+    model.model._profile = None
+    M = B * T
+    table, ms = [], []
+    for l in range(LAYERS):
+        Kl = (N_MELS // 4) * 64 if l == 0 else 2 * HIDDEN
+        for nm_, bound, work in ((f"gemm_lstm_gx_l{l}", "mfma_bf16", 2.0 * M * 8 * HIDDEN * Kl), (f"lstm_rec_train_l{l}", "mfma_f16", 2.0 * M * 8 * HIDDEN * HIDDEN),
+                                 (f"lstm_bptt_l{l}", "mfma_bf16", 2.0 * M * 8 * HIDDEN * HIDDEN)):
+            if nm_ in spans:
+                table.append((nm_, bound, work, "FLOP")); ms.append(float(np.mean(spans[nm_])))
+    stages = _stage_rows(table, ms)
+    _, roof = _roofline_from_stages(stages, share_of=1e3 * el / K)
+    sec = {"workload": "CNNRNNModel training step, batch=16 cached-format chunks, 1 GPU (BASELINE.json configs[3] per-GPU shape)",
+           "value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_step": round(1e3 * el / K, 3), "steps": K,
+           "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "model_tflops_per_s": round(3.0 * 72.76e9 * B * T / 938.0 * K / el / 1e12, 1),
+           "roofline": roof, "stages_timed": stages, "final_loss": round(float(loss.item()), 5)}
+    if do_cpu:
+        from oracle import model_ref
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        nb = 2
+        batch = [(mel[:nb, :, :, :].clone(), roll[:nb].clone(), lengths[:nb].clone())]
+        t1 = time.perf_counter()
+        model_ref.train_steps(sd, batch, o=model_ref.Opts(fast_lstm=True))
+        dt = time.perf_counter() - t1
+        sec["cpu_baseline"] = {"value": round(nb / dt, 3), "unit": "chunks/s", "cores": cores, "kind": "port",
+                               "sample": f"1 step on {nb} chunks: fp32 torch-CPU train-mode forward + autograd backward + clip + Adam (oracle.train_steps), {cores} threads"}
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +457,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight per GPU (each step is issued whole on stream i %% streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sections", action="store_true", help="only the headline line: skip the 1-stream pass and the configs[2] / configs[3] sections")
     ap.add_argument("--model", choices=["cnn_rnn", "cnn_rnn_large"], default="cnn_rnn",
                     help="cnn_rnn = the bench line (BASELINE configs[1]); cnn_rnn_large = informational run of configs[2] "
                          "(use --batch 16): whole-step timing only")
@@ -329,88 +558,92 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- an un-overlapped pass: ONE batch in flight, so that per-kernel times are kernel efficiencies, not contention
+    one_ms = None
+    if rank == 0 and not args.no_sections:
+        K1 = 10
+        fused_hl = bool(net.fuse_input_projection)
+        net.fuse_input_projection = False
+        ev1m = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K1)]
+        ev1n = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K1)]
+        with torch.cuda.stream(streams[0]), torch.no_grad():
+            for row in ev1m + ev1n:
+                for e in row:
+                    e.record()
+            for i in range(K1 + 1):
+                ii = max(i - 1, 0)                       # (first iteration = warm-up of the un-fused path, overwritten)
+                ev1m[ii][0].record()
+                fe(wave, clamp=False, out=mel[0], chunk_max=cmax[0])
+                ev1m[ii][1].record()
+                net(mel[0], chunk_max_power=cmax[0], events=ev1n[ii])
+        torch.cuda.synchronize()
+        net.raise_on_handoff_timeout(B, T)
+        one_ms = [float(np.mean([ev1m[i][0].elapsed_time(ev1m[i][1]) for i in range(K1)]))]
+        for s_ in range(nst):
+            one_ms.append(float(np.mean([ev1n[i][s_].elapsed_time(ev1n[i][s_ + 1]) for i in range(K1)])))
+        net.fuse_input_projection = fused_hl
+
     if rank == 0:
-        # ---- per-kernel times from the events recorded inside the timed region
+        # ---- per-kernel times from the events recorded inside the timed region (several batches in flight: kernels of
+        #      different steps overlap, so these are NOT kernel efficiencies -- those come from the 1-stream pass below)
         table = stage_table(B, T, N_MELS, HIDDEN, LAYERS, fused=bool(net.fuse_input_projection))
         ms = [float(np.mean([ev_mel[i][0].elapsed_time(ev_mel[i][1]) for i in range(K)]))]
         for s in range(nst):
             ms.append(float(np.mean([ev_net[i][s].elapsed_time(ev_net[i][s + 1]) for i in range(K)])))
-        stages = []
-        for (name, bound, work, unit), t_ms in zip(table, ms):
-            if unit == "B":
-                ach, peak, u = work / (max(t_ms, 1e-6) * 1e-3) / 1e9, PEAK_HBM_GBS, "GB/s"
-            else:
-                ach = work / (max(t_ms, 1e-6) * 1e-3) / 1e12
-                peak, u = (PEAK_F32_MATRIX_TFLOPS if bound == "mfma_f32" else PEAK_BF16_TFLOPS), "TFLOP/s"    # f16 peak = bf16 peak
-            stages.append({"kernel": name, "bound": "hbm" if bound == "hbm" else "mfma", "ms": round(t_ms, 4),
-                           "achieved": round(ach, 2), "peak": peak, "unit": u, "frac": round(ach / peak, 4),
-                           "work_per_launch": work, "work_unit": unit,
-                           "mfma_dtype": {"mfma": "bf16", "mfma_f32": "f32", "mfma_f16": "f16"}.get(bound)})
-        # dominant kernel = largest share of the step; the three recurrence launches are one kernel
-        groups = {}
-        for s in stages:
-            key = s["kernel"].rsplit("_l", 1)[0] if "_l" in s["kernel"] else s["kernel"]
-            g = groups.setdefault(key, {"ms": 0.0, "work": 0.0, "n": 0, "ref": s})
-            g["ms"] += s["ms"]; g["work"] += s["work_per_launch"]; g["n"] += 1
-        dom_key = max(groups, key=lambda k: groups[k]["ms"])
-        g = groups[dom_key]
-        avg_ms, avg_work = g["ms"] / g["n"], g["work"] / g["n"]
-        ref = g["ref"]
-        ach = avg_work / (avg_ms * 1e-3) / (1e9 if ref["work_unit"] == "B" else 1e12)
-        # HBM bytes per launch from the committed PMC profile of this same command (separate --pmc passes,
-        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/r01_pmc_traffic.json
-        traffic = None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            hit = [v for k, v in prof.items() if dom_key.replace("_l", "").split("_gx")[0] in k.replace("::", "_")]
-            if dom_key == "lstm_rec":
-                hit = [v for k, v in prof.items() if "lstm_rec_kernel" in k]
-            if hit and B == 32:      # launch-weighted mean over the kernel's variants (plain / fused-projection recurrence)
-                traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
-        except Exception:
-            traffic = None
-        roofline = {"kernel": dom_key, "bound": ref["bound"], "achieved": round(ach, 2), "peak": ref["peak"],
-                    "unit": ref["unit"], "frac": round(ach / ref["peak"], 4), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": g["n"],
-                    "share_of_step": round(g["ms"] / sum(ms), 3), "mfma_dtype": ref["mfma_dtype"]}
+        stages_overlapped = _stage_rows(table, ms)
+        dom_key_o, roofline_overlapped = _roofline_from_stages(stages_overlapped)
+        if one_ms is not None:
+            stages = _stage_rows(stage_table(B, T, N_MELS, HIDDEN, LAYERS, fused=False), one_ms)
+        else:
+            stages = stages_overlapped
+        dom_key, roofline = _roofline_from_stages(stages)
+        roofline["measured_in"] = "1-stream pass of this run (one batch in flight)" if one_ms is not None else "timed region (batches overlap)"
+        # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the committed
+        # rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950), and the line says so
+        traffic, tsrc = None, None
+        for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
+                hit = [v for k, v in prof.items() if ("lstm_rec" in k if dom_key == "lstm_rec" else dom_key.split("_l")[0] in k.replace("::", "_"))]
+                if hit and B == 32:
+                    traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
+                    tsrc = f"profiles/{fname} (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
+                    break
+            except Exception:
+                continue
+        roofline["traffic"], roofline["traffic_source"] = traffic, tsrc
 
         # ---- CPU baseline: the oracle (port of the reference path) on this node's host cores
         cpu = None
+        cores = host_cores()
         if not args.no_cpu_baseline and world == 1:
-            from oracle import frontend_ref, model_ref      # the CPU port of the reference path: used ONLY in this leg
-            cores = host_cores()
-            log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
-            torch.set_num_threads(cores)
-            w_np = wave[:1].cpu().numpy()
-            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-            def cpu_chunk():
-                m = frontend_ref.audio_to_mel_batch(w_np, SR, N_MELS, HOP)          # main.py:117-125
-                with torch.no_grad():
-                    return model_ref.cnnrnn_forward(sd, torch.from_numpy(m), model_ref.Opts(fast_lstm=True))
-            t1 = time.perf_counter(); ref_logits = cpu_chunk(); first = time.perf_counter() - t1
-            log(f"cpu baseline: first chunk {first:.2f} s")
-            n = int(max(2, min(24, 15.0 / max(first, 1e-3))))
-            t1 = time.perf_counter()
-            for _ in range(n):
-                cpu_chunk()
-            dt = time.perf_counter() - t1
-            cpu = {"value": round(n / dt, 3), "unit": "chunks/s", "cores": cores, "kind": "port",
-                   "sample": f"{n} chunks, batch 1 (the reference's main.py:258 loop): numpy STFT/mel/dB + fp32 torch-CPU "
-                             f"CNNRNNModel forward (oracle/frontend_ref.py + oracle/model_ref.py), {cores} threads"}
-            # the timed GPU logits for chunk 0 must agree with the oracle (same weights, same audio)
-            err = float((logits[0].cpu() - ref_logits[0]).abs().max())
-            cpu["max_abs_logit_diff_vs_gpu"] = round(err, 5)
+            cpu = cpu_baseline_small(model, wave, logits, cores)
+        sections = {}
+        if world == 1 and not args.no_sections:
+            del mel, cmax
+            net._ws.clear()
+            torch.cuda.empty_cache()
+            for name, fn in (("configs2_large_b16", section_large), ("configs3_train_b16", section_train)):
+                t1 = time.perf_counter()
+                try:
+                    sections[name] = fn(mta, dev, cores, not args.no_cpu_baseline)
+                except Exception as e:                      # a section must not cost the headline line
+                    sections[name] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"section {name}: {time.perf_counter() - t1:.1f} s")
+                torch.cuda.empty_cache()
 
         out = {"metric": "30 s audio chunks/sec (mel+CNNRNN forward)", "value": round(world * B * K / elapsed, 2),
                "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "bf16 MFMA (f32 accumulate) for conv2 / layer-0 projection / fc, f16 MFMA for the recurrence and the "
-                        "projections fused into it (f32 state, gates and accumulation), f32 FFT and conv1",
+               "dtype": "f16 MFMA operands with f32 accumulate (conv2, input projections, recurrence, fc), f32 LSTM state / gates, "
+                        "f32 FFT and conv1",
                "data": "synthetic",
                "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
                                       "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
-                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)", "streams_per_gpu": NS, "fused_input_projection": bool(net.fuse_input_projection)},
-               "roofline": roofline, "cpu_baseline": cpu, "stages": stages}
+                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)", "streams_per_gpu": NS, "fused_input_projection": bool(net.fuse_input_projection), "lstm_mode": int(os.environ.get("MT_LSTM_MODE", "0") or 0)},
+               "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
+               "roofline_overlapped": roofline_overlapped, "stages_overlapped": stages_overlapped, **sections}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

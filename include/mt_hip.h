@@ -293,6 +293,15 @@ int    mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, const float*
                                   int B, int T, float* logits3, void* workspace, size_t workspace_bytes,
                                   mt_stream_t stream, mt_stream_t side_stream, void* ev_fork, void* ev_join);
 
+/* Everything on `stream`, recording the caller's hipEvent_t handles at the stage boundaries (events[0] before the first kernel,
+ * then one after each of the mt_cnnrnn_large_num_stages(layers) stages: conv1, res_block1, res_block2, freq_aware_conv, local
+ * LSTM (projection, recurrence, re-layout), main LSTM layers (projection, recurrence, re-layout) x layers, attention +
+ * LayerNorm, heads) so that a benchmark can time each kernel group on the launch stream.                               */
+int    mt_cnnrnn_large_num_stages(int layers);
+int    mt_cnnrnn_large_forward_ev(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power,
+                                  int B, int T, float* logits3, void* workspace, size_t workspace_bytes,
+                                  void* const* events, int n_events, mt_stream_t stream);
+
 /* ------------------------------------------------------------------ loss, prediction, F1
  * Masked BCE-with-logits (transcription_model.py:110-162,:196-217):
  *   loss[0] (=, or += when accumulate) weight * sum_{valid} bce(logit, target) / max(n_valid_frames*P, 1)

@@ -116,6 +116,8 @@ _SIGS = {
     "mt_cnnrnn_large_status_offset": (sz, [C.POINTER(CnnRnnLargeWeights), i32, i32, i32]),
     "mt_cnnrnn_large_forward": (i32, [C.POINTER(CnnRnnLargeWeights), vp, vp, i32, i32, vp, vp, sz, vp]),
     "mt_cnnrnn_large_forward_ex": (i32, [C.POINTER(CnnRnnLargeWeights), vp, vp, i32, i32, vp, vp, sz, vp, vp, vp, vp]),
+    "mt_cnnrnn_large_num_stages": (i32, [i32]),
+    "mt_cnnrnn_large_forward_ev": (i32, [C.POINTER(CnnRnnLargeWeights), vp, vp, i32, i32, vp, vp, sz, C.POINTER(vp), i32, vp]),
     "mt_adam_workspace_bytes": (sz, []),
     "mt_adam_clip_step": (i32, [vp, vp, vp, vp, ll] + [C.c_float] * 6 + [i32, vp, vp, sz, vp]),
     "mt_bce_workspace_bytes": (sz, []),

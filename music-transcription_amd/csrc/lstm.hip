@@ -113,7 +113,10 @@ __device__ unsigned long long mt_lstm_diag[1024][8];
 // the projection GEMM (0.38 ms) and the re-layout disappear: a loss with one batch in flight (-6 %), a gain when
 // several are (+8 % at three: the GEMMs are the serialised resource there).  Opt-in (mt_cnnrnn_weights.w_ihx).
 template <int NKSW, bool XCD, bool TRAIN = false, bool XP = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
-__global__ __launch_bounds__(256) void lstm_rec_kernel(LstmArgs a) {
+// Register budget: without the fused projection the kernel is held to 128 registers per lane (VGPRs + AGPRs; launch bound of
+// 4 waves per SIMD) so that one of its waves shares a SIMD with the two 192-register waves of the big-tile GEMM: a GEMM of
+// another batch in flight then still gets every CU (tests/test_kernel_budget_cpu.py).
+__global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][64][20];       // [k-slice wave][lane][16 regs + pad]: 80-B lane stride, conflict-free b128
     __shared__ __attribute__((aligned(16))) f16_t hs[32][8];           // [batch][unit]
 #ifdef MT_LSTM_LDS_PAD

@@ -103,9 +103,14 @@ extern "C" size_t mt_cnnrnn_large_status_offset(const mt_cnnrnn_large_weights* w
 // side_stream / ev_fork / ev_join (all three, or all NULL): the local LSTM branch (projection, recurrence, re-layout) is
 // issued on side_stream between the two caller-owned events, beside the main LSTM stack -- both are latency-bound and
 // together use 192 of the 256 CUs.  Without them everything runs on `stream` in order.
-extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
-                                          float* logits3, void* workspace, size_t workspace_bytes, mt_stream_t stream,
-                                          mt_stream_t side_stream, void* ev_fork, void* ev_join) {
+// events (optional, benchmarks): the caller's hipEvent_t handles, recorded on `stream` at the stage boundaries
+// (mt_cnnrnn_large_num_stages): start | conv1 | res_block1 | res_block2 | freq_aware_conv | local LSTM: projection, recurrence,
+// re-layout | main LSTM layer l: projection, recurrence, re-layout | attention + LayerNorm | heads.
+#define REC() do { if (events && ei < n_events) MT_CHECK_HIP(hipEventRecord((hipEvent_t)events[ei], st)); ++ei; } while (0)
+static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
+                              float* logits3, void* workspace, size_t workspace_bytes, mt_stream_t stream,
+                              mt_stream_t side_stream, void* ev_fork, void* ev_join, void* const* events, int n_events) {
+    int ei = 0;
     RUN(check_large(w));
     MT_REQUIRE(mel && logits3 && workspace && B > 0 && T > 0, MT_EINVAL, "mt_cnnrnn_large_forward: bad arguments");
     const LargePlan p = lplan(w, B, T);
@@ -114,12 +119,17 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
     hipStream_t st = (hipStream_t)stream;
     const int Hv = w->hidden, Hl = w->hidden_local, dt = w->operand_dtype;
     // ---- CNN
+    REC();
     RUN(mt_conv1_bn_relu_pool_dt(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, dt, stream));
+    REC();
     RUN(mt_conv_cl_dt(ws + p.act1, nullptr, w->rb1c1_w, w->rb1c1_b, ws + p.r1a, B, p.F1, T, 32, 0, 64, 3, 1, 0, 0, 0, dt, stream));
     RUN(mt_conv_cl_dt(ws + p.r1a, ws + p.act1, w->rb1c2_w, w->rb1c2_b, ws + p.r1, B, p.F1, T, 64, 32, 64, 3, 1, 1, 0, 0, dt, stream));
+    REC();
     RUN(mt_conv_cl_dt(ws + p.r1, nullptr, w->rb2c1_w, w->rb2c1_b, ws + p.r2a, B, p.F2, T, 64, 0, 128, 3, 1, 0, 0, 0, dt, stream));
     RUN(mt_conv_cl_dt(ws + p.r2a, ws + p.r1, w->rb2c2_w, w->rb2c2_b, ws + p.r2, B, p.F2, T, 128, 64, 128, 3, 1, 0, 0, 0, dt, stream));
+    REC();
     RUN(mt_conv_cl_dt(ws + p.r2, nullptr, w->fa_w, w->fa_b, ws + p.x0, B, p.F2, T, 128, 0, 256, 7, 1, 1, 1, p.K0, dt, stream));
+    REC();
     // ---- concatenated feature rows: bf16 GEMM operand (zero pad columns) + fp32 copy for the residual
     if (p.Cp != p.comb) MT_CHECK_HIP(hipMemsetAsync(ws + p.rb, 0, (size_t)p.Mpad * p.Cp * 2, st));
     if (p.K1 != 2 * Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, st));
@@ -131,8 +141,11 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
         MT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, (hipEvent_t)ev_fork, 0));
     }
     RUN(mt_gemm_lstm_gx_dt(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, dt, ls));
+    REC();
     RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode, ls));
+    REC();
     RUN(mt_lstm_relayout_dt((const float*)(ws + p.hx2), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, dt, ls));
+    REC();
     if (fork) MT_CHECK_HIP(hipEventRecord((hipEvent_t)ev_join, (hipStream_t)side_stream));
     // main LSTM; layers > 0 with a packed W_ihx take their input projection inside the recurrence (no GEMM, no re-layout)
     char* hcur = ws + p.hx;
@@ -141,6 +154,7 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
         const bool last = l + 1 == w->layers;
         const bool fused = l > 0 && w->main_w_ihx[l] && w->lstm_mode == 0 && p.Hp <= 512;
         if (fused) {
+            REC();                                               // (no projection GEMM: empty stage)
             RUN(mt_lstm_bidir_fwd_xproj((const float*)hcur, w->main_w_ihx[l], w->main_b[l], w->main_w_hh[l], (float*)hnext,
                                         ws + p.sync + p.sync_stride * (l + 1), p.sync_stride, B, T, p.Hp, stream));
             char* tmp = hcur; hcur = hnext; hnext = tmp;
@@ -148,12 +162,15 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
             const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
             const int K = l == 0 ? p.K0 : p.K1;
             RUN(mt_gemm_lstm_gx_dt(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, dt, stream));
+            REC();
             RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * (l + 1),
                                   p.sync_stride, B, T, p.Hp, w->lstm_mode, stream));
         }
+        REC();
         const bool next_fused = !last && w->main_w_ihx[l + 1] && w->lstm_mode == 0 && p.Hp <= 512;
         if (last) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, dt, stream));
         else if (!next_fused) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, dt, stream));
+        REC();
     }
     if (fork) MT_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0));      // both column ranges of rb / r32 are complete
     const void* feat = ws + p.rb;            // [Mpad][Cp] bf16
@@ -178,12 +195,31 @@ extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, cons
                                   p.M, p.comb, 1e-6f, dt, stream));
         feat = ws + p.ln;
     }
+    REC();
     if (w->use_heads) {
         if (p.Hs != Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.sh, 0, (size_t)p.Mpad * p.Hs * 2, st));
         RUN(mt_gemm_batched_h16out_dt(feat, p.Cp, 0, 0, w->shared_w, p.Cp, 0, 0, w->shared_b, ws + p.sh, p.Hs, 0, 0, p.M, Hv, p.Cp, 1, 1, 1, dt, stream));
-        return mt_gemm_logits_dt(ws + p.sh, p.Hs, w->heads_w, p.Hs, w->heads_b, logits3, B, T, 3 * MT_N_PITCH, p.Hs, dt, stream);
+        RUN(mt_gemm_logits_dt(ws + p.sh, p.Hs, w->heads_w, p.Hs, w->heads_b, logits3, B, T, 3 * MT_N_PITCH, p.Hs, dt, stream));
+    } else {
+        RUN(mt_gemm_logits_dt(feat, p.Cp, w->fc_w, p.Cp, w->fc_b, logits3, B, T, MT_N_PITCH, p.Cp, dt, stream));
     }
-    return mt_gemm_logits_dt(feat, p.Cp, w->fc_w, p.Cp, w->fc_b, logits3, B, T, MT_N_PITCH, p.Cp, dt, stream);
+    REC();
+    return MT_OK;
+}
+#undef REC
+
+extern "C" int mt_cnnrnn_large_forward_ex(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
+                                          float* logits3, void* workspace, size_t workspace_bytes, mt_stream_t stream,
+                                          mt_stream_t side_stream, void* ev_fork, void* ev_join) {
+    return large_forward_impl(w, mel, chunk_max_power, B, T, logits3, workspace, workspace_bytes, stream, side_stream, ev_fork, ev_join, nullptr, 0);
+}
+
+// Everything on `stream`, recording the caller's events at the stage boundaries (benchmarks: per-kernel times on the launch stream).
+extern "C" int mt_cnnrnn_large_num_stages(int layers) { return 9 + 3 * layers; }
+extern "C" int mt_cnnrnn_large_forward_ev(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
+                                          float* logits3, void* workspace, size_t workspace_bytes, void* const* events, int n_events,
+                                          mt_stream_t stream) {
+    return large_forward_impl(w, mel, chunk_max_power, B, T, logits3, workspace, workspace_bytes, stream, nullptr, nullptr, nullptr, events, n_events);
 }
 
 extern "C" int mt_cnnrnn_large_forward(const mt_cnnrnn_large_weights* w, const float* mel, const float* chunk_max_power, int B, int T,

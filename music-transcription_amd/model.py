@@ -454,7 +454,7 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
             w.fc_b = put("fc_b", self.fc.bias.detach().float().cpu())
         return {"tensors": t, "struct": w}
 
-    def forward(self, x, return_all_heads=False, chunk_max_power: Optional[torch.Tensor] = None, check_status: bool = False):
+    def forward(self, x, return_all_heads=False, chunk_max_power: Optional[torch.Tensor] = None, check_status: bool = False, events=None):
         self._require_cuda(x)
         if x.requires_grad:
             raise NotImplementedError("gradients w.r.t. the input mel are not implemented (the reference never asks for them)")
@@ -505,9 +505,15 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
         for l in range(1, self.num_layers):
             w.main_w_ihx[l] = ptr(pk["tensors"][f"m_wix{l}"]) if (fuse and self.hidden_size <= 512) else None
         with torch.cuda.device(x.device):
-            check(lib.mt_cnnrnn_large_forward_ex(w, ptr(x), ptr(chunk_max_power), B, T, ptr(out), ptr(ws), ws.numel(),
-                                                 _lib.stream_ptr(), side.cuda_stream, evs[0].cuda_event, evs[1].cuda_event),
-                  "mt_cnnrnn_large_forward")
+            if events is not None:     # benchmark path: everything on the caller's stream, events at the stage boundaries
+                import ctypes
+                ev_arr = (ctypes.c_void_p * len(events))(*[e.cuda_event for e in events])
+                check(lib.mt_cnnrnn_large_forward_ev(w, ptr(x), ptr(chunk_max_power), B, T, ptr(out), ptr(ws), ws.numel(), ev_arr, len(events),
+                                                     _lib.stream_ptr()), "mt_cnnrnn_large_forward_ev")
+            else:
+                check(lib.mt_cnnrnn_large_forward_ex(w, ptr(x), ptr(chunk_max_power), B, T, ptr(out), ptr(ws), ws.numel(),
+                                                     _lib.stream_ptr(), side.cuda_stream, evs[0].cuda_event, evs[1].cuda_event),
+                      "mt_cnnrnn_large_forward")
         if check_status:
             self.raise_on_handoff_timeout(B, T)
         if heads_out and return_all_heads:

@@ -75,6 +75,34 @@ def pack_train(model, dev, part: str = "all") -> Dict[str, object]:
     return t
 
 
+class _Prof:
+    """Optional per-launch timing for benchmarks: when `model._profile` is a list, `with prof("name"):` brackets the launches
+    inside with two timing events on the current stream and appends (name, start, end).  Free otherwise."""
+
+    def __init__(self, model):
+        self.rec = getattr(model, "_profile", None)
+
+    def __call__(self, name):
+        return _ProfSpan(self.rec, name)
+
+
+class _ProfSpan:
+    def __init__(self, rec, name):
+        self.rec, self.name = rec, name
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.rec.append((self.name, self.a, b))
+        return False
+
+
 _SIDE = {}
 
 
@@ -102,6 +130,7 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
     """Returns (logits (B,88,T) f32, saved state for backward_train).  Updates the BatchNorm running statistics."""
     dev = x.device
     B, _, F, T = x.shape
+    prof = _Prof(model)
     # The LSTM / fc operands are packed on the side stream while the main stream runs the convolutions, and the first
     # BPTT workspace gets its poison fill there as well (the side stream first waits for everything already queued on
     # the main stream: the previous step's optimizer update, and the last users of whatever the allocator hands back).
@@ -169,9 +198,11 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
             gx = torch.empty(lib.mt_lstm_gx_bytes(B, T, Hp) // 4, **f32)
             cx = torch.empty(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
             hx = torch.empty(lib.mt_lstm_hx_bytes(B, T, Hp) // 4, **f32)
-            check(lib.mt_gemm_lstm_gx(ptr(Xs[l]), K, ptr(pk["w_ih"][l]), K, ptr(pk["b_g"][l]), ptr(gx), B, T, Hp, K, _st()), "mt_gemm_lstm_gx")
-            check(lib.mt_lstm_bidir_fwd_train(ptr(gx), ptr(pk["w_hh"][l]), ptr(hx), ptr(cx), ptr(sync), sync.numel(), B, T, Hp, _st()),
-                  "mt_lstm_bidir_fwd_train")
+            with prof(f"gemm_lstm_gx_l{l}"):
+                check(lib.mt_gemm_lstm_gx(ptr(Xs[l]), K, ptr(pk["w_ih"][l]), K, ptr(pk["b_g"][l]), ptr(gx), B, T, Hp, K, _st()), "mt_gemm_lstm_gx")
+            with prof(f"lstm_rec_train_l{l}"):
+                check(lib.mt_lstm_bidir_fwd_train(ptr(gx), ptr(pk["w_hh"][l]), ptr(hx), ptr(cx), ptr(sync), sync.numel(), B, T, Hp, _st()),
+                      "mt_lstm_bidir_fwd_train")
             if K1 == 2 * H:
                 Xn = torch.empty(Mpad, K1, **bf)
                 Xn[M:].zero_()
@@ -194,6 +225,7 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
 def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict[str, torch.Tensor]:
     """Gradients of every parameter (reference names without the `model.` prefix, reference shapes)."""
     pk = sv["pk"]
+    prof = _Prof(model)
     d = pk["dims"]
     H, Hp, L, F, F1, Fo2, K0, K1 = d["H"], d["Hp"], d["L"], d["F"], d["F1"], d["Fo2"], d["K0"], d["K1"]
     B, T, x = sv["B"], sv["T"], sv["x"]
@@ -277,8 +309,9 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
             dgx = dgxs[it % len(dgxs)]
             if ev_unp[it % len(dgxs)] is not None:
                 main.wait_event(ev_unp[it % len(dgxs)])  # the side stream's unpack of this buffer's previous user is done
-            check(lib.mt_lstm_bidir_bwd_ex(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(part), part.numel(),
-                                           ptr(sync), sync.numel(), B, T, Hp, 1, _st()), "mt_lstm_bidir_bwd")
+            with prof(f"lstm_bptt_l{l}"):
+                check(lib.mt_lstm_bidir_bwd_ex(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(pk["w_hh"][l]), ptr(dgx), ptr(part), part.numel(),
+                                               ptr(sync), sync.numel(), B, T, Hp, 1, _st()), "mt_lstm_bidir_bwd")
             ev = torch.cuda.Event()
             ev.record(main)                              # dgates of this layer are complete
             if l == L - 1:                           # the host queues the side-stream work only once the top recurrence is running

@@ -559,7 +559,8 @@ def test_oversubscribed_persistent_launches_fail_fast(mta):
                     outs.append(net(mel))
         torch.cuda.synchronize()
         net.raise_on_handoff_timeout()
-        assert len(outs) == 2 and all(torch.equal(o, ref) for o in outs)
+        # (a stream that has already drained no longer counts, so the refusal comes with the third or the fourth forward)
+        assert 2 <= len(outs) <= 3 and all(torch.equal(o, ref) for o in outs)
         # ... and so does the library when that bound is bypassed (another process, a caller of the C ABI)
         net._ws.clear()
         net._check_inflight_bound = lambda *a, **k: None
@@ -572,7 +573,7 @@ def test_oversubscribed_persistent_launches_fail_fast(mta):
         dt = __import__("time").perf_counter() - t0
         torch.cuda.synchronize()
         assert dt < 1.0                                                          # refused at launch time, not after a spin bound
-        assert len(outs) >= 2 and all(torch.equal(o, ref) for o in outs[:2])     # the admitted forwards are unharmed
+        assert 2 <= len(outs) <= 3 and all(torch.equal(o, ref) for o in outs)    # the admitted forwards are unharmed
         assert _lib.lib.mt_persistent_cus_in_flight(None) == 0
         del net._check_inflight_bound
         net._ws.clear()

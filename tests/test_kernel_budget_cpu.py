@@ -17,7 +17,12 @@ def _vgprs(src, tmp_path):
     out = tmp_path / (src + ".s")
     subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                     os.path.join(CSRC, src), "-o", str(out)], check=True, capture_output=True, timeout=600)
-    return {m.group(1): int(m.group(2)) for m in re.finditer(r"\.set (\S+)\.num_vgpr, (\d+)", out.read_text())}
+    txt = out.read_text()
+    v = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.set (\S+)\.num_vgpr, (\d+)", txt)}
+    a = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.set (\S+)\.num_agpr, (\d+)", txt)}
+    # gfx950 has ONE register file per SIMD: a wave's allocation is its VGPRs (rounded up to the accumulator offset's granule of 4)
+    # plus its AGPRs
+    return {k: (n + 3) // 4 * 4 + a.get(k, 0) for k, n in v.items()}
 
 
 def _alloc(n):
