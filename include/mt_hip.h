@@ -372,9 +372,16 @@ int    mt_bn_relu_pool_apply(const void* z, const float* mean, const float* rstd
 int    mt_bn_pool_bwd(const float* dX, int ldd, const void* z, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, double* sums128, void* dz, void* dz_lo,
                       float* dgamma, float* dbeta, int B, int F, int T, mt_stream_t stream);
-/* a [B][F][T][32] bf16 -> colT[(tap*32+ci)*ld + (b*F+f)*T + t] = a[b][f+kh-1][t+kw-1][ci] (zero outside),
- * tap = kh*3+kw: the W operand of the conv2 weight-gradient GEMM (contraction over positions).             */
-int    mt_im2col_t_3x3_c32(const void* a, void* colT, long long ld, int B, int F, int T, mt_stream_t stream);
+/* Pool routing that ties exactly where the f32 conv results tie (nn.MaxPool2d on f32 activations routes a tie to the first
+ * row; two rows that merely round to the same bf16 value are NOT a tie): mt_conv_cl_tie is the raw convolution (bf16 in,
+ * channels-last bf16 out, no activation / pool) that also writes, per frequency-row pair (2fo, 2fo+1), position and channel,
+ * the order bits of its f32 accumulators -- tie[(((b*(F/2) + fo)*T + t)*(Cout/32) + co/32)*2 + {0, 1}] bit co%32 =
+ * {z(2fo) > z(2fo+1), z(2fo) < z(2fo+1)} -- and mt_bn_pool_bwd_tie routes with them (tie == NULL: as mt_bn_pool_bwd).   */
+int    mt_conv_cl_tie(const void* A, const void* W, const float* bias, void* out, unsigned* tie, int B, int F, int T,
+                      int C1, int Cout, int KH, mt_stream_t stream);
+int    mt_bn_pool_bwd_tie(const float* dX, int ldd, const void* z, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, double* sums128, void* dz, void* dz_lo,
+                          float* dgamma, float* dbeta, const unsigned* tie, int B, int F, int T, mt_stream_t stream);
 /* Weight and bias gradient of the second conv (Conv2d(32, 64, 3, padding=1), cnn_rnn_model.py:35) from the
  * channels-last activation a1 [B][F][T][32] and the two bf16 pieces of dz [B][F][T][64] (mt_bn_pool_bwd), with the
  * POSITION as the MFMA contraction index: no im2col, no transposed copy.  n_wg persistent workgroups

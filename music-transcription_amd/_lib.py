@@ -132,7 +132,8 @@ _SIGS = {
     "mt_bn_stats_cl": (i32, [vp, ll, i32, vp, vp]),
     "mt_bn_relu_pool_apply": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mt_bn_pool_bwd": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "mt_im2col_t_3x3_c32": (i32, [vp, vp, ll, i32, i32, i32, vp]),
+    "mt_conv_cl_tie": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "mt_bn_pool_bwd_tie": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mt_conv2_wgrad_workgroups": (i32, []),
     "mt_conv2_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mt_transpose_bf16": (i32, [vp, ll, ll, i32, vp, ll, i32, vp]),

@@ -31,6 +31,9 @@ struct ConvGArgs {
     int B, F, T, C1, C2, Cout, KH, relu, ldx;
     int pitchA, pitchS;   // elements between consecutive positions of A / S (>= C1 / C2: a channel slice of a wider tensor)
     int accum;            // != 0: out += result (the output is read back and the sum stored)
+    unsigned* tie;        // optional (no pool, channels-last output): order bits of the f32 accumulators of each frequency-row pair
+                          //   (2fo, 2fo+1) BEFORE the 16-bit rounding: tie[(((b*(F/2) + fo)*T + t)*(Cout/32) + co/32)*2 + {0,1}] bit co%32 =
+                          //   {z(2fo) > z(2fo+1), z(2fo) < z(2fo+1)} -- MaxPool2d((2,1)) routing that does not depend on the rounding
 };
 
 constexpr int CG_TF = 16, CG_TT = 16;
@@ -192,6 +195,16 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int t = t0 + p + 8 * qq + 4 * h;
+                    if (!POOL && a.tie) {                  // (uniform branch: every lane takes part in the ballots)
+                        const float z0 = acc[i][j][4 * qq + p], z1 = acc[i][j][4 * (qq + 2) + p];
+                        const unsigned long long gt = __ballot(z0 > z1), lt = __ballot(z0 < z1);
+                        const int f = f0 + 4 * wm + 2 * i;
+                        if (r == 0 && t < a.T && f + 1 < a.F) {
+                            const size_t w_ = ((((size_t)b * (a.F >> 1) + (f >> 1)) * a.T + t) * (a.Cout >> 5) + ((n0 + wn * (BN_ / 2) + j * 32) >> 5)) * 2;
+                            a.tie[w_] = (unsigned)(h ? gt >> 32 : gt);
+                            a.tie[w_ + 1] = (unsigned)(h ? lt >> 32 : lt);
+                        }
+                    }
                     if (t >= a.T) continue;
                     const float v0 = acc[i][j][4 * qq + p] + bv, v1 = acc[i][j][4 * (qq + 2) + p] + bv;
                     if (POOL) {
@@ -283,9 +296,21 @@ extern "C" int mt_conv_cl_ex(const void* A, int pitchA, const void* S, int pitch
                (C2 == 0 || C2 == 32 || C2 == 64 || C2 == 128) && (C2 == 0 || S) && (Cout % 64 == 0), MT_EUNSUPPORTED,
                "mt_conv_cl: unsupported shape C1=%d C2=%d Cout=%d KH=%d", C1, C2, Cout, KH);
     ConvGArgs a{(const bf16_t*)A, (const bf16_t*)S, (const bf16_t*)W, bias, (bf16_t*)out, B, F, T, C1, C2, Cout, KH, relu, ldx,
-                pitchA, pitchS, accum};
+                pitchA, pitchS, accum, nullptr};
     return dt == MT_DT_F16 ? conv_cl_dispatch<MT_DT_F16>(a, pool, out_mode, (hipStream_t)stream)
                            : conv_cl_dispatch<MT_DT_BF16>(a, pool, out_mode, (hipStream_t)stream);
+}
+
+// Raw convolution (no activation, no pool, channels-last bf16 output) that also records, for every frequency-row pair a following
+// MaxPool2d((2,1)) merges, the ORDER of the two f32 results before they are rounded to bf16 (ConvGArgs::tie): the training step's
+// pool routing then ties exactly where the f32 values tie, as nn.MaxPool2d on f32 activations does (cnn_rnn_model.py:35-38).
+extern "C" int mt_conv_cl_tie(const void* A, const void* W, const float* bias, void* out, unsigned* tie, int B, int F, int T, int C1, int Cout,
+                              int KH, mt_stream_t stream) {
+    MT_REQUIRE(A && W && bias && out && tie, MT_EINVAL, "mt_conv_cl_tie: null pointer");
+    MT_REQUIRE(B > 0 && F >= 2 && T > 0 && (KH == 3 || KH == 7) && (C1 == 32 || C1 == 64 || C1 == 128) && (Cout % 64 == 0), MT_EUNSUPPORTED,
+               "mt_conv_cl_tie: unsupported shape C1=%d Cout=%d KH=%d", C1, Cout, KH);
+    ConvGArgs a{(const bf16_t*)A, nullptr, (const bf16_t*)W, bias, (bf16_t*)out, B, F, T, C1, 0, Cout, KH, 0, 0, C1, 0, 0, tie};
+    return conv_cl_dispatch<MT_DT_BF16>(a, 0, 0, (hipStream_t)stream);
 }
 extern "C" int mt_conv_cl_dt(const void* A, const void* S, const void* W, const float* bias, void* out,
                              int B, int F, int T, int C1, int C2, int Cout, int KH, int relu, int pool, int out_mode, int ldx,

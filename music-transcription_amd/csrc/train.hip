@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           double* __restrict__ sums, bf16_t* __restrict__ dz, bf16_t* __restrict__ dz_lo,
-                                                          int B, int F, int T) {
+                                                          const unsigned* __restrict__ tie, int B, int F, int T) {
     __shared__ float red[2][256];
     const int c = threadIdx.x & 63, Fo = F >> 1, Fh = (F + 1) >> 1;     // Fh pairs; the last one is a single row when F is odd
     const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
@@ -165,7 +165,14 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const float* __restric
         if (pair) {
             const float y0 = fmaf(ga, x0, be), y1 = fmaf(ga, x1, be);
             const float g = dX[((size_t)t * B + b) * ldd + (size_t)fo * 64 + c];
-            if (y1 > y0) { if (y1 > 0.0f) d1 = g; }
+            bool second = y1 > y0;
+            if (tie) {       // order of the conv's f32 results before their bf16 rounding (mt_conv_cl_tie): ties only where f32 ties
+                const unsigned* w_ = tie + ((((size_t)b * Fo + fo) * T + t) * 2 + (c >> 5)) * 2;
+                const bool gt = (w_[0] >> (c & 31)) & 1u, lt = (w_[1] >> (c & 31)) & 1u;
+                const float sc = ga * rs;
+                second = sc > 0.0f ? lt : (sc < 0.0f ? gt : false);
+            }
+            if (second) { if (y1 > 0.0f) d1 = g; }
             else if (y0 > 0.0f) d0 = g;
         }
         if (APPLY) {
@@ -200,26 +207,6 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __
     if (c < C) { dbeta[c] = (float)sums[c]; dgamma[c] = (float)sums[C + c]; }
 }
 
-// ------------------------------------------------------------------------------------------------ im2col^T for the conv2 wgrad
-// a [B][F][T][32] bf16 -> colT[(tap*32 + ci)*ld + n], n = (b*F + f)*T + t, tap = kh*3 + kw: a[b][f+kh-1][t+kw-1][ci] (0 outside)
-__global__ __launch_bounds__(256) void im2colT_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ colT, long long ld,
-                                                      int B, int F, int T) {
-    __shared__ bf16_t tile[3][66][34];                // [row][t + halo][ci (+2 pad)]
-    const int t0 = blockIdx.x * 64, f = blockIdx.y, b = blockIdx.z;
-    for (int i = threadIdx.x; i < 3 * 66 * 32; i += 256) {
-        const int ci = i & 31, tl = (i >> 5) % 66, r = i / (66 * 32);
-        const int ff = f - 1 + r, tt = t0 - 1 + tl;
-        tile[r][tl][ci] = (ff >= 0 && ff < F && tt >= 0 && tt < T) ? a[(((size_t)b * F + ff) * T + tt) * 32 + ci] : (bf16_t)0;
-    }
-    __syncthreads();
-    const int tl = threadIdx.x & 63;
-    if (t0 + tl >= T) return;
-    const long long n = ((long long)b * F + f) * T + t0 + tl;
-    for (int k = threadIdx.x >> 6; k < 288; k += 4) {
-        const int tap = k >> 5, ci = k & 31, kh = tap / 3, kw = tap - 3 * kh;
-        colT[(size_t)k * ld + n] = tile[kh][tl + kw][ci];
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ conv2 weight gradient, direct
 // dW[co][tap][ci] = sum_pos (dz_hi + dz_lo)[pos][co] * a1[pos + tap][ci],  db[co] = sum_pos dz_hi[pos][co]
@@ -637,27 +624,25 @@ extern "C" int mt_bn_relu_pool_apply(const void* z, const float* mean, const flo
     return MT_OK;
 }
 
-extern "C" int mt_bn_pool_bwd(const float* dX, int ldd, const void* z, const float* mean, const float* rstd, const float* gamma,
-                              const float* beta, double* sums128, void* dz, void* dz_lo, float* dgamma, float* dbeta, int B, int F,
-                              int T, mt_stream_t stream) {
+extern "C" int mt_bn_pool_bwd_tie(const float* dX, int ldd, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, double* sums128, void* dz, void* dz_lo, float* dgamma, float* dbeta, const unsigned* tie,
+                                  int B, int F, int T, mt_stream_t stream) {
     MT_REQUIRE(dX && z && mean && rstd && gamma && beta && sums128 && dz && B > 0 && F >= 2 && T > 0, MT_EINVAL, "mt_bn_pool_bwd: bad arguments");
     MT_CHECK_HIP(hipMemsetAsync(sums128, 0, 128 * sizeof(double), ST(stream)));
     long long g = ((long long)B * ((F + 1) / 2) * T + 63) / 64;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(bn_pool_bwd_kernel<false>, dim3((unsigned)g), dim3(256), 0, ST(stream), dX, ldd, (const bf16_t*)z, mean, rstd, gamma, beta,
-                       sums128, (bf16_t*)nullptr, (bf16_t*)nullptr, B, F, T);
+                       sums128, (bf16_t*)nullptr, (bf16_t*)nullptr, tie, B, F, T);
     hipLaunchKernelGGL(bn_pool_bwd_kernel<true>, dim3((unsigned)g), dim3(256), 0, ST(stream), dX, ldd, (const bf16_t*)z, mean, rstd, gamma, beta,
-                       sums128, (bf16_t*)dz, (bf16_t*)dz_lo, B, F, T);
+                       sums128, (bf16_t*)dz, (bf16_t*)dz_lo, tie, B, F, T);
     if (dgamma && dbeta) hipLaunchKernelGGL(bn_param_grads_kernel, dim3(1), dim3(64), 0, ST(stream), sums128, dgamma, dbeta, 64);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
-
-extern "C" int mt_im2col_t_3x3_c32(const void* a, void* colT, long long ld, int B, int F, int T, mt_stream_t stream) {
-    MT_REQUIRE(a && colT && B > 0 && F > 0 && T > 0 && ld >= (long long)B * F * T, MT_EINVAL, "mt_im2col_t_3x3_c32: bad arguments");
-    hipLaunchKernelGGL(im2colT_kernel, dim3(cdiv(T, 64), F, B), dim3(256), 0, ST(stream), (const bf16_t*)a, (bf16_t*)colT, ld, B, F, T);
-    MT_CHECK_LAUNCH();
-    return MT_OK;
+extern "C" int mt_bn_pool_bwd(const float* dX, int ldd, const void* z, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, double* sums128, void* dz, void* dz_lo, float* dgamma, float* dbeta, int B, int F,
+                              int T, mt_stream_t stream) {
+    return mt_bn_pool_bwd_tie(dX, ldd, z, mean, rstd, gamma, beta, sums128, dz, dz_lo, dgamma, dbeta, nullptr, B, F, T, stream);
 }
 
 extern "C" int mt_conv2_wgrad_workgroups(void) { return 256; }

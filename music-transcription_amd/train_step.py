@@ -162,7 +162,10 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
         check(lib.mt_conv1_bn_relu_pool(ptr(x), None, ptr(wf1), ptr(bf1), ptr(a1), B, F, T, _st()), "mt_conv1_bn_relu_pool")
         # ---- conv2: raw bf16 output -> statistics -> BN + ReLU + pool straight into the GEMM operand
         z2 = torch.empty(B, F1, T, 64, **bf)
-        check(lib.mt_conv_cl_bf16(ptr(a1), None, ptr(pk["w2"]), ptr(pk["b2"]), ptr(z2), B, F1, T, 32, 0, 64, 3, 0, 0, 0, 0, _st()), "mt_conv_cl_bf16")
+        # (+ the order of each pooled row pair's f32 results before their bf16 rounding: the backward pass routes with it)
+        tie2 = torch.empty(B * (F1 // 2) * T * 2 * 2, device=dev, dtype=torch.int32)
+        check(lib.mt_conv_cl_tie(ptr(a1), ptr(pk["w2"]), ptr(pk["b2"]), ptr(z2), ptr(tie2), B, F1, T, 32, 64, 3, _st()), "mt_conv_cl_tie")
+        sv["tie2"] = tie2
         sums2 = sums[128:]
         mean2, rstd2 = torch.empty(64, **f32), torch.empty(64, **f32)
         check(lib.mt_bn_stats_cl(ptr(z2), B * F1 * T, 64, ptr(sums2), _st()), "mt_bn_stats_cl")
@@ -372,8 +375,9 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
         sums = torch.zeros(512, device=dev, dtype=torch.float64)
         dz2, dz2lo = torch.empty(Npos, 64, **bf), torch.empty(Npos, 64, **bf)
         g["cnn.5.weight"], g["cnn.5.bias"] = torch.empty(64, **f32), torch.empty(64, **f32)
-        check(lib.mt_bn_pool_bwd(ptr(dX0), K0, ptr(sv["z2"]), ptr(sv["mean2"]), ptr(sv["rstd2"]), ptr(pk["g2"]), ptr(pk["be2"]), ptr(sums),
-                                 ptr(dz2), ptr(dz2lo), ptr(g["cnn.5.weight"]), ptr(g["cnn.5.bias"]), B, F1, T, _st()), "mt_bn_pool_bwd")
+        check(lib.mt_bn_pool_bwd_tie(ptr(dX0), K0, ptr(sv["z2"]), ptr(sv["mean2"]), ptr(sv["rstd2"]), ptr(pk["g2"]), ptr(pk["be2"]), ptr(sums),
+                                     ptr(dz2), ptr(dz2lo), ptr(g["cnn.5.weight"]), ptr(g["cnn.5.bias"]), ptr(sv["tie2"]), B, F1, T, _st()),
+              "mt_bn_pool_bwd_tie")
         da1 = torch.empty(B, F1, T, 64, **bf)
         check(lib.mt_conv_cl_bf16(ptr(dz2), None, ptr(pk["w2d"]), ptr(pk["zero64"]), ptr(da1), B, F1, T, 64, 0, 64, 3, 0, 0, 0, 0, _st()),
               "mt_conv_cl_bf16 (dgrad)")

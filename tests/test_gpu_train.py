@@ -110,6 +110,7 @@ def test_train_step_matches_reference_golden(mta, golden_dir):
     ref = {k[len("grad::"):]: g[k] for k in g.files if k.startswith("grad::")}
     assert set(ref) == set(grads)
     worst, cos = _compare_grads(grads, ref)
+    print("\n[small vs fp32 golden] cos=%.6f " % cos + ", ".join(f"{k.replace('model.', '')}={v:.3g}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:6]))
     bad = {k: v for k, v in worst.items() if v > GRAD_REL_FP32_BY_KEY.get(k, GRAD_REL_FP32)}
     assert not bad and cos > GRAD_COS_FP32, (bad, cos)
     _, ref_emu = _oracle_grads(R.make_state_dict("cnn_rnn", nm, H, L, sw), mel, roll, lengths, True)
