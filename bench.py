@@ -493,9 +493,15 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import music_transcription_amd as mta
+    from music_transcription_amd import model as mt_model
 
     B, K, W = args.batch, args.steps, args.warmup
     T = mta.num_frames(N_SAMPLES, HOP)
+    # Recurrence hand-off: with >= 3 batches in flight the XCD-local 16-unit variant (csrc/lstm.hip, mode 2) holds 64 CUs per
+    # launch instead of 128 and wins (+4..7 % measured); alone it loses to the agent-scope kernel (1.98 vs 1.53 ms per layer).
+    # It takes effect only if a census launch shows the dispatcher dealing workgroups evenly over the XCDs (model.lstm_mode).
+    if "MT_LSTM_MODE" not in os.environ and max(1, args.streams) >= 3:
+        os.environ["MT_LSTM_MODE"] = "2"
     # seeded synthetic input: noise + decaying piano-range sinusoids; seed = 1234 + rank.
     # Four distinct chunks tiled to the batch keep host-side synthesis short; the kernels see B chunks.
     base = synth_audio(min(B, 4), N_SAMPLES, seed=1234 + rank)
@@ -552,6 +558,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     net.raise_on_handoff_timeout(B, T)
+    hl_mode = int(mt_model._LSTM_MODE.get(dev_index, 0))        # what the timed region actually ran (census may have refused mode 2)
     log(f"timed region: {elapsed:.3f} s for {K} steps")
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -564,6 +571,8 @@ def main():
         K1 = 10
         fused_hl = bool(net.fuse_input_projection)
         net.fuse_input_projection = False
+        mode_hl = mt_model._LSTM_MODE.get(dev_index, 0)
+        mt_model._LSTM_MODE[dev_index] = 0               # one batch in flight: the agent-scope kernel
         ev1m = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K1)]
         ev1n = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K1)]
         with torch.cuda.stream(streams[0]), torch.no_grad():
@@ -582,6 +591,7 @@ def main():
         for s_ in range(nst):
             one_ms.append(float(np.mean([ev1n[i][s_].elapsed_time(ev1n[i][s_ + 1]) for i in range(K1)])))
         net.fuse_input_projection = fused_hl
+        mt_model._LSTM_MODE[dev_index] = mode_hl
 
     if rank == 0:
         # ---- per-kernel times from the events recorded inside the timed region (several batches in flight: kernels of
@@ -621,6 +631,7 @@ def main():
             cpu = cpu_baseline_small(model, wave, logits, cores)
         sections = {}
         if world == 1 and not args.no_sections:
+            mt_model._LSTM_MODE[dev_index] = 0           # the sections below run the agent-scope recurrence
             del mel, cmax
             net._ws.clear()
             torch.cuda.empty_cache()
@@ -629,7 +640,8 @@ def main():
                 try:
                     sections[name] = fn(mta, dev, cores, not args.no_cpu_baseline)
                 except Exception as e:                      # a section must not cost the headline line
-                    sections[name] = {"error": f"{type(e).__name__}: {e}"}
+                    import traceback
+                    sections[name] = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
                 log(f"section {name}: {time.perf_counter() - t1:.1f} s")
                 torch.cuda.empty_cache()
 
@@ -641,7 +653,7 @@ def main():
                "data": "synthetic",
                "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
                                       "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
-                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)", "streams_per_gpu": NS, "fused_input_projection": bool(net.fuse_input_projection), "lstm_mode": int(os.environ.get("MT_LSTM_MODE", "0") or 0)},
+                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)", "streams_per_gpu": NS, "fused_input_projection": bool(net.fuse_input_projection), "lstm_mode": hl_mode},
                "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
                "roofline_overlapped": roofline_overlapped, "stages_overlapped": stages_overlapped, **sections}
         print(json.dumps(out))

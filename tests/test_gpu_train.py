@@ -17,11 +17,11 @@ from oracle import model_ref as R
 
 GRAD_REL = 3e-2        # max |g - g_ref| / max |g_ref| per tensor, against the oracle with the HIP path's bf16 rounding points
 GRAD_REL_FP32 = 1e-1   # the same against the fp32 reference (bf16 activations flip a few ReLU / max-pool decisions)
-# conv2's weight gradient is a sum with heavy cancellation (BatchNorm makes sum dz = 0 and sum dz*z = 0): the ~0.07 % of
-# pool pairs whose two rows round to the SAME bf16 value (gradient goes to the first row, as nn.MaxPool2d does on a
-# tie) move it by up to ~15 % of its largest entry at these tiny shapes; against the oracle with the same rounding
-# points it agrees to GRAD_REL like every other tensor.
-GRAD_REL_FP32_BY_KEY = {"model.cnn.4.weight": 2e-1}
+# conv2's weight gradient is a sum with heavy cancellation (BatchNorm makes sum dz = 0 and sum dz*z = 0).  The ~0.07 % of pool
+# pairs whose two rows round to the SAME bf16 value used to move it by ~14 % of its largest entry (the gradient went to the
+# first row, as on a true tie); the pool now routes by the order of the conv's f32 results before their rounding
+# (mt_conv_cl_tie), and conv2's weight gradient meets the common 10 % bound against the fp32 reference (observed 6 %).
+GRAD_REL_FP32_BY_KEY = {}
 GRAD_COS = 0.9995      # cosine of the flat gradient against the oracle with the same rounding points
 GRAD_COS_FP32 = 0.998  # ... against the fp32 reference (tiny shapes: a few hundred positions per channel)
 LOGIT_TOL = 3e-2

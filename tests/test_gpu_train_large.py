@@ -408,7 +408,7 @@ def test_large_variants_and_dict_loss_vs_oracle_autograd(mta, kw, all_heads):
         assert close(out, lo)
     worst, cos = _compare_grads(grads, ref)
     _report(f"variant {kw} all_heads={all_heads}", worst, cos)
-    bad = {k: v for k, v in worst.items() if v > max(GRAD_REL_BY_KEY.get(k[len("model."):], GRAD_REL), 0.1)}
+    bad = {k: v for k, v in worst.items() if v > max(GRAD_REL_BY_KEY.get(k[len("model."):], GRAD_REL), 0.15)}
     assert not bad and cos > GRAD_COS, (bad, cos)
 
 
