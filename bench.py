@@ -168,7 +168,8 @@ def bench_train(args):
     import music_transcription_amd as mta
     B, K, W, T = args.batch, args.steps, args.warmup, 937
     g = torch.Generator().manual_seed(1234 + rank)
-    model = seeded_model(mta, "cnn_rnn", str(dev), dropout=0.3)      # the same initial weights on every rank
+    mtype = args.model
+    model = seeded_model(mta, mtype, str(dev), dropout=0.3 if mtype == "cnn_rnn" else 0.2)      # the same initial weights on every rank
     opt = mta.make_optimizer(model, lr=1e-4)
     batches = []
     for _ in range(2):
@@ -207,13 +208,14 @@ def bench_train(args):
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
     if rank == 0:
-        flops = 3.0 * 72.76e9 * B * world * T / 938.0
-        print(json.dumps({"metric": "30 s audio chunks/sec (CNNRNNModel training step)", "value": round(B * world * K / el, 2),
+        flops = 3.0 * (72.76e9 if mtype == "cnn_rnn" else 326.47e9) * B * world * T / 938.0
+        print(json.dumps({"metric": f"30 s audio chunks/sec ({'CNNRNNModel' if mtype == 'cnn_rnn' else 'CNNRNNModelLarge'} training step)", "value": round(B * world * K / el, 2),
                           "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / K, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "data": "synthetic",
-                          "config": {"workload": "CNNRNNModel training, batch=16/GPU cached-format chunks, data-parallel "
-                                                 "(BASELINE.json configs[3])", "batch_per_gpu": B, "frames": T,
+                          "config": {"workload": ("CNNRNNModel training, batch=16/GPU cached-format chunks, data-parallel (BASELINE.json configs[3])"
+                                                  if mtype == "cnn_rnn" else "CNNRNNModelLarge training (what example.sh:22 trains), cached-format chunks, data-parallel"),
+                                     "batch_per_gpu": B, "frames": T,
                                      "parallelism": f"dp{world} (one RCCL all-reduce of the flat gradient per step)"},
                           "model_tflops_per_s": round(flops * K / el / 1e12, 1), "final_loss": round(float(loss.item()), 5)}))
     if world > 1:
@@ -437,7 +439,7 @@ def section_train(mta, dev, cores, do_cpu):
     if do_cpu:
         from oracle import model_ref
         torch.set_num_threads(cores)
-        sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        sd = {k: (v.detach().float() if v.dtype.is_floating_point else v.detach()).cpu().clone() for k, v in model.state_dict().items()}
         nb = 2
         batch = [(mel[:nb, :, :, :].clone(), roll[:nb].clone(), lengths[:nb].clone())]
         t1 = time.perf_counter()

@@ -37,8 +37,8 @@
 //     lines (loads that bypass the caches serialise at their line's home channel): 3.3 us;
 //   * flag stored right behind the payload without draining it (poison makes the order irrelevant): 3.05 us;
 //   * f16 exchange instead of two bf16 pieces: 2.45 us;  * no flag at all (one round trip instead of two): 1.88 us.
-// The XCD-local variants (plain stores into one XCD's L2) keep the replicated flags.  Every spin is bounded: on
-// timeout the workgroup raises the abort word, which every other workgroup's spin also watches, and all leave.
+// The XCD-local variant (lstm_rec16_kernel below: plain stores into one XCD's L2) polls the payload the same way.  Every spin is
+// bounded: on timeout the workgroup raises the abort word, which every other workgroup's spin also watches, and all leave.
 #include "mt_common.h"
 #include <atomic>
 #include <stdlib.h>
@@ -51,11 +51,11 @@ struct LstmArgs {
     const float* gx;      // [NG][T][2][NKB][4][8][32]
     const float* w_hh;    // [2][4H][H]
     float* hx;            // [NG][T][2][NKB/2][64][8] f16 (typed float* in the C ABI)
-    unsigned* flags;      // [NG][2][NKB]   zeroed before every launch
+    unsigned* flags;      // unused (the hand-off has no flags any more); kept so that the sync workspace layout stays put
     unsigned* status;     // [0] = abort/timeout word, zeroed before every launch
     int B, T, H;
     int g0;               // first batch group of this launch
-    // XCD-local mode (see lstm_rec_kernel): lanes = (direction, batch group) pairs of this launch,
+    // XCD-local mode (lstm_rec16_kernel): lanes = (direction, batch group) pairs of this launch,
     unsigned* tickets;    // [8] per-XCD arrival counters, zeroed before every launch
     int nlanes, xcd_off;  // lane l runs on the XCD with hardware id (l + xcd_off) & 7
     // train mode (lstm_rec_kernel<.., TRAIN = true>): what the backward pass needs (lstm_bwd.hip)
@@ -95,16 +95,6 @@ __device__ unsigned long long mt_lstm_diag[1024][8];
 #define DIAG_STAMP(i) do { } while (0)
 #endif
 
-// XCD = true: XCD-local hand-off.  The S = H/8 workgroups of one (direction, batch group) "lane" are made up of
-// workgroups that physically sit on ONE XCD: every workgroup reads its hardware XCC id, lanes are bound to XCC
-// ids, and a workgroup takes its slice index from an arrival ticket of its own XCD -- nothing is inferred from
-// blockIdx.  Inside an XCD the L2 is the coherence point of all its CUs, so the payload and the flag are PLAIN
-// stores (they stay in that L2) and the sc1 loads (L1 bypass) hit them at L2 latency instead of crossing the
-// fabric: ~2x shorter steps.  Which XCD a workgroup lands on is the dispatcher's choice: if an XCD receives fewer
-// than S workgroups of the launch its lane cannot complete; that is a liveness matter only (bounded spins raise
-// the status word), never a stale read.  The host sizes the grid 8 x S (the dispatcher deals workgroups
-// round-robin over the 8 XCDs) and falls back to the agent-scope variant (XCD = false) if a census launch at
-// start-up shows a different distribution.
 // XP = true: the layer's INPUT PROJECTION is fused in (layers fed by another LSTM layer): no gx buffer (0.5 GB written by a
 // GEMM and read back here), no projection GEMM, no re-layout pass between the layers.  x_t is read as MFMA B operands
 // straight from the previous layer's hx images (plain loads, issued at the top of the step), and the product W_ihx x_t
@@ -112,7 +102,7 @@ __device__ unsigned long long mt_lstm_diag[1024][8];
 // (2.35 vs 1.65 us at H = 512: 64 KB more per workgroup per step in front of the gather in the in-order memory queue),
 // the projection GEMM (0.38 ms) and the re-layout disappear: a loss with one batch in flight (-6 %), a gain when
 // several are (+8 % at three: the GEMMs are the serialised resource there).  Opt-in (mt_cnnrnn_weights.w_ihx).
-template <int NKSW, bool XCD, bool TRAIN = false, bool XP = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
+template <int NKSW, bool TRAIN = false, bool XP = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
 // Register budget: without the fused projection the kernel is held to 128 registers per lane (VGPRs + AGPRs; launch bound of
 // 4 waves per SIMD) so that one of its waves shares a SIMD with the two 192-register waves of the big-tile GEMM: a GEMM of
 // another batch in flight then still gets every CU (tests/test_kernel_budget_cpu.py).
@@ -124,24 +114,9 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
     if (threadIdx.x == 0) lds_pad[blockIdx.x & 1023] = 1;
 #endif
     __shared__ int abort_s;
-    __shared__ int ident_s[2];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int H = a.H, T = a.T, nkb = H >> 3, nks = H >> 4;
-    int kb, d, g;
-    if (XCD) {
-        if (tid == 0) {
-            const int xcc = __builtin_amdgcn_s_getreg(20 /*HW_REG_XCC_ID*/ | (0 << 6) | ((4 - 1) << 11));
-            const int ln = (xcc - a.xcd_off) & 7;
-            ident_s[0] = ln;
-            ident_s[1] = ln < a.nlanes ? (int)__hip_atomic_fetch_add(a.tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
-        }
-        __syncthreads();
-        const int ln = ident_s[0], ticket = ident_s[1];
-        if (ln >= a.nlanes || ticket >= nkb) return;       // this XCD hosts no lane, or the lane is already fully staffed
-        kb = ticket; d = ln & 1; g = a.g0 + (ln >> 1);
-    } else {
-        kb = blockIdx.x; d = blockIdx.y; g = blockIdx.z + a.g0;
-    }
+    const int kb = blockIdx.x, d = blockIdx.y, g = blockIdx.z + a.g0;
     const int b = lane & 31, hh = lane >> 5;
     const int Bg = min(32, a.B - g * 32);            // valid batch rows of this group
 
@@ -186,11 +161,6 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         XP ? (void*)((const char*)a.hx_prev + (size_t)g * gd_blocks * 512) : (void*)hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
-    // step flags are kept in FLAG_REPL replicas on separate cache lines: a producer writes all replicas with one
-    // wave instruction, a consumer polls the replica kb % FLAG_REPL, so each flag line has nkb / FLAG_REPL pollers
-    // instead of nkb (loads that bypass the caches serialise at the line's home memory channel)
-    unsigned* flags_all = a.flags + ((size_t)g * 2 + d) * FLAG_REPL * nkb;
-    unsigned* flags = flags_all + (kb % FLAG_REPL) * nkb;
     if (tid == 0) abort_s = 0;
     __syncthreads();
 #ifdef MT_LSTM_DIAG
@@ -227,39 +197,8 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
             acc = accx;
         }
         if (s > 0) {
-            if (XCD) {
-            // ---- XCD-local variant: wait until every workgroup of this direction has published step s-1.  One round trip per
-            //      poll: every lane loads one flag and, in the same burst, a second flag (H > 512) or the abort word.
-            if (wv == 0) {
-                const unsigned* p1 = flags + (lane < nkb ? lane : nkb - 1);
-                const bool p2_is_flag = (lane + 64 < nkb);
-                const unsigned* p2 = p2_is_flag ? flags + lane + 64 : flags + (lane < nkb ? lane : nkb - 1);
-                long long t0 = 0;
-                bool ok = false;
-                for (unsigned it = 0;; ++it) {
-                    const unsigned v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned v2 = p2_is_flag ? __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : v1;
-                    const bool ready = (v1 >= (unsigned)s) && (v2 >= (unsigned)s);
-                    if (__all(ready)) { ok = true; break; }
-                    // the abort word is one line polled by every workgroup of the launch: look at it only now and then
-                    if ((it & 15u) == 15u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    if ((it & 255u) == 255u) {
-                        const long long now = __builtin_amdgcn_s_memrealtime();
-                        if (t0 == 0) t0 = now;
-                        else if (now - t0 > LSTM_SPIN_LIMIT_TICKS) {
-                            if (lane == 0) __hip_atomic_store(a.status, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
-                }
-                if (!ok && lane == 0) abort_s = 1;
-            }
-            DIAG_STAMP(0);
-            __syncthreads();
-            DIAG_STAMP(1);
-            if (abort_s) return;                       // uniform: every wave of the workgroup leaves
-            } else {
-                // Agent-scope variant: NO flag wait.  The payload loads themselves are the poll -- a word that still holds the
+            {
+                // NO flag wait.  The payload loads themselves are the poll -- a word that still holds the
                 // poison pattern has not been published (or has not landed) -- so a step costs one memory round trip after
                 // the producers' stores become visible instead of two (flag, then payload): 2.45 -> 1.88 us/step.  The short
                 // sleep keeps the first, certain-to-fail attempt (issued right behind this workgroup's own publish) off the
@@ -297,7 +236,7 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
                 sleep64(a.sleep_retry);
-                if (!XCD && (it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
                     break;
                 }
@@ -357,17 +296,10 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
             const u32x4 piece = *(const u32x4*)(&hs[b][0]);
             const int hoff = ((t * 2 + d) * nkb) * 512 + (kb >> 1) * 1024 + ((kb & 1) * 32 + b) * 16;
             if (lane < 32) {
-                if (XCD) __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
-                else __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1: write-through*/);
+                __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1: write-through*/);
             }
-#ifdef MT_LSTM_DRAIN
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // classic form: the pieces have landed before the flag says so
-#endif
-            // Default: NO drain.  The flag is then only a hint that the stores were issued; a consumer that gets ahead
-            // of the payload sees the poison pattern in the words that have not landed and redoes its loads (every
-            // word is written exactly once by one store, so it is either poison or final).  Measured 3.05 vs 3.30
-            // us/step: the store round trip leaves the critical path.
-            if (XCD && lane < FLAG_REPL) *(volatile unsigned*)(flags_all + lane * nkb + kb) = (unsigned)(s + 1);   // plain store: stays in this XCD's L2
+            // NO drain and no flag: a consumer that gets ahead of the payload sees the poison pattern in the words that have not
+            // landed and redoes its loads (every word is written exactly once by one store, so it is either poison or final).
         }
         DIAG_STAMP(6);
     }
@@ -598,9 +530,9 @@ static int launch_rec16(const LstmArgs& a, hipStream_t st) {
 
 template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, hipStream_t st) {
-    if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
-    else if (a.cx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_train");
-    else MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd");
+    if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
+    else if (a.cx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, true, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_train");
+    else MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd");
     return MT_OK;
 }
 
@@ -703,8 +635,7 @@ extern "C" int mt_lstm_bidir_fwd_train(float* gx_inout, const float* w_hh, float
     return lstm_fwd_impl(gx_inout, w_hh, hx, sync_ws, sync_bytes, B, T, H, 0, stream, cx);
 }
 
-// mode 0: agent-scope hand-off (placement-independent); mode 1: XCD-local hand-off, 8 units per workgroup
-// (see lstm_rec_kernel); mode 2: XCD-local, 16 units per workgroup (lstm_rec16_kernel).
+// mode 0: agent-scope hand-off (placement-independent); mode 2: XCD-local, 16 units per workgroup (lstm_rec16_kernel).
 extern "C" int mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                                     int B, int T, int H, int mode, mt_stream_t stream) {
     MT_REQUIRE(mode == 0 || mode == 2, MT_EINVAL, "mt_lstm_bidir_fwd_ex: mode must be 0 (agent-scope hand-off) or 2 (XCD-local, 16 units per workgroup)");

@@ -433,3 +433,49 @@ def test_large_train_with_dropout_runs_and_is_seeded(mta):
     with torch.no_grad():
         ev = m(mel)
     assert not torch.equal(ev, outs[0][0])
+
+
+def test_large_full_size_training_step(mta):
+    """CNNRNNModelLarge 320/512/3 (what example.sh:22 trains), cached-format batch of 4 ragged chunks (T <= 937), every
+    dropout of the reference active: logits and every gradient finite, BatchNorm buffers updated, the train-mode forward
+    under torch.no_grad() equals the one with the autograd edge for the same seed, and two fused clip + Adam steps at a
+    large learning rate lower the loss on the same batch."""
+    nm, H, L, B, T = 320, 512, 3, 4, 937
+    m = mta.TranscriptionModel(model_type="cnn_rnn_large", n_mels=nm, hidden_size=H, num_layers=L, dropout=0.2, device="cuda")
+    m.load_state_dict(R.make_state_dict("cnn_rnn_large", nm, H, L, 9), strict=True)
+    g = torch.Generator().manual_seed(3)
+    lengths = torch.tensor([T, 700, 469, 900], dtype=torch.int64)
+    mel = torch.rand(B, 1, nm, T, generator=g) * 60.0 - 70.0
+    roll = (torch.rand(B, 88, T, generator=g) < 0.04).float()
+    for b in range(B):
+        mel[b, :, :, lengths[b]:] = 0.0
+        roll[b, :, lengths[b]:] = 0.0
+    meld, rolld = mel.cuda(), roll.cuda()
+    m.train()
+    rm0 = m.model.freq_aware_conv[1].running_mean.clone()
+    torch.manual_seed(5)
+    logits = m(meld)
+    loss = m.compute_loss(logits, rolld, lengths)
+    loss.backward()
+    m.model.raise_on_train_handoff_timeout()
+    assert logits.shape == (B, 88, T) and torch.isfinite(logits).all()
+    for k, p in m.named_parameters():
+        if "onset_head" in k or "offset_head" in k:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k        # frame-only loss (train_transcriber.py:119)
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k
+    assert not torch.equal(rm0, m.model.freq_aware_conv[1].running_mean)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        again = m(meld)
+    assert torch.equal(again, logits.detach())
+    opt = mta.make_optimizer(m, lr=1e-3)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        ls = m.compute_loss(m(meld), rolld, lengths)
+        ls.backward()
+        st = opt.step(sync_grads=False).tolist()
+        assert st[1] == 1.0 and np.isfinite(st[0])
+        losses.append(float(ls.item()))
+    assert losses[-1] < losses[0], losses
