@@ -617,7 +617,9 @@ def main():
         for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
-                hit = [v for k, v in prof.items() if ("lstm_rec" in k if dom_key == "lstm_rec" else dom_key.split("_l")[0] in k.replace("::", "_"))]
+                # (the 1-stream pass runs the agent-scope recurrence, mt::lstm_rec_kernel; the XCD-local mt::lstm_rec16_kernel of a
+                #  multi-stream headline is a different kernel)
+                hit = [v for k, v in prof.items() if ("lstm_rec_kernel" in k if dom_key == "lstm_rec" else dom_key.split("_l")[0] in k.replace("::", "_"))]
                 if hit and B == 32:
                     traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
                     tsrc = f"profiles/{fname} (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
