@@ -53,8 +53,8 @@ def stage_table(B, T, n_mels, H, L, fused=False):
         # algorithmic FLOPs of W_hh h (+ W_ih x when fused); f16 MFMA; the kernel is bound by the per-step
         # inter-workgroup hand-off latency, not by the matrix pipe
         st.append((f"lstm_rec_l{l}", "mfma_f16", 2.0 * M * 8 * H * H + (proj if in_rec else 0.0), "FLOP"))
-        # (the re-layout pass is skipped when the next layer reads hx directly)
-        st.append((f"lstm_relayout_l{l}", "hbm", 0 if (fused and l + 1 < L) else M * 2 * H * (4 + 2), "B"))
+        # (no re-layout pass: with f16 operands the consuming GEMMs read their A tiles straight from the hx images; the stage is empty)
+        st.append((f"lstm_relayout_l{l}", "hbm", 0, "B"))
     st.append(("gemm_logits", "mfma", 2.0 * M * 88 * 2 * H, "FLOP"))
     return st
 
@@ -272,7 +272,7 @@ def large_stage_table(B, T, n_mels, H, L):
     for l in range(L):
         K = K0 if l == 0 else 2 * H
         st += [(f"gemm_lstm_gx_l{l}", "mfma", 2.0 * M * 8 * H * K, "FLOP"), (f"lstm_rec_l{l}", "mfma_f16", 2.0 * M * 8 * H * H, "FLOP"),
-               (f"lstm_relayout_l{l}", "hbm", M * 2 * H * (2 + 2 + (4 if l == L - 1 else 0)), "B")]
+               (f"lstm_relayout_l{l}", "hbm", M * 2 * H * (2 + 2 + 4) if l == L - 1 else 0, "B")]      # (layers below the top: the next GEMM reads hx directly)
     st += [("attention_layernorm", "mfma", 2.0 * M * comb * 3 * comb + 2 * 2.0 * B * heads * T * T * dh + 2.0 * M * comb * comb, "FLOP"),
            ("heads", "mfma", 2.0 * M * comb * H + 2.0 * M * H * 264, "FLOP")]
     return st
@@ -307,6 +307,43 @@ def cpu_baseline_small(model, wave, logits, cores):
     t1 = time.perf_counter(); run(w8); dt8 = time.perf_counter() - t1
     cpu["batch8"] = {"value": round(8 / dt8, 3), "unit": "chunks/s", "sample": "1 batch of 8 chunks, same path"}
     return cpu
+
+
+def section_coscheduled(mta, dev, net, fe, wave32):
+    """The same workload with the three batches of 32 chunks CO-SCHEDULED: one forward over B = 96, in which the recurrence
+    interleaves the three batch groups inside one persistent launch (csrc/lstm.hip, NG) -- while one group's h travels to its
+    consumers the workgroup computes the others' steps -- and the GEMMs see M = 96 T rows.  Informational: the headline keeps
+    BASELINE's batch = 32 per forward."""
+    import torch
+    B, K = 96, 12
+    T = mta.num_frames(N_SAMPLES, HOP)
+    wave = torch.cat([wave32] * 3)
+    out = {}
+    for NS in (1, 2):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+        mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
+        cmax = [torch.empty(B, device=dev) for _ in range(NS)]
+
+        def step(j):
+            s = j % NS
+            with torch.cuda.stream(streams[s]), torch.no_grad():
+                fe(wave, clamp=False, out=mel[s], chunk_max=cmax[s])
+                return net(mel[s], chunk_max_power=cmax[s])
+        for j in range(NS + 1):
+            step(j)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(K):
+            lg = step(j)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        net.raise_on_handoff_timeout(B, T)
+        out[f"streams_{NS}"] = {"value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_forward": round(1e3 * el / K, 3)}
+        del mel, cmax
+        net._ws.clear()
+    out["workload"] = "CNNRNNModel inference, 3 batches of 32 chunks co-scheduled in one forward (B = 96)"
+    out["finite"] = bool(torch.isfinite(lg).all())
+    return out
 
 
 def section_large(mta, dev, cores, do_cpu):
@@ -639,6 +676,11 @@ def main():
             del mel, cmax
             net._ws.clear()
             torch.cuda.empty_cache()
+            try:
+                sections["configs1_coscheduled_b96"] = section_coscheduled(mta, dev, net, fe, wave)
+            except Exception as e:
+                import traceback
+                sections["configs1_coscheduled_b96"] = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
             for name, fn in (("configs2_large_b16", section_large), ("configs3_train_b16", section_train)):
                 t1 = time.perf_counter()
                 try:

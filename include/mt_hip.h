@@ -119,6 +119,13 @@ int    mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const 
 /* Final projection with the reference's transpose fused: logits[b][n][t], rows m = t*B+b. */
 int    mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
                       int B, int T, int N, int K, mt_stream_t stream);
+/* The layer-to-layer input projection and the final fc with A read STRAIGHT from the previous LSTM layer's hx images (f16
+ * operands: the exchanged h is the operand type already), K = 2*Hprev, column k = dir*Hprev + unit, Hprev % 64 == 0: no
+ * re-layout pass between the layers.  hx_prev as mt_lstm_bidir_fwd* wrote it for the same B, T.                      */
+int    mt_gemm_lstm_gx_from_hx(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
+                               int B, int T, int H, int Hprev, mt_stream_t stream);
+int    mt_gemm_logits_from_hx(const float* hx_prev, const void* W, int ldw, const float* bias, float* logits,
+                              int B, int T, int N, int Hprev, mt_stream_t stream);
 /* The three GEMMs above with the operand type of A and W chosen by the caller (dt = MT_DT_BF16 | MT_DT_F16). */
 int    mt_gemm_f32acc_dt(const void* A, int lda, const void* W, int ldw, const float* bias,
                          float* C, int ldc, int M, int N, int K, int dt, mt_stream_t stream);

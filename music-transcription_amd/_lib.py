@@ -91,6 +91,8 @@ _SIGS = {
     "mt_lstm_relayout_dt": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "mt_attn_softmax_clamped_dt": (i32, [vp, i32, vp, i32, i32, ll, C.c_float, C.c_float, i32, vp]),
     "mt_layernorm_residual_dt": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, ll, i32, C.c_float, i32, vp]),
+    "mt_gemm_lstm_gx_from_hx": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_gemm_logits_from_hx": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_bf16_f32acc": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_lstm_gx": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_lstm_dh": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),

@@ -44,7 +44,20 @@ struct GemmEpi {
     int Hv;                // EPI_LSTM_DH: valid units per direction (H = padded), dropout of the layer whose output this is
     float drop_p;
     unsigned seed, layer;
+    // AHX: A is read straight from an LSTM layer's hx images (lstm.hip: [b/32][t][dir][k/16][(k/8 % 2)*32 + b%32][8] f16) instead of
+    // row-major rows -- row m = t*aB + b, column k = dir*aH + unit -- so no re-layout pass sits between the layers (f16 operands)
+    int aB, aT, aH;
 };
+
+// element offset of row m / of the 16-byte chunk (K-tile kt, chunk c8 of its 8) in the hx layout; aH % 64 == 0
+__device__ __forceinline__ size_t hx_row_off(const GemmEpi& ep, int m) {
+    const int t = m / ep.aB, b = m - t * ep.aB;
+    return ((size_t)((b >> 5) * ep.aT + t) * 2 * (ep.aH >> 4)) * 512 + (b & 31) * 8;
+}
+__device__ __forceinline__ int hx_chunk_off(const GemmEpi& ep, int kt, int c8) {
+    const int tpd = ep.aH >> 6, dir = kt / tpd, ks = (kt - dir * tpd) * 4 + (c8 >> 1);
+    return (dir * (ep.aH >> 4) + ks) * 512 + (c8 & 1) * 256;
+}
 
 // one element of the EPI_LSTM_DH output
 __device__ __forceinline__ void dh_store(const GemmEpi& ep, float* outp, int m, int n, float v) {
@@ -129,7 +142,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, int mb, int nb,
     }
 }
 
-template <int EPI, int DT>
+template <int EPI, int DT, bool AHX = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                    int M, int N, int K, GemmEpi ep) {
     constexpr bool SWAP = (EPI == EPI_LSTM_GX);
@@ -169,11 +182,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const bf16_t* __restrict__ A,
     typedef __attribute__((address_space(1))) const void gvoid_t;
     typedef __attribute__((address_space(3))) void lvoid_t;
     const int drow = lane >> 3, dslot = lane & 7;
+    size_t arow[4] = {0, 0, 0, 0};                   // AHX: this lane's four A rows in the hx layout (rows past M repeat the last one)
+    if (AHX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) arow[j] = hx_row_off(ep, min(m0 + wv * 32 + j * 8 + drow, M - 1));
+    }
 #define MT_DMA1(kt, buf, J)                                                                                   \
     {                                                                                                         \
         const int row_ = wv * 32 + (J) * 8 + drow;                                                            \
         const int chunk_ = dslot ^ ((row_ >> 1) & 7);                                                         \
-        const bf16_t* ga_ = A + (size_t)(m0 + row_) * lda + (size_t)(kt) * BK + chunk_ * 8;                   \
+        const bf16_t* ga_ = AHX ? A + arow[J] + hx_chunk_off(ep, (kt), chunk_)                                \
+                                : A + (size_t)(m0 + row_) * lda + (size_t)(kt) * BK + chunk_ * 8;             \
         const bf16_t* gw_ = W + (size_t)(n0 + row_) * ldw + (size_t)(kt) * BK + chunk_ * 8;                   \
         char* la_ = smem + (buf) * (BM + BN) * BK * 2 + (wv * 32 + (J) * 8) * 128;                            \
         __builtin_amdgcn_global_load_lds((gvoid_t*)ga_, (lvoid_t*)la_, 16, 0, 0);                             \
@@ -346,7 +365,7 @@ __device__ __forceinline__ void epilogue_tile16(const f32x4& acc, int mb, int nb
     }
 }
 
-template <int EPI, int DT>
+template <int EPI, int DT, bool AHX = false>
 __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
                                                        int M, int N, int K, GemmEpi ep) {
     constexpr bool SWAP = (EPI != EPI_LSTM_GX && EPI != EPI_LSTM_DH);      // see epilogue_tile16
@@ -378,11 +397,17 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict_
     typedef __attribute__((address_space(1))) const void gvoid_t;
     typedef __attribute__((address_space(3))) void lvoid_t;
     const int drow = lane >> 3, dslot = lane & 7;
+    size_t arow[4] = {0, 0, 0, 0};                   // AHX: this lane's four A rows in the hx layout (rows past M repeat the last one)
+    if (AHX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) arow[j] = hx_row_off(ep, min(m0 + wv * 32 + j * 8 + drow, M - 1));
+    }
 #define GX_DMA1(kt, buf, J)                                                                                   \
     {                                                                                                         \
         const int row_ = wv * 32 + (J) * 8 + drow;                                                            \
         const int chunk_ = dslot ^ ((row_ >> 1) & 7);                                                         \
-        const bf16_t* ga_ = A + (size_t)min(m0 + row_, a_last) * lda + (size_t)(kt) * BK + chunk_ * 8;        \
+        const bf16_t* ga_ = AHX ? A + arow[J] + hx_chunk_off(ep, (kt), chunk_)                                \
+                                : A + (size_t)min(m0 + row_, a_last) * lda + (size_t)(kt) * BK + chunk_ * 8;  \
         const bf16_t* gw_ = W + (size_t)min(n0 + row_, w_last) * ldw + (size_t)(kt) * BK + chunk_ * 8;        \
         char* la_ = smem2 + (buf) * (BM2 + BN2) * BK * 2 + (wv * 32 + (J) * 8) * 128;                         \
         __builtin_amdgcn_global_load_lds((gvoid_t*)ga_, (lvoid_t*)la_, 16, 0, 0);                             \
@@ -561,6 +586,29 @@ static int launch_dt(int epi, const bf16_t* a, int lda, const bf16_t* w, int ldw
     return MT_OK;
 }
 
+// A read from hx images (f16 operands): the layer-to-layer input projection and the final fc, no re-layout pass in front of them
+static int launch_hx(int epi, const void* hx, const void* W, int ldw, int M, int N, GemmEpi ep, hipStream_t st) {
+    MT_REQUIRE(hx && W && ep.out && ep.aB > 0 && ep.aT > 0 && ep.aH >= 64 && ep.aH % 64 == 0 && M == ep.aB * ep.aT, MT_EINVAL,
+               "gemm (A from hx): bad dims B=%d T=%d H=%d (H must be a multiple of 64)", ep.aB, ep.aT, ep.aH);
+    const int K = 2 * ep.aH;
+    MT_REQUIRE(ldw >= K && ldw % 8 == 0, MT_EINVAL, "gemm (A from hx): ldw=%d < K=%d", ldw, K);
+    const bf16_t* a = (const bf16_t*)hx; const bf16_t* w = (const bf16_t*)W;
+    if (epi == EPI_LSTM_GX && M >= 1024 && N >= 512 && N % 128 == 0 && (long long)cdiv(M, BM2) * cdiv(N, BN2) >= 128) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256x_kernel<EPI_LSTM_GX, MT_DT_F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm256x_kernel<EPI_LSTM_GX, MT_DT_F16, true>), dim3(cdiv(N, BN2) * cdiv(M, BM2)), dim3(512), G256_LDS, st, a, K, w, ldw, M, N, K, ep);
+    } else if (epi == EPI_LSTM_GX) {
+        hipLaunchKernelGGL((gemm_kernel<EPI_LSTM_GX, MT_DT_F16, true>), dim3(cdiv(N, BN) * cdiv(M, BM)), dim3(256), 0, st, a, K, w, ldw, M, N, K, ep);
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<EPI_LOGITS, MT_DT_F16, true>), dim3(cdiv(N, BN) * cdiv(M, BM)), dim3(256), 0, st, a, K, w, ldw, M, N, K, ep);
+    }
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
 static int launch(int epi, int dt, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st, int batch = 1) {
     MT_REQUIRE(A && W && ep.out, MT_EINVAL, "gemm: null pointer");
     MT_REQUIRE_DT(dt, "gemm");
@@ -600,6 +648,22 @@ extern "C" int mt_gemm_lstm_gx_dt(const void* X, int ldx, const void* W_ih, int 
 extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
                                int B, int T, int H, int K, mt_stream_t stream) {
     return mt_gemm_lstm_gx_dt(X, ldx, W_ih, ldw, bias, gx, B, T, H, K, MT_DT_BF16, stream);
+}
+
+// The same two projections with A read straight from the previous LSTM layer's hx images (f16 operands; hx as
+// mt_lstm_bidir_fwd* writes it, B / T / H of THAT layer, H % 64 == 0): K = 2H, column k = dir*H + unit.
+extern "C" int mt_gemm_lstm_gx_from_hx(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
+                                       int B, int T, int H, int Hprev, mt_stream_t stream) {
+    MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx_from_hx: bias is required (b_ih + b_hh)");
+    MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx_from_hx: bad dims B=%d T=%d H=%d", B, T, H);
+    GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0.0f, 0, 0, B, T, Hprev};
+    return launch_hx(EPI_LSTM_GX, hx_prev, W_ih, ldw, T * B, 8 * H, ep, (hipStream_t)stream);
+}
+extern "C" int mt_gemm_logits_from_hx(const float* hx_prev, const void* W, int ldw, const float* bias, float* logits,
+                                      int B, int T, int N, int Hprev, mt_stream_t stream) {
+    MT_REQUIRE(B > 0 && T > 0 && N % MT_N_PITCH == 0, MT_EINVAL, "mt_gemm_logits_from_hx: bad dims (N must be a multiple of 88)");
+    GemmEpi ep{logits, bias, 0, B, T, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0.0f, 0, 0, B, T, Hprev};
+    return launch_hx(EPI_LOGITS, hx_prev, W, ldw, T * B, N, ep, (hipStream_t)stream);
 }
 
 extern "C" int mt_gemm_lstm_dh(const void* dY, int ldy, const void* W, int ldw, float* dh, int B, int T, int H, int Hv, int K,

@@ -55,6 +55,7 @@ struct LstmArgs {
     unsigned* status;     // [0] = abort/timeout word, zeroed before every launch
     int B, T, H;
     int g0;               // first batch group of this launch
+    int ngl;              // batch groups of this launch
     // XCD-local mode (lstm_rec16_kernel): lanes = (direction, batch group) pairs of this launch,
     unsigned* tickets;    // [8] per-XCD arrival counters, zeroed before every launch
     int nlanes, xcd_off;  // lane l runs on the XCD with hardware id (l + xcd_off) & 7
@@ -102,7 +103,10 @@ __device__ unsigned long long mt_lstm_diag[1024][8];
 // (2.35 vs 1.65 us at H = 512: 64 KB more per workgroup per step in front of the gather in the in-order memory queue),
 // the projection GEMM (0.38 ms) and the re-layout disappear: a loss with one batch in flight (-6 %), a gain when
 // several are (+8 % at three: the GEMMs are the serialised resource there).  Opt-in (mt_cnnrnn_weights.w_ihx).
-template <int NKSW, bool TRAIN = false, bool XP = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
+// NG > 1: ONE workgroup carries the same 8 hidden units of NG batch groups (same W_hh slice, one cell state per group) and walks
+// them round-robin inside every step: while group g's published h travels to its consumers (the ~1 us hand-off that bounds a lone
+// step), the workgroup computes the other groups' steps, so B = 32 NG chunks cost little more time per step than 32.
+template <int NKSW, bool TRAIN = false, bool XP = false, int NG = 1>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
 // Register budget: without the fused projection the kernel is held to 128 registers per lane (VGPRs + AGPRs; launch bound of
 // 4 waves per SIMD) so that one of its waves shares a SIMD with the two 192-register waves of the big-tile GEMM: a GEMM of
 // another batch in flight then still gets every CU (tests/test_kernel_budget_cpu.py).
@@ -116,9 +120,9 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
     __shared__ int abort_s;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int H = a.H, T = a.T, nkb = H >> 3, nks = H >> 4;
-    const int kb = blockIdx.x, d = blockIdx.y, g = blockIdx.z + a.g0;
+    const int kb = blockIdx.x, d = blockIdx.y, gbase = blockIdx.z * NG + a.g0;
+    const int ngh = min(NG, a.g0 + a.ngl - gbase);   // batch groups this workgroup carries
     const int b = lane & 31, hh = lane >> 5;
-    const int Bg = min(32, a.B - g * 32);            // valid batch rows of this group
 
     // ---- W_hh slice as MFMA A-operands (f16): lane (row r, k half hh) holds
     //      W[row][16 ks + 8 hh + j], j = 0..7; row r = 8q + 4h + p <-> unit 2q + h, gate p
@@ -148,19 +152,15 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
 
     // this thread's cell: unit jl = 2*wv + hh of the workgroup, batch row b
     const int jl = 2 * wv + hh;
-    float c = 0.0f;
+    float cst[NG];                                   // cell state, one per batch group
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) cst[gi] = 0.0f;
     float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (XP) {
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) bias4[pp] = a.bias[(size_t)d * 4 * H + pp * H + kb * 8 + jl];
     }
     const size_t gd_blocks = (size_t)T * 2 * nkb;                       // (t, d, kb) blocks per batch group: 4 KB of gx, 512 B of hx each
-    const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
-    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
-    // buffer resource over this group's hx (all t, both d): offsets stay < 2^31
-    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        XP ? (void*)((const char*)a.hx_prev + (size_t)g * gd_blocks * 512) : (void*)hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
     if (tid == 0) abort_s = 0;
     __syncthreads();
 #ifdef MT_LSTM_DIAG
@@ -171,6 +171,18 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
     for (int s = 0; s < T; ++s) {
         const int t = d ? (T - 1 - s) : s;
         const int tprev = d ? (t + 1) : (t - 1);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi >= ngh) continue;                                        // (uniform over the workgroup)
+        const int g = gbase + gi;
+        const int Bg = min(32, a.B - g * 32);                           // valid batch rows of this group
+        float& c = cst[gi];
+        const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
+        char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
+        // buffer resource over this group's hx (all t, both d): offsets stay < 2^31
+        const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            XP ? (void*)((const char*)a.hx_prev + (size_t)g * gd_blocks * 512) : (void*)hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
         // gate pre-activations from the input projection (independent of h: issue early)
         float gxv[4];
         const float* gxp = gx_g + (((size_t)t * 2 + d) * nkb + kb) * 1024 + jl * 32 + b;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
                 // the producers' stores become visible instead of two (flag, then payload): 2.45 -> 1.88 us/step.  The short
                 // sleep keeps the first, certain-to-fail attempt (issued right behind this workgroup's own publish) off the
                 // fabric; every wave polls its own k-steps, the only workgroup barrier left is the LDS reduce.
-                sleep64(a.sleep_first);
+                if (NG == 1) sleep64(a.sleep_first);      // (with several groups the other groups' steps are the wait)
             }
             // ---- gather h_{t-1} (one 16-B sc1 load per lane per k-step) and run the f16 MFMA chain (f32 accumulate).
             //      A word still holding the poison pattern means its store has not landed: redo (rare, bounded).
@@ -302,6 +314,7 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
             // landed and redoes its loads (every word is written exactly once by one store, so it is either poison or final).
         }
         DIAG_STAMP(6);
+      }
     }
 #ifdef MT_LSTM_DIAG
     if (tid == 0) {
@@ -532,7 +545,11 @@ template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, hipStream_t st) {
     if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
     else if (a.cx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, true, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_train");
-    else MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd");
+    else if (ngroups == 1) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false>), dim3(a.H >> 3, 2, 1), "mt_lstm_bidir_fwd");
+    // inference with several batch groups: up to 4 groups interleaved inside one set of workgroups (see NG above)
+    else if (ngroups == 2) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, 2>), dim3(a.H >> 3, 2, 1), "mt_lstm_bidir_fwd");
+    else if (ngroups == 3) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, 3>), dim3(a.H >> 3, 2, 1), "mt_lstm_bidir_fwd");
+    else MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, 4>), dim3(a.H >> 3, 2, cdiv(ngroups, 4)), "mt_lstm_bidir_fwd");
     return MT_OK;
 }
 
@@ -580,18 +597,21 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     // sync_ws: [0] status word, [32..64) XCD tickets, [256..) flags (own cache lines, away from the polled status word)
     static const int env_first = getenv("MT_LSTM_POLL_FIRST") ? atoi(getenv("MT_LSTM_POLL_FIRST")) : -1;
     static const int env_retry = getenv("MT_LSTM_POLL_RETRY") ? atoi(getenv("MT_LSTM_POLL_RETRY")) : -1;
-    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, 0, (unsigned*)((char*)sync_ws + 32), 0, 0,
+    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, 0, 0, (unsigned*)((char*)sync_ws + 32), 0, 0,
                cx ? const_cast<float*>(gx) : nullptr, cx, w_ihx, bias, hx_prev,
                env_first >= 0 ? env_first : (xcd_local ? X16_POLL_SLEEP : PAYLOAD_POLL_SLEEP), env_retry >= 0 ? env_retry : 0};
     // every workgroup of a launch must be resident (they wait on each other).  Agent-scope variant: at most 256
-    // workgroups (one per CU) per launch; XCD-local variant: at most 8 lanes = 4 batch groups per launch, each lane's
-    // H/8 workgroups share one XCD (H/8 <= 128 -> at most 4 per CU).  Further groups run as further launches.
+    // workgroups (one per CU) per launch -- for plain inference each set of 2 H/8 workgroups carries up to 4 batch groups
+    // interleaved (lstm_rec_kernel, NG), the training / fused-projection variants one; XCD-local variant: at most 8 lanes =
+    // 4 batch groups per launch, each lane's H/16 workgroups share one XCD.  Further groups run as further launches.
     static std::atomic<unsigned> rotate{0};
-    const int per_launch = xcd_local ? 4 : ((256 / (2 * nkb)) > 0 ? (256 / (2 * nkb)) : 1);
+    const int zmax = (256 / (2 * nkb)) > 0 ? (256 / (2 * nkb)) : 1;
+    const int per_launch = xcd_local ? 4 : ((cx || w_ihx) ? zmax : 4 * zmax);
     const int nksw = cdiv(nkb / 2, 4);
     for (int g0 = 0; g0 < ng; g0 += per_launch) {
         a.g0 = g0;
         const int n = (ng - g0) < per_launch ? (ng - g0) : per_launch;
+        a.ngl = n;
         a.nlanes = 2 * n;
         a.xcd_off = xcd_local ? (int)(rotate.fetch_add(2 * n) & 7) : 0;
         if (xcd_local && g0 > 0) MT_CHECK_HIP(hipMemsetAsync((char*)sync_ws + 32, 0, 32, st));   // fresh tickets per launch

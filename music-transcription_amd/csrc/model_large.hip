@@ -16,6 +16,7 @@ int mt_gemm_batched_f32_dt(const void*, int, long long, long long, const void*, 
 int mt_gemm_batched_h16out_dt(const void*, int, long long, long long, const void*, int, long long, long long, const float*, void*, int,
                               long long, long long, int, int, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
+int mt_gemm_lstm_gx_from_hx(const float*, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
 int mt_lstm_relayout_dt(const float*, void*, int, float*, int, int, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 int mt_attn_softmax_clamped_dt(const float*, int, void*, int, int, long long, float, float, int, mt_stream_t);
@@ -150,6 +151,8 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
     // main LSTM; layers > 0 with a packed W_ihx take their input projection inside the recurrence (no GEMM, no re-layout)
     char* hcur = ws + p.hx;
     char* hnext = ws + p.hx3;
+    // f16 operands: main layers l > 0 read their GEMM A tiles straight from the previous layer's hx images (see model.hip)
+    const bool from_hx = dt == MT_DT_F16 && p.Hp == Hv && Hv % 64 == 0;
     for (int l = 0; l < w->layers; ++l) {
         const bool last = l + 1 == w->layers;
         const bool fused = l > 0 && w->main_w_ihx[l] && w->lstm_mode == 0 && p.Hp <= 512;
@@ -161,7 +164,12 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
         } else {
             const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
             const int K = l == 0 ? p.K0 : p.K1;
-            RUN(mt_gemm_lstm_gx_dt(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, dt, stream));
+            if (l > 0 && from_hx) {
+                RUN(mt_gemm_lstm_gx_from_hx((const float*)hcur, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, Hv, stream));
+                char* tmp = hcur; hcur = hnext; hnext = tmp;
+            } else {
+                RUN(mt_gemm_lstm_gx_dt(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, dt, stream));
+            }
             REC();
             RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * (l + 1),
                                   p.sync_stride, B, T, p.Hp, w->lstm_mode, stream));
@@ -169,7 +177,7 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
         REC();
         const bool next_fused = !last && w->main_w_ihx[l + 1] && w->lstm_mode == 0 && p.Hp <= 512;
         if (last) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, dt, stream));
-        else if (!next_fused) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, dt, stream));
+        else if (!next_fused && !from_hx) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, dt, stream));
         REC();
     }
     if (fork) MT_CHECK_HIP(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0));      // both column ranges of rb / r32 are complete

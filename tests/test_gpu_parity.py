@@ -97,7 +97,7 @@ def test_gemm_bf16(mta, M, N, K):
 # ------------------------------------------------------------------ LSTM layer (input projection + recurrence)
 @pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("B,T,H,K", [(2, 20, 16, 64), (5, 33, 32, 128), (32, 40, 512, 1024), (33, 12, 256, 192), (1, 50, 64, 64),
-                                     (150, 9, 64, 64), (32, 300, 512, 128)])    # the last: input projection on the 256 x 256 tile
+                                     (150, 9, 64, 64), (70, 11, 32, 64), (32, 300, 512, 128)])    # 5 / 3 batch groups: interleaved in one launch; the last: input projection on the 256 x 256 tile
 def test_lstm_layer_matches_oracle(mta, B, T, H, K, mode):
     from music_transcription_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator().manual_seed(B * 1000 + T * 10 + H)
@@ -370,6 +370,26 @@ def test_evaluate_and_tune_threshold(mta, tmp_path):
     best_t, best_f1 = ev.tune_threshold(model, ds, log=None)
     grid = ev.f1_at_thresholds(lr, np.arange(0.01, 0.995, 0.005)).mean(0)
     assert best_f1 >= grid.max() - 5e-3 and 0.01 <= best_t <= 0.99                       # coarse-to-fine finds the plateau
+
+
+def test_full_size_coscheduled_batches_equal_separate_forwards(mta):
+    """Three batches of 32 chunks in ONE forward (B = 96: the recurrence interleaves the three batch groups inside one
+    persistent launch, csrc/lstm.hip NG) give, chunk for chunk, the logits of three separate B = 32 forwards."""
+    from oracle import frontend_ref as FR
+    sd = R.make_state_dict("cnn_rnn", 320, 512, 3, seed=1)
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=320, hidden_size=512, num_layers=3, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    wave = torch.from_numpy(FR.synth_audio(6, 480000, seed=31)).cuda()
+    wave = torch.cat([wave * s for s in (1.0, 0.5, 0.25, 0.9, 0.7, 0.6, 0.8, 0.3, 0.45, 0.55, 0.65, 0.75, 0.85, 0.95, 0.35, 0.15)], 0)      # 96 distinct chunks
+    mel, _ = mta.MelFrontend(16000, 320, 512, "cuda")(wave, clamp=True)
+    with torch.no_grad():
+        big = model(mel).clone()
+        model.model.raise_on_handoff_timeout()
+        for k in range(3):
+            part = model(mel[32 * k:32 * (k + 1)].contiguous())
+            assert (part - big[32 * k:32 * (k + 1)]).abs().max().item() < 2e-3, k      # (GEMM tile order differs with M)
+        model.model.raise_on_handoff_timeout()
+    assert torch.isfinite(big).all() and float(big.std()) > 1e-3
 
 
 # ------------------------------------------------------------------ BASELINE-size properties (no oracle needed at this size)
