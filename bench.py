@@ -310,16 +310,17 @@ def cpu_baseline_small(model, wave, logits, cores):
 
 
 def section_coscheduled(mta, dev, net, fe, wave32):
-    """The same workload with the three batches of 32 chunks CO-SCHEDULED: one forward over B = 96, in which the recurrence
-    interleaves the three batch groups inside one persistent launch (csrc/lstm.hip, NG) -- while one group's h travels to its
-    consumers the workgroup computes the others' steps -- and the GEMMs see M = 96 T rows.  Informational: the headline keeps
-    BASELINE's batch = 32 per forward."""
+    """The same workload with several batches of 32 chunks CO-SCHEDULED in one forward (B = 64 / 96 / 128): the recurrence
+    interleaves the batch groups inside one persistent launch (csrc/lstm.hip, NG) -- while one group's h travels to its consumers
+    the workgroup computes the others' steps -- and the GEMMs see M = B T rows.  Informational: the headline keeps BASELINE's
+    batch = 32 per forward.  MT_BENCH_COSCHED = "96x1,96x2" selects (chunks per forward) x (streams)."""
     import torch
-    B, K = 96, 12
     T = mta.num_frames(N_SAMPLES, HOP)
-    wave = torch.cat([wave32] * 3)
     out = {}
-    for NS in (1, 2):
+    for combo in os.environ.get("MT_BENCH_COSCHED", "96x1,96x2").split(","):
+        B, NS = (int(v) for v in combo.split("x"))
+        K = max(6, 1152 // B)
+        wave = torch.cat([wave32] * (B // 32))
         streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
         mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
         cmax = [torch.empty(B, device=dev) for _ in range(NS)]
@@ -338,11 +339,11 @@ def section_coscheduled(mta, dev, net, fe, wave32):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         net.raise_on_handoff_timeout(B, T)
-        out[f"streams_{NS}"] = {"value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_forward": round(1e3 * el / K, 3)}
+        out[f"b{B}_streams_{NS}"] = {"value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_forward": round(1e3 * el / K, 3),
+                                     "finite": bool(torch.isfinite(lg).all())}
         del mel, cmax
         net._ws.clear()
-    out["workload"] = "CNNRNNModel inference, 3 batches of 32 chunks co-scheduled in one forward (B = 96)"
-    out["finite"] = bool(torch.isfinite(lg).all())
+    out["workload"] = "CNNRNNModel inference, several batches of 32 chunks co-scheduled in one forward"
     return out
 
 

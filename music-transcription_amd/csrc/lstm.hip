@@ -80,6 +80,7 @@ __device__ __forceinline__ void sleep64(int n) {
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // tanh(x) = 2 sigmoid(2x) - 1
 __device__ __forceinline__ float tanhf_(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
+constexpr int OOB_OFF = 0x7FFFFF00;           // a buffer offset beyond every resource here: such loads return 0, such stores are dropped
 constexpr unsigned H_POISON = 0xFFFFFFFFu;   // never the bit pattern of a hidden state (|h| < 1)
 #ifndef MT_FLAG_REPL
 #define MT_FLAG_REPL 8
@@ -96,6 +97,34 @@ __device__ unsigned long long mt_lstm_diag[1024][8];
 #define DIAG_STAMP(i) do { } while (0)
 #endif
 
+// Vector-memory loads the compiler does not track (NG > 1 variants of lstm_rec_kernel).  The requests of several batch groups are
+// in flight across the slots of a step; the compiler's own bookkeeping cannot count them through the poll loops and falls back to
+// s_waitcnt vmcnt(0) -- which waits for the youngest request to get at the oldest.  Here every such load is an asm statement, and
+// the wait in front of its consumer is written by hand from the fixed issue order of a slot (vm_wait<N>: at most N younger
+// requests may still be out; loads return in order).  `vm_settle` ties a register to the wait that precedes it in program order
+// (volatile asm statements keep their order), so no consumer can be scheduled above the wait.
+typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4_t;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+__device__ __forceinline__ i32x4_t raw_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void asm_load_b128_sc1(u32x4_t& dst, int voff, i32x4_t rsrc) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(dst) : "v"(voff), "s"(rsrc));
+}
+template <int OFF>
+__device__ __forceinline__ void asm_load_b32(float& dst, int voff, i32x4_t rsrc) {
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N)); }
+__device__ __forceinline__ void vm_settle(u32x4_t& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void vm_settle(float& v) { asm volatile("" : "+v"(v)); }
+
 // XP = true: the layer's INPUT PROJECTION is fused in (layers fed by another LSTM layer): no gx buffer (0.5 GB written by a
 // GEMM and read back here), no projection GEMM, no re-layout pass between the layers.  x_t is read as MFMA B operands
 // straight from the previous layer's hx images (plain loads, issued at the top of the step), and the product W_ihx x_t
@@ -110,7 +139,7 @@ template <int NKSW, bool TRAIN = false, bool XP = false, int NG = 1>   // NKSW: 
 // Register budget: without the fused projection the kernel is held to 128 registers per lane (VGPRs + AGPRs; launch bound of
 // 4 waves per SIMD) so that one of its waves shares a SIMD with the two 192-register waves of the big-tile GEMM: a GEMM of
 // another batch in flight then still gets every CU (tests/test_kernel_budget_cpu.py).
-__global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
+__global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 ? 3 : 4))) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][64][20];       // [k-slice wave][lane][16 regs + pad]: 80-B lane stride, conflict-free b128
     __shared__ __attribute__((aligned(16))) f16_t hs[32][8];           // [batch][unit]
 #ifdef MT_LSTM_LDS_PAD
@@ -132,9 +161,13 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
     f16x8 w16[NKSW];
 #pragma unroll
     for (int i = 0; i < NKSW; ++i) {
-        const int ks = wv * NKSW + i;
+        const int ks = wv * NKSW + i, ksc = min(ks, nks - 1);       // (clamped address + select: no branch, the loads pipeline)
+        const f32x4 w0 = *(const f32x4*)(wsrc + ksc * 16 + 8 * hh), w1 = *(const f32x4*)(wsrc + ksc * 16 + 8 * hh + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w16[i][j] = (ks < nks) ? (f16_t)wsrc[ks * 16 + 8 * hh + j] : (f16_t)0.0f;
+        for (int j = 0; j < 4; ++j) {
+            w16[i][j] = (ks < nks) ? (f16_t)w0[j] : (f16_t)0.0f;
+            w16[i][4 + j] = (ks < nks) ? (f16_t)w1[j] : (f16_t)0.0f;
+        }
     }
 
     // XP: the W_ih slice of the same 32 gate rows over the 2H input features (2 NKSW k-steps per wave), f16
@@ -144,9 +177,13 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
         const float* wxsrc = a.w_ihx + ((size_t)d * 4 * H + wrow) * (2 * H);
 #pragma unroll
         for (int i = 0; i < NKSX; ++i) {
-            const int kx = wv * NKSX + i;
+            const int kx = wv * NKSX + i, kxc = min(kx, 2 * nks - 1);
+            const f32x4 w0 = *(const f32x4*)(wxsrc + kxc * 16 + 8 * hh), w1 = *(const f32x4*)(wxsrc + kxc * 16 + 8 * hh + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) wx[i][j] = (kx < 2 * nks) ? (f16_t)wxsrc[kx * 16 + 8 * hh + j] : (f16_t)0.0f;
+            for (int j = 0; j < 4; ++j) {
+                wx[i][j] = (kx < 2 * nks) ? (f16_t)w0[j] : (f16_t)0.0f;
+                wx[i][4 + j] = (kx < 2 * nks) ? (f16_t)w1[j] : (f16_t)0.0f;
+            }
         }
     }
 
@@ -168,6 +205,46 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
     long long tl = __builtin_amdgcn_s_memrealtime();
 #endif
 
+    // NG > 1: the h gather of the NEXT (step, group) slot is issued right behind this slot's MFMAs, so that its round trip through
+    // the memory system runs under this slot's reduce / cell / publish phases (the slot that published those bytes lies ngh - 1
+    // slots back: they have usually landed; if not, the poison check sends the wave into the ordinary re-issue loop)
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+    // NG = 4: requested TWO slots ahead (two register sets, alternating with the slot): a request then has two slot times to come
+    // back, and the bytes it asks for were published two slots before it was issued.
+    constexpr int PD = (NG == 4 && NKSW <= 8) ? 2 : 1;
+    u32x4 hqs[PD][NKSW];
+#ifdef MT_LSTM_NOPF
+    const bool pf = false;
+#else
+    const bool pf = NG > 1 && (PD == 1 ? ngh > 1 : ngh == NG);
+#endif
+    // The gate pre-activations come from HBM: group gi's values for step s + 1 are requested as soon as its cell update of step s has
+    // consumed the registers (gxr[gi]), a whole round of slots ahead of their use.  (A lane of a padded batch row passes an
+    // out-of-range offset and reads 0: no branch in the step.)
+    float gxr[NG][4];
+    auto request_gx = [&](float (&dst)[4], int sn, int gn) {
+        const int tn = d ? (T - 1 - sn) : sn;
+        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.gx + (size_t)gn * gd_blocks * 1024 + ((size_t)tn * 2 + d) * nkb * 1024), 0, nkb * 4096, 0x00020000);
+        const int goff = (sn < T && b < min(32, a.B - gn * 32)) ? (kb * 1024 + jl * 32 + b) * 4 : OOB_OFF;
+        if (NG > 1) {
+            const i32x4_t gr = raw_rsrc(a.gx + (size_t)gn * gd_blocks * 1024 + ((size_t)tn * 2 + d) * nkb * 1024, nkb * 4096);
+            asm_load_b32<0>(dst[0], goff, gr); asm_load_b32<1024>(dst[1], goff, gr);
+            asm_load_b32<2048>(dst[2], goff, gr); asm_load_b32<3072>(dst[3], goff, gr);
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) dst[pp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, goff, pp * 1024, 0));
+        }
+    };
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        if (!XP) request_gx(gxr[gi], gi < ngh ? 0 : T, gbase + gi);
+    }
+    // NG > 1, all NG groups present, away from the ends of the sequence: the issue order of a slot is fixed -- [wait h] MFMAs, 8 h
+    // requests for the next slot, reduce, [wait gx] cell, 4 gx requests for this group's next step, publish -- so a group's gx
+    // values are followed by 12 requests per other group's slot and the 8 of this slot, and a slot's h by the 4 gx requests behind it
+    // (vmcnt is a 6-bit counter: a larger bound is cut to 63, which waits for more than needed, never for less)
+    constexpr int GX_YOUNGER = (NKSW + (NG - 1) * (NKSW + 4)) < 63 ? (NKSW + (NG - 1) * (NKSW + 4)) : 63;
     for (int s = 0; s < T; ++s) {
         const int t = d ? (T - 1 - s) : s;
         const int tprev = d ? (t + 1) : (t - 1);
@@ -177,17 +254,14 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
         const int g = gbase + gi;
         const int Bg = min(32, a.B - g * 32);                           // valid batch rows of this group
         float& c = cst[gi];
+        u32x4 (&hq)[NKSW] = hqs[gi % PD];               // (NG slots per step and PD divides NG: the slot's parity is gi's)
         const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
         char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
         // buffer resource over this group's hx (all t, both d): offsets stay < 2^31
         const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
             XP ? (void*)((const char*)a.hx_prev + (size_t)g * gd_blocks * 512) : (void*)hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
-        // gate pre-activations from the input projection (independent of h: issue early)
-        float gxv[4];
-        const float* gxp = gx_g + (((size_t)t * 2 + d) * nkb + kb) * 1024 + jl * 32 + b;
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) gxv[pp] = XP ? bias4[pp] : ((b < Bg) ? gxp[pp * 256] : 0.0f);
+
         // XP: x_t = the previous layer's h of step t, both directions (2H features), as MFMA B operands straight from its
         // hx images (plain loads: that buffer is complete)
         typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_;
@@ -196,8 +270,7 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
 #pragma unroll
             for (int i = 0; i < NKSX; ++i) {
                 const int kx = wv * NKSX + i, dsel = kx >= nks ? 1 : 0, ksx = kx - dsel * nks;
-                xr[i] = (kx < 2 * nks) ? __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ((t * 2 + dsel) * nkb) * 512 + ksx * 1024 + lane * 16, 0, 0)
-                                       : u32x4_{0, 0, 0, 0};
+                xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (kx < 2 * nks) ? ((t * 2 + dsel) * nkb) * 512 + ksx * 1024 + lane * 16 : OOB_OFF, 0, 0);
             }
         }
         f32x16 acc, accx;
@@ -221,13 +294,23 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
             //      A word still holding the poison pattern means its store has not landed: redo (rare, bounded).
             const int hbase = ((tprev * 2 + d) * nkb) * 512 + lane * 16;
             long long t1 = 0;
+            const i32x4_t hr = raw_rsrc(hx_g, (unsigned)(gd_blocks * 512));
             for (unsigned it = 0;; ++it) {
-                typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-                u32x4 rh[NKSW];
+                if (!pf || it > 0) {
 #pragma unroll
-                for (int i = 0; i < NKSW; ++i) {
-                    const int ks = wv * NKSW + i;
-                    rh[i] = (ks < nks) ? __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 1024, 0, 16 /*sc1*/) : u32x4{0, 0, 0, 0};
+                    for (int i = 0; i < NKSW; ++i) {
+                        const int ks = wv * NKSW + i;
+                        if (NG > 1) asm_load_b128_sc1(hq[i], (ks < nks) ? hbase + ks * 1024 : OOB_OFF, hr);
+                        else hq[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (ks < nks) ? hbase + ks * 1024 : OOB_OFF, 0, 16 /*sc1*/);
+                    }
+                }
+                if (NG > 1) {
+                    // requested PD slots ago: younger are the 4 gx requests of that slot and, with PD = 2, the previous slot's NKSW + 4
+                    // (in the sequence's last step a slot may have had nothing left to request)
+                    if (pf && it == 0 && (PD == 1 || s + 1 < T)) vm_wait<4 + (PD - 1) * (NKSW + 4)>();
+                    else vm_wait<0>();
+#pragma unroll
+                    for (int i = 0; i < NKSW; ++i) vm_settle(hq[i]);
                 }
                 if (XP) {
                     if (it == 0) {                     // the input projection runs under the gather's latency
@@ -241,8 +324,8 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
                 unsigned worst = 0;
 #pragma unroll
                 for (int i = 0; i < NKSW; ++i) {
-                    worst = max(max(worst, max(rh[i][0], rh[i][1])), max(rh[i][2], rh[i][3]));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[i], __builtin_bit_cast(f16x8, rh[i]), acc, 0, 0, 0);
+                    worst = max(max(worst, max(hq[i][0], hq[i][1])), max(hq[i][2], hq[i][3]));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[i], __builtin_bit_cast(f16x8, hq[i]), acc, 0, 0, 0);
                 }
                 if (!__any(worst == H_POISON)) break;
 #pragma unroll
@@ -265,6 +348,21 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
                 }
             }
         }
+        // ---- requests for the slot PD ahead: (s, gi + PD), or (s + 1, gi + PD - ngh)
+        const bool wrap = gi + PD >= ngh;
+        const int sn = s + (wrap ? 1 : 0), gn = wrap ? g + PD - ngh : g + PD;
+        if (pf) {
+            if (sn > 0 && sn < T) {
+                const int tpn = d ? (T - sn) : (sn - 1);                // the step before sn, as a time index
+                const i32x4_t nr = raw_rsrc((char*)a.hx + (size_t)gn * gd_blocks * 512, (unsigned)(gd_blocks * 512));
+                const int nbase = ((tpn * 2 + d) * nkb) * 512 + lane * 16;
+#pragma unroll
+                for (int i = 0; i < NKSW; ++i) {
+                    const int ks = wv * NKSW + i;
+                    asm_load_b128_sc1(hq[i], (ks < nks) ? nbase + ks * 1024 : OOB_OFF, nr);
+                }
+            }
+        }
 #ifdef MT_LSTM_DIAG
         asm volatile("" :: "v"(acc[0]));
 #endif
@@ -275,14 +373,24 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
             *(f32x4*)(&red[wv][lane][4 * e4]) = f32x4{acc[4 * e4], acc[4 * e4 + 1], acc[4 * e4 + 2], acc[4 * e4 + 3]};
         __syncthreads();
         DIAG_STAMP(3);
-        if (abort_s) return;                           // a payload spin gave up (status word says where)
+        if (abort_s) {                                 // a payload spin gave up (status word says where)
+            if (NG > 1) vm_wait<0>();
+            return;
+        }
         float pre[4];
+        if (NG > 1) {                                  // this group's gx values, requested a round of slots ago
+            if (pf && ngh == NG && s >= 2 && s + 2 <= T) vm_wait<GX_YOUNGER>();
+            else vm_wait<0>();
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) vm_settle(gxr[gi][pp]);
+        }
         {
             const f32x4 r0 = *(const f32x4*)(&red[0][lane][4 * wv]), r1 = *(const f32x4*)(&red[1][lane][4 * wv]);
             const f32x4 r2 = *(const f32x4*)(&red[2][lane][4 * wv]), r3 = *(const f32x4*)(&red[3][lane][4 * wv]);
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + gxv[pp];
+            for (int pp = 0; pp < 4; ++pp) pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + (XP ? bias4[pp] : gxr[gi][pp]);
         }
+        if (!XP) request_gx(gxr[gi], s + 1, g);
         // ---- cell update (PyTorch LSTM): c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')
         const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
         c = fmaf(fg, c, ig * gg);
@@ -304,18 +412,16 @@ __global__ __launch_bounds__(256, XP ? 1 : 4) void lstm_rec_kernel(LstmArgs a) {
         DIAG_STAMP(5);
         __syncthreads();                                          // pieces assembled; every wave is done with `red`
         if (wv == 0) {
-            typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
             const u32x4 piece = *(const u32x4*)(&hs[b][0]);
             const int hoff = ((t * 2 + d) * nkb) * 512 + (kb >> 1) * 1024 + ((kb & 1) * 32 + b) * 16;
-            if (lane < 32) {
-                __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, hoff, 0, 16 /*sc1: write-through*/);
-            }
+            __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, lane < 32 ? hoff : OOB_OFF, 0, 16 /*sc1: write-through*/);
             // NO drain and no flag: a consumer that gets ahead of the payload sees the poison pattern in the words that have not
             // landed and redoes its loads (every word is written exactly once by one store, so it is either poison or final).
         }
         DIAG_STAMP(6);
       }
     }
+    if (NG > 1) vm_wait<0>();
 #ifdef MT_LSTM_DIAG
     if (tid == 0) {
         const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -545,7 +651,8 @@ template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, hipStream_t st) {
     if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
     else if (a.cx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, true, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_train");
-    else if (ngroups == 1) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false>), dim3(a.H >> 3, 2, 1), "mt_lstm_bidir_fwd");
+    // (H > 512: a workgroup's W_hh slice takes 64 registers per lane and the interleaved variants would spill: one group per workgroup)
+    else if (ngroups == 1 || NKSW > 8) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd");
     // inference with several batch groups: up to 4 groups interleaved inside one set of workgroups (see NG above)
     else if (ngroups == 2) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, 2>), dim3(a.H >> 3, 2, 1), "mt_lstm_bidir_fwd");
     else if (ngroups == 3) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, 3>), dim3(a.H >> 3, 2, 1), "mt_lstm_bidir_fwd");
@@ -591,6 +698,7 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     MT_REQUIRE(sync_bytes >= mt_lstm_sync_bytes(B, H), MT_EWORKSPACE, "mt_lstm_bidir_fwd: sync workspace too small");
     const int nkb = H >> 3, ng = cdiv(B, 32);
     MT_REQUIRE((size_t)T * 2 * nkb * 512 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_bidir_fwd: T*H too large for one buffer descriptor");
+    MT_REQUIRE((((size_t)w_hh | (size_t)w_ihx) & 15) == 0, MT_EINVAL, "mt_lstm_bidir_fwd: weight matrices must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
     MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
@@ -606,8 +714,8 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     // 4 batch groups per launch, each lane's H/16 workgroups share one XCD.  Further groups run as further launches.
     static std::atomic<unsigned> rotate{0};
     const int zmax = (256 / (2 * nkb)) > 0 ? (256 / (2 * nkb)) : 1;
-    const int per_launch = xcd_local ? 4 : ((cx || w_ihx) ? zmax : 4 * zmax);
     const int nksw = cdiv(nkb / 2, 4);
+    const int per_launch = xcd_local ? 4 : ((cx || w_ihx || nksw > 8) ? zmax : 4 * zmax);
     for (int g0 = 0; g0 < ng; g0 += per_launch) {
         a.g0 = g0;
         const int n = (ng - g0) < per_launch ? (ng - g0) : per_launch;

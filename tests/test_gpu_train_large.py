@@ -463,7 +463,7 @@ def test_large_full_size_training_step(mta):
         if "onset_head" in k or "offset_head" in k:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k        # frame-only loss (train_transcriber.py:119)
         elif k[len("model."):] in ZERO_GRAD:
-            assert p.grad is not None and float(p.grad.abs().max()) == 0.0, k   # conv bias in front of a BatchNorm
+            assert p.grad is not None and float(p.grad.abs().max()) < 1e-6, k   # conv bias in front of a BatchNorm: zero up to the rounding of sum(dz)
         else:
             assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, k
     assert not torch.equal(rm0, m.model.freq_aware_conv[1].running_mean)

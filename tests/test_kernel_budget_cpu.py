@@ -32,7 +32,9 @@ def _alloc(n):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_gemm256x_and_plain_recurrence_share_a_simd(tmp_path):
     g = {k: v for k, v in _vgprs("gemm.hip", tmp_path).items() if "gemm256x_kernel" in k}
-    r = {k: v for k, v in _vgprs("lstm.hip", tmp_path).items() if "lstm_rec_kernelILi8ELb0ELb0E" in k}
+    # the one-group-per-workgroup recurrence (what a batch of 32 launches); the variants that interleave several batch groups
+    # (NG = 2..4) spend registers on requests in flight instead and are not held to this budget
+    r = {k: v for k, v in _vgprs("lstm.hip", tmp_path).items() if "lstm_rec_kernelILi8ELb0ELb0ELi1E" in k}
     assert g and r
     gemm, rec = max(g.values()), max(r.values())
     assert 2 * _alloc(gemm) + _alloc(rec) <= 512, (gemm, rec)

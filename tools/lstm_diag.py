@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "music-transcription_amd", "csrc")
 so = "/tmp/libmt_hip_diag.so"
 extra = os.environ.get("MT_DIAG_FLAGS", "")
-srcs = [os.path.join(csrc, f) for f in ("api.hip", "lstm.hip")]
+srcs = [os.path.join(csrc, f) for f in ("api.hip", "lstm.hip", "residency.hip")]
 subprocess.check_call(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMT_LSTM_DIAG {extra} -I{ROOT}/include -shared {' '.join(srcs)} -o {so}", shell=True)
 lib = C.CDLL(so)
 B, T, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (32, 938, 512)))
