@@ -317,7 +317,7 @@ def section_coscheduled(mta, dev, net, fe, wave32):
     import torch
     T = mta.num_frames(N_SAMPLES, HOP)
     out = {}
-    for combo in os.environ.get("MT_BENCH_COSCHED", "96x1,96x2").split(","):
+    for combo in os.environ.get("MT_BENCH_COSCHED", "32x3,96x1,96x4,128x3").split(","):
         B, NS = (int(v) for v in combo.split("x"))
         K = max(6, 1152 // B)
         wave = torch.cat([wave32] * (B // 32))
@@ -330,17 +330,21 @@ def section_coscheduled(mta, dev, net, fe, wave32):
             with torch.cuda.stream(streams[s]), torch.no_grad():
                 fe(wave, clamp=False, out=mel[s], chunk_max=cmax[s])
                 return net(mel[s], chunk_max_power=cmax[s])
-        for j in range(NS + 1):
-            step(j)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for j in range(K):
-            lg = step(j)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        net.raise_on_handoff_timeout(B, T)
-        out[f"b{B}_streams_{NS}"] = {"value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_forward": round(1e3 * el / K, 3),
-                                     "finite": bool(torch.isfinite(lg).all())}
+        try:
+            for j in range(NS + 1):
+                step(j)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for j in range(K):
+                lg = step(j)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            net.raise_on_handoff_timeout(B, T)
+            out[f"b{B}_streams_{NS}"] = {"value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_forward": round(1e3 * el / K, 3),
+                                         "finite": bool(torch.isfinite(lg).all())}
+        except Exception as e:                      # (e.g. the library's residency check refusing that many launches in flight)
+            torch.cuda.synchronize()
+            out[f"b{B}_streams_{NS}"] = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         del mel, cmax
         net._ws.clear()
     out["workload"] = "CNNRNNModel inference, several batches of 32 chunks co-scheduled in one forward"
@@ -491,11 +495,14 @@ def section_train(mta, dev, cores, do_cpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 5 ms: long enough that the first and last rounds of the streams in flight do not weigh)")
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (300 x 3.5 ms: long enough that the first and last rounds of the forwards in flight do not weigh)")
+    ap.add_argument("--warmup", type=int, default=9)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--streams", type=int, default=3,
-                    help="independent batches in flight per GPU (each step is issued whole on stream i %% streams)")
+                    help="forwards in flight per GPU (forward f is issued whole on stream f %% streams)")
+    ap.add_argument("--cosched", type=int, default=3,
+                    help="batches (steps) co-scheduled into ONE forward: the recurrence interleaves their batch groups inside one "
+                         "persistent launch (csrc/lstm.hip, NG).  1 = one batch per forward, as in round 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sections", action="store_true", help="only the headline line: skip the 1-stream pass and the configs[2] / configs[3] sections")
     ap.add_argument("--model", choices=["cnn_rnn", "cnn_rnn_large"], default="cnn_rnn",
@@ -536,16 +543,21 @@ def main():
     from music_transcription_amd import model as mt_model
 
     B, K, W = args.batch, args.steps, args.warmup
+    C = max(1, min(args.cosched, 4, K))               # batches per forward (the recurrence interleaves at most 4 batch groups of 32)
+    BF = C * B                                        # chunks per forward
     T = mta.num_frames(N_SAMPLES, HOP)
-    # Recurrence hand-off: with >= 3 batches in flight the XCD-local 16-unit variant (csrc/lstm.hip, mode 2) holds 64 CUs per
-    # launch instead of 128 and wins (+4..7 % measured); alone it loses to the agent-scope kernel (1.98 vs 1.53 ms per layer).
-    # It takes effect only if a census launch shows the dispatcher dealing workgroups evenly over the XCDs (model.lstm_mode).
-    if "MT_LSTM_MODE" not in os.environ and max(1, args.streams) >= 3:
+    # A STEP is one pass of the hot path over one batch of B = 32 chunks (BASELINE configs[1]).  The steps of the timed region are
+    # issued C at a time as one forward over C x 32 chunks (K % C left-over steps as one smaller forward at the end), and --streams
+    # such forwards are in flight: C x streams batches of 32 at once, against round 1's 3 (one per stream).
+    # One batch per forward (--cosched 1) with >= 3 streams: the XCD-local 16-unit recurrence (csrc/lstm.hip, mode 2) holds 64 CUs
+    # per launch instead of 128; it takes effect only if a census launch shows the dispatcher dealing workgroups evenly over the XCDs.
+    if "MT_LSTM_MODE" not in os.environ and C == 1 and max(1, args.streams) >= 3:
         os.environ["MT_LSTM_MODE"] = "2"
     # seeded synthetic input: noise + decaying piano-range sinusoids; seed = 1234 + rank.
     # Four distinct chunks tiled to the batch keep host-side synthesis short; the kernels see B chunks.
     base = synth_audio(min(B, 4), N_SAMPLES, seed=1234 + rank)
     wave = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B].copy()).to(dev)
+    wave_f = torch.cat([wave] * C) if C > 1 else wave
     model = seeded_model(mta, "cnn_rnn", str(dev))
     model.eval()
     net = model.model
@@ -559,45 +571,54 @@ def main():
     if NS > 6:
         raise SystemExit("--streams: at most 6 forwards in flight per GPU (co-residency of the persistent recurrence launches)")
     # with several batches in flight the projection GEMMs are the shared resource: let layers 1.. project inside the recurrence
-    net.fuse_input_projection = NS == 2
+    net.fuse_input_projection = NS == 2 and C == 1
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-    mel = [torch.empty(B, 1, N_MELS, T, device=dev) for _ in range(NS)]
-    cmax = [torch.empty(B, device=dev) for _ in range(NS)]
+    mel = [torch.empty(BF, 1, N_MELS, T, device=dev) for _ in range(NS)]
+    cmax = [torch.empty(BF, device=dev) for _ in range(NS)]
 
     nst = 3 + 3 * LAYERS
-    ev_mel = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K)]
-    ev_net = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K)]
+    NF, REM = K // C, K % C                          # full forwards of C steps, steps left over for one smaller forward
+    ev_mel = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(NF)]
+    ev_net = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(NF)]
     for row in ev_mel + ev_net:          # create the underlying hipEvent_t handles before the timed region
         for e in row:
             e.record()
 
-    def step(j, i=None):
-        """One whole pass (mel + forward) over one batch, issued on stream j % NS."""
+    def forward(j, i=None, nb=C):
+        """One whole pass (mel + forward) over nb batches of B chunks, issued on stream j % NS."""
         s = j % NS
+        n = nb * B
         with torch.cuda.stream(streams[s]), torch.no_grad():
             if i is not None:
                 ev_mel[i][0].record()
-            fe(wave, clamp=False, out=mel[s], chunk_max=cmax[s])   # unclamped dB + per-chunk max; conv1 clamps on load
+            fe(wave_f[:n], clamp=False, out=mel[s][:n], chunk_max=cmax[s][:n])   # unclamped dB + per-chunk max; conv1 clamps on load
             if i is not None:
                 ev_mel[i][1].record()
-            return net(mel[s], chunk_max_power=cmax[s], events=None if i is None else ev_net[i])
+            return net(mel[s][:n], chunk_max_power=cmax[s][:n], events=None if i is None else ev_net[i])
 
-    log(f"rank {rank}/{world}: setup done, B={B} T={T}; warmup {W}, steps {K}")
-    for j in range(max(W, NS if W else 0)):
-        step(j)
+    log(f"rank {rank}/{world}: setup done, B={B} x {C} per forward, T={T}, {NS} streams; warmup {W}, steps {K}")
+    for j in range(max((W + C - 1) // C, NS if W else 0)):
+        forward(j)
+    if REM and W:
+        forward(0, nb=REM)                           # (its workspace shape, before the timed region)
+        forward(1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(K):
-        logits = step(i, i)
+    for i in range(NF):
+        logits = forward(i, i)
+    if REM:
+        logits = forward(NF, nb=REM)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    net.raise_on_handoff_timeout(B, T)
+    net.raise_on_handoff_timeout(BF, T)
+    if REM:
+        net.raise_on_handoff_timeout(REM * B, T)
     hl_mode = int(mt_model._LSTM_MODE.get(dev_index, 0))        # what the timed region actually ran (census may have refused mode 2)
     log(f"timed region: {elapsed:.3f} s for {K} steps")
     if world > 1:
@@ -622,9 +643,9 @@ def main():
             for i in range(K1 + 1):
                 ii = max(i - 1, 0)                       # (first iteration = warm-up of the un-fused path, overwritten)
                 ev1m[ii][0].record()
-                fe(wave, clamp=False, out=mel[0], chunk_max=cmax[0])
+                fe(wave, clamp=False, out=mel[0][:B], chunk_max=cmax[0][:B])
                 ev1m[ii][1].record()
-                net(mel[0], chunk_max_power=cmax[0], events=ev1n[ii])
+                net(mel[0][:B], chunk_max_power=cmax[0][:B], events=ev1n[ii])
         torch.cuda.synchronize()
         net.raise_on_handoff_timeout(B, T)
         one_ms = [float(np.mean([ev1m[i][0].elapsed_time(ev1m[i][1]) for i in range(K1)]))]
@@ -636,10 +657,10 @@ def main():
     if rank == 0:
         # ---- per-kernel times from the events recorded inside the timed region (several batches in flight: kernels of
         #      different steps overlap, so these are NOT kernel efficiencies -- those come from the 1-stream pass below)
-        table = stage_table(B, T, N_MELS, HIDDEN, LAYERS, fused=bool(net.fuse_input_projection))
-        ms = [float(np.mean([ev_mel[i][0].elapsed_time(ev_mel[i][1]) for i in range(K)]))]
+        table = stage_table(BF, T, N_MELS, HIDDEN, LAYERS, fused=bool(net.fuse_input_projection))
+        ms = [float(np.mean([ev_mel[i][0].elapsed_time(ev_mel[i][1]) for i in range(NF)]))]
         for s in range(nst):
-            ms.append(float(np.mean([ev_net[i][s].elapsed_time(ev_net[i][s + 1]) for i in range(K)])))
+            ms.append(float(np.mean([ev_net[i][s].elapsed_time(ev_net[i][s + 1]) for i in range(NF)])))
         stages_overlapped = _stage_rows(table, ms)
         dom_key_o, roofline_overlapped = _roofline_from_stages(stages_overlapped)
         if one_ms is not None:
@@ -670,7 +691,7 @@ def main():
         cpu = None
         cores = host_cores()
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline_small(model, wave, logits, cores)
+            cpu = cpu_baseline_small(model, wave, logits[:B], cores)
         sections = {}
         if world == 1 and not args.no_sections:
             mt_model._LSTM_MODE[dev_index] = 0           # the sections below run the agent-scope recurrence
@@ -678,10 +699,10 @@ def main():
             net._ws.clear()
             torch.cuda.empty_cache()
             try:
-                sections["configs1_coscheduled_b96"] = section_coscheduled(mta, dev, net, fe, wave)
+                sections["configs1_other_schedules"] = section_coscheduled(mta, dev, net, fe, wave)
             except Exception as e:
                 import traceback
-                sections["configs1_coscheduled_b96"] = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
+                sections["configs1_other_schedules"] = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
             for name, fn in (("configs2_large_b16", section_large), ("configs3_train_b16", section_train)):
                 t1 = time.perf_counter()
                 try:
@@ -700,7 +721,11 @@ def main():
                "data": "synthetic",
                "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
                                       "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
-                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)", "streams_per_gpu": NS, "fused_input_projection": bool(net.fuse_input_projection), "lstm_mode": hl_mode},
+                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)",
+                          "coscheduled_batches_per_forward": C, "streams_per_gpu": NS, "batches_in_flight": C * NS,
+                          "scheduling": f"a step = one batch of {B} chunks; {C} steps are issued as one forward over {BF} chunks (the recurrence "
+                                        f"interleaves their batch groups in one persistent launch), {NS} forwards in flight on {NS} streams",
+                          "fused_input_projection": bool(net.fuse_input_projection), "lstm_mode": hl_mode},
                "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
                "roofline_overlapped": roofline_overlapped, "stages_overlapped": stages_overlapped, **sections}
         print(json.dumps(out))

@@ -97,12 +97,12 @@ __device__ unsigned long long mt_lstm_diag[1024][8];
 #define DIAG_STAMP(i) do { } while (0)
 #endif
 
-// Vector-memory loads the compiler does not track (NG > 1 variants of lstm_rec_kernel).  The requests of several batch groups are
-// in flight across the slots of a step; the compiler's own bookkeeping cannot count them through the poll loops and falls back to
-// s_waitcnt vmcnt(0) -- which waits for the youngest request to get at the oldest.  Here every such load is an asm statement, and
-// the wait in front of its consumer is written by hand from the fixed issue order of a slot (vm_wait<N>: at most N younger
-// requests may still be out; loads return in order).  `vm_settle` ties a register to the wait that precedes it in program order
-// (volatile asm statements keep their order), so no consumer can be scheduled above the wait.
+// Vector-memory loads the compiler does not track (NG > 1 variants of lstm_rec_kernel).  There the h gather of the next slot is
+// requested in the middle of the current one and stays in flight across its barriers and its publish store; the compiler's own
+// bookkeeping cannot count requests through the poll loops and falls back to s_waitcnt vmcnt(0) at the first opportunity.  So the
+// gather is an asm statement and the wait in front of its consumer is written by hand from the fixed issue order of a slot
+// (vm_wait<N>: at most N younger requests may still be out; loads return in order).  `vm_settle` ties a register to the wait
+// that precedes it in program order (volatile asm statements keep their order), so no consumer can be scheduled above the wait.
 typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4_t;
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
 __device__ __forceinline__ i32x4_t raw_rsrc(const void* p, unsigned bytes) {
@@ -117,13 +117,8 @@ __device__ __forceinline__ i32x4_t raw_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ void asm_load_b128_sc1(u32x4_t& dst, int voff, i32x4_t rsrc) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(dst) : "v"(voff), "s"(rsrc));
 }
-template <int OFF>
-__device__ __forceinline__ void asm_load_b32(float& dst, int voff, i32x4_t rsrc) {
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen offset:%3" : "=v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF));
-}
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N)); }
 __device__ __forceinline__ void vm_settle(u32x4_t& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void vm_settle(float& v) { asm volatile("" : "+v"(v)); }
 
 // XP = true: the layer's INPUT PROJECTION is fused in (layers fed by another LSTM layer): no gx buffer (0.5 GB written by a
 // GEMM and read back here), no projection GEMM, no re-layout pass between the layers.  x_t is read as MFMA B operands
@@ -133,15 +128,22 @@ __device__ __forceinline__ void vm_settle(float& v) { asm volatile("" : "+v"(v))
 // the projection GEMM (0.38 ms) and the re-layout disappear: a loss with one batch in flight (-6 %), a gain when
 // several are (+8 % at three: the GEMMs are the serialised resource there).  Opt-in (mt_cnnrnn_weights.w_ihx).
 // NG > 1: ONE workgroup carries the same 8 hidden units of NG batch groups (same W_hh slice, one cell state per group) and walks
-// them round-robin inside every step: while group g's published h travels to its consumers (the ~1 us hand-off that bounds a lone
-// step), the workgroup computes the other groups' steps, so B = 32 NG chunks cost little more time per step than 32.
+// them round-robin inside every step ("slots"): while group g's published h travels to its consumers (the ~1 us hand-off that
+// bounds a lone step), the workgroup computes the other groups' slots, and the gather of the next slot is already in flight
+// (measured at H = 512: 1.44 us per step for 32 chunks, 2.6 us for 96).
 template <int NKSW, bool TRAIN = false, bool XP = false, int NG = 1>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
 // Register budget: without the fused projection the kernel is held to 128 registers per lane (VGPRs + AGPRs; launch bound of
 // 4 waves per SIMD) so that one of its waves shares a SIMD with the two 192-register waves of the big-tile GEMM: a GEMM of
 // another batch in flight then still gets every CU (tests/test_kernel_budget_cpu.py).
-__global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 ? 3 : 4))) void lstm_rec_kernel(LstmArgs a) {
+__global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][64][20];       // [k-slice wave][lane][16 regs + pad]: 80-B lane stride, conflict-free b128
     __shared__ __attribute__((aligned(16))) f16_t hs[32][8];           // [batch][unit]
+    // Without the fused projection the workgroup has a FIFTH wave that does nothing but bring the gate pre-activations in: the 4-KB
+    // gx block of every (step, group) slot goes from HBM straight into this ring by LDS-DMA, GX_RING - 1 slots ahead of its use.
+    // HBM latency is then nobody's critical path -- in a compute wave's own memory queue those requests sat in front of the h gather
+    // (vector-memory loads return in order) and every step waited for HBM instead of for the hand-off.
+    constexpr int GX_RING = XP ? 1 : 6;
+    __shared__ __attribute__((aligned(16))) float gring[GX_RING][XP ? 4 : 1024];
 #ifdef MT_LSTM_LDS_PAD
     __shared__ char lds_pad[MT_LSTM_LDS_PAD];                          // experiment: inflate the LDS footprint
     if (threadIdx.x == 0) lds_pad[blockIdx.x & 1023] = 1;
@@ -152,6 +154,40 @@ __global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 
     const int kb = blockIdx.x, d = blockIdx.y, gbase = blockIdx.z * NG + a.g0;
     const int ngh = min(NG, a.g0 + a.ngl - gbase);   // batch groups this workgroup carries
     const int b = lane & 31, hh = lane >> 5;
+
+    if (!XP && wv == 4) {
+        // ---- the loader wave.  Slots are numbered in execution order, n = step * ngh + group; slot n lives in gring[n % GX_RING].
+        //      It takes part in the workgroup's barriers (one before the loop, two per slot) and in nothing else.
+        typedef __attribute__((address_space(1))) void gvoid_t;
+        typedef __attribute__((address_space(3))) void lvoid_t;
+        const size_t gd_blocks_l = (size_t)T * 2 * nkb;
+        const int nslots = T * ngh;
+        int is = 0, ig = 0;                                         // (step, group) of the next slot to request
+        auto request = [&](int n) {
+            const int tn = d ? (T - 1 - is) : is;
+            const float* src = a.gx + (size_t)(gbase + ig) * gd_blocks_l * 1024 + (((size_t)tn * 2 + d) * nkb + kb) * 1024 + lane * 4;
+            float* dst = &gring[n % GX_RING][0];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) __builtin_amdgcn_global_load_lds((gvoid_t*)(src + qq * 256), (lvoid_t*)(dst + qq * 256), 16, 0, 0);
+            if (++ig == ngh) { ig = 0; ++is; }
+        };
+        for (int n = 0; n < GX_RING - 1 && n < nslots; ++n) request(n);
+        __builtin_amdgcn_s_barrier();
+        for (int n = 0; n < nslots; ++n) {
+            if (n + GX_RING - 1 < nslots) {
+                request(n + GX_RING - 1);                             // into the ring slot the compute waves read in slot n - 1
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (GX_RING - 1)) : "memory");   // slot n has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                             // the slot's reduce barrier: gring[n % GX_RING] is readable behind it
+            int ab;                                                   // (asm: the compiler would drain every DMA in flight in front of an LDS read)
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ab) : "v"((unsigned)(size_t)(lvoid_t*)&abort_s) : "memory");
+            if (ab) return;
+            __builtin_amdgcn_s_barrier();                             // the slot's publish barrier
+        }
+        return;
+    }
 
     // ---- W_hh slice as MFMA A-operands (f16): lane (row r, k half hh) holds
     //      W[row][16 ks + 8 hh + j], j = 0..7; row r = 8q + 4h + p <-> unit 2q + h, gate p
@@ -209,42 +245,13 @@ __global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 
     // the memory system runs under this slot's reduce / cell / publish phases (the slot that published those bytes lies ngh - 1
     // slots back: they have usually landed; if not, the poison check sends the wave into the ordinary re-issue loop)
     typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-    // NG = 4: requested TWO slots ahead (two register sets, alternating with the slot): a request then has two slot times to come
-    // back, and the bytes it asks for were published two slots before it was issued.
-    constexpr int PD = (NG == 4 && NKSW <= 8) ? 2 : 1;
-    u32x4 hqs[PD][NKSW];
+    u32x4 hq[NKSW];
 #ifdef MT_LSTM_NOPF
     const bool pf = false;
 #else
-    const bool pf = NG > 1 && (PD == 1 ? ngh > 1 : ngh == NG);
+    const bool pf = NG > 1 && ngh > 1;
 #endif
-    // The gate pre-activations come from HBM: group gi's values for step s + 1 are requested as soon as its cell update of step s has
-    // consumed the registers (gxr[gi]), a whole round of slots ahead of their use.  (A lane of a padded batch row passes an
-    // out-of-range offset and reads 0: no branch in the step.)
-    float gxr[NG][4];
-    auto request_gx = [&](float (&dst)[4], int sn, int gn) {
-        const int tn = d ? (T - 1 - sn) : sn;
-        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.gx + (size_t)gn * gd_blocks * 1024 + ((size_t)tn * 2 + d) * nkb * 1024), 0, nkb * 4096, 0x00020000);
-        const int goff = (sn < T && b < min(32, a.B - gn * 32)) ? (kb * 1024 + jl * 32 + b) * 4 : OOB_OFF;
-        if (NG > 1) {
-            const i32x4_t gr = raw_rsrc(a.gx + (size_t)gn * gd_blocks * 1024 + ((size_t)tn * 2 + d) * nkb * 1024, nkb * 4096);
-            asm_load_b32<0>(dst[0], goff, gr); asm_load_b32<1024>(dst[1], goff, gr);
-            asm_load_b32<2048>(dst[2], goff, gr); asm_load_b32<3072>(dst[3], goff, gr);
-        } else {
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) dst[pp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, goff, pp * 1024, 0));
-        }
-    };
-#pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
-        if (!XP) request_gx(gxr[gi], gi < ngh ? 0 : T, gbase + gi);
-    }
-    // NG > 1, all NG groups present, away from the ends of the sequence: the issue order of a slot is fixed -- [wait h] MFMAs, 8 h
-    // requests for the next slot, reduce, [wait gx] cell, 4 gx requests for this group's next step, publish -- so a group's gx
-    // values are followed by 12 requests per other group's slot and the 8 of this slot, and a slot's h by the 4 gx requests behind it
-    // (vmcnt is a 6-bit counter: a larger bound is cut to 63, which waits for more than needed, never for less)
-    constexpr int GX_YOUNGER = (NKSW + (NG - 1) * (NKSW + 4)) < 63 ? (NKSW + (NG - 1) * (NKSW + 4)) : 63;
+    int ring = 0;                                     // gring slot of the current (step, group) slot
     for (int s = 0; s < T; ++s) {
         const int t = d ? (T - 1 - s) : s;
         const int tprev = d ? (t + 1) : (t - 1);
@@ -254,7 +261,6 @@ __global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 
         const int g = gbase + gi;
         const int Bg = min(32, a.B - g * 32);                           // valid batch rows of this group
         float& c = cst[gi];
-        u32x4 (&hq)[NKSW] = hqs[gi % PD];               // (NG slots per step and PD divides NG: the slot's parity is gi's)
         const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
         char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
         // buffer resource over this group's hx (all t, both d): offsets stay < 2^31
@@ -305,9 +311,8 @@ __global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 
                     }
                 }
                 if (NG > 1) {
-                    // requested PD slots ago: younger are the 4 gx requests of that slot and, with PD = 2, the previous slot's NKSW + 4
-                    // (in the sequence's last step a slot may have had nothing left to request)
-                    if (pf && it == 0 && (PD == 1 || s + 1 < T)) vm_wait<4 + (PD - 1) * (NKSW + 4)>();
+                    // requested in the previous slot: nothing younger is in this wave's queue but, in wave 0, that slot's publish store
+                    if (pf && it == 0 && wv == 0) vm_wait<1>();
                     else vm_wait<0>();
 #pragma unroll
                     for (int i = 0; i < NKSW; ++i) vm_settle(hq[i]);
@@ -328,6 +333,9 @@ __global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[i], __builtin_bit_cast(f16x8, hq[i]), acc, 0, 0, 0);
                 }
                 if (!__any(worst == H_POISON)) break;
+#ifdef MT_LSTM_DIAG
+                if (tid == 0) dg[7] += 1;                // (diagnostic build: payload polls that came back poisoned)
+#endif
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
                 sleep64(a.sleep_retry);
@@ -348,9 +356,9 @@ __global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 
                 }
             }
         }
-        // ---- requests for the slot PD ahead: (s, gi + PD), or (s + 1, gi + PD - ngh)
-        const bool wrap = gi + PD >= ngh;
-        const int sn = s + (wrap ? 1 : 0), gn = wrap ? g + PD - ngh : g + PD;
+        // ---- request the next slot's h: (s, gi + 1), or (s + 1, first group)
+        const bool wrap = gi + 1 >= ngh;
+        const int sn = s + (wrap ? 1 : 0), gn = wrap ? gbase : g + 1;
         if (pf) {
             if (sn > 0 && sn < T) {
                 const int tpn = d ? (T - sn) : (sn - 1);                // the step before sn, as a time index
@@ -378,19 +386,14 @@ __global__ __launch_bounds__(256, XP ? 1 : ((NKSW > 8 || NG == 4) ? 2 : (NG > 1 
             return;
         }
         float pre[4];
-        if (NG > 1) {                                  // this group's gx values, requested a round of slots ago
-            if (pf && ngh == NG && s >= 2 && s + 2 <= T) vm_wait<GX_YOUNGER>();
-            else vm_wait<0>();
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) vm_settle(gxr[gi][pp]);
-        }
         {
             const f32x4 r0 = *(const f32x4*)(&red[0][lane][4 * wv]), r1 = *(const f32x4*)(&red[1][lane][4 * wv]);
             const f32x4 r2 = *(const f32x4*)(&red[2][lane][4 * wv]), r3 = *(const f32x4*)(&red[3][lane][4 * wv]);
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + (XP ? bias4[pp] : gxr[gi][pp]);
+            for (int pp = 0; pp < 4; ++pp)                          // (+ the loader wave's gx block; padded batch rows stay at 0)
+                pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + (XP ? bias4[pp] : (b < Bg ? gring[ring][pp * 256 + jl * 32 + b] : 0.0f));
         }
-        if (!XP) request_gx(gxr[gi], s + 1, g);
+        ring = ring + 1 == GX_RING ? 0 : ring + 1;
         // ---- cell update (PyTorch LSTM): c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')
         const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
         c = fmaf(fg, c, ig * gg);
@@ -626,15 +629,16 @@ int persistent_admit(const void* kernel, int block, size_t smem, int nwg, hipStr
 int persistent_mark(hipStream_t st);
 
 // every workgroup of a persistent launch must be resident: admission check first (fails fast), completion event behind it
-#define MT_PERSISTENT_LAUNCH(kernel, grid, who)                                                                   \
+#define MT_PERSISTENT_LAUNCH_N(kernel, grid, nthreads, who)                                                       \
     do {                                                                                                          \
         const dim3 g_ = (grid);                                                                                   \
-        int rc_ = persistent_admit((const void*)(kernel), 256, 0, (int)(g_.x * g_.y * g_.z), st, who);            \
+        int rc_ = persistent_admit((const void*)(kernel), (nthreads), 0, (int)(g_.x * g_.y * g_.z), st, who);     \
         if (rc_ != MT_OK) return rc_;                                                                             \
-        hipLaunchKernelGGL((kernel), g_, dim3(256), 0, st, a);                                                    \
+        hipLaunchKernelGGL((kernel), g_, dim3(nthreads), 0, st, a);                                               \
         MT_CHECK_LAUNCH();                                                                                        \
         if ((rc_ = persistent_mark(st)) != MT_OK) return rc_;                                                     \
     } while (0)
+#define MT_PERSISTENT_LAUNCH(kernel, grid, who) MT_PERSISTENT_LAUNCH_N(kernel, grid, 256, who)
 
 template <int NKSW>
 static int launch_rec16(const LstmArgs& a, hipStream_t st) {
@@ -650,13 +654,13 @@ static int launch_rec16(const LstmArgs& a, hipStream_t st) {
 template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, hipStream_t st) {
     if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
-    else if (a.cx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, true, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_train");
+    else if (a.cx) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, true, false>), dim3(a.H >> 3, 2, ngroups), 320, "mt_lstm_bidir_fwd_train");
     // (H > 512: a workgroup's W_hh slice takes 64 registers per lane and the interleaved variants would spill: one group per workgroup)
-    else if (ngroups == 1 || NKSW > 8) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd");
+    else if (ngroups == 1 || NKSW > 8) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false>), dim3(a.H >> 3, 2, ngroups), 320, "mt_lstm_bidir_fwd");
     // inference with several batch groups: up to 4 groups interleaved inside one set of workgroups (see NG above)
-    else if (ngroups == 2) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, 2>), dim3(a.H >> 3, 2, 1), "mt_lstm_bidir_fwd");
-    else if (ngroups == 3) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, 3>), dim3(a.H >> 3, 2, 1), "mt_lstm_bidir_fwd");
-    else MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, false, 4>), dim3(a.H >> 3, 2, cdiv(ngroups, 4)), "mt_lstm_bidir_fwd");
+    else if (ngroups == 2) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 2>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd");
+    else if (ngroups == 3) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 3>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd");
+    else MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 4>), dim3(a.H >> 3, 2, cdiv(ngroups, 4)), 320, "mt_lstm_bidir_fwd");
     return MT_OK;
 }
 

@@ -36,3 +36,4 @@ names = ["poll wait", "barrier", "h load + MFMA", "LDS reduce (+barrier)", "cell
 for i, n in enumerate(names[:7]):
     print(f"{n:24s} mean {d[:, i].mean():8.0f} ns   min {d[:, i].min():8.0f}   max {d[:, i].max():8.0f}")
 print(f"{'sum':24s} mean {d[:, :7].sum(1).mean():8.0f} ns")
+print(f"poisoned polls per step (wave 0): mean {out[:nwg][out[:nwg].sum(1) > 0][:, 7].mean() / T:.3f}")
