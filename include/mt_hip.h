@@ -46,6 +46,11 @@ extern "C" {
  * exponent range for gradients; BASELINE configs[3] names bf16).  The un-suffixed entry points are the bf16 forms. */
 #define MT_DT_BF16 0
 #define MT_DT_F16  1
+/* Flag OR-ed into `dt` of mt_gemm_lstm_gx_dt and into `mode` of mt_lstm_bidir_fwd_ex (mode 0 only): the gate pre-activations
+ * travel between the two as f16 -- same [group][t][dir][unit/8][gate][unit%8][chunk%32] layout, half the bytes of the largest
+ * intermediate of the forward (492 -> 246 MB per layer at B = 32); round-to-nearest-even of W_ih x + b, added in f32 by the
+ * cell update.  Inference only (the training step keeps its gates in f32).                                                  */
+#define MT_GX_F16  0x10
 
 #define MT_N_FFT 2048        /* librosa default the reference relies on (main.py:117-122) */
 #define MT_N_PITCH 88
@@ -124,6 +129,9 @@ int    mt_gemm_logits(const void* X, int ldx, const void* W, int ldw, const floa
  * re-layout pass between the layers.  hx_prev as mt_lstm_bidir_fwd* wrote it for the same B, T.                      */
 int    mt_gemm_lstm_gx_from_hx(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
                                int B, int T, int H, int Hprev, mt_stream_t stream);
+/* The same; gx_f16 != 0 stores gx as f16 (see MT_GX_F16).                                                              */
+int    mt_gemm_lstm_gx_from_hx_ex(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
+                                  int B, int T, int H, int Hprev, int gx_f16, mt_stream_t stream);
 int    mt_gemm_logits_from_hx(const float* hx_prev, const void* W, int ldw, const float* bias, float* logits,
                               int B, int T, int N, int Hprev, mt_stream_t stream);
 /* The three GEMMs above with the operand type of A and W chosen by the caller (dt = MT_DT_BF16 | MT_DT_F16). */

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmt_hip.so")
 MAX_LSTM_LAYERS = 8
 N_PITCH = 88
 DT_BF16, DT_F16 = 0, 1          # MT_DT_* (include/mt_hip.h): 16-bit operand type of the GEMM / conv kernels
+GX_F16 = 0x10                   # MT_GX_F16: gate pre-activations travel GEMM -> recurrence as f16
 
 
 class MtError(RuntimeError):
@@ -92,6 +93,7 @@ _SIGS = {
     "mt_attn_softmax_clamped_dt": (i32, [vp, i32, vp, i32, i32, ll, C.c_float, C.c_float, i32, vp]),
     "mt_layernorm_residual_dt": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, ll, i32, C.c_float, i32, vp]),
     "mt_gemm_lstm_gx_from_hx": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_gemm_lstm_gx_from_hx_ex": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mt_gemm_logits_from_hx": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_bf16_f32acc": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_lstm_gx": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),

@@ -47,6 +47,9 @@ struct GemmEpi {
     // AHX: A is read straight from an LSTM layer's hx images (lstm.hip: [b/32][t][dir][k/16][(k/8 % 2)*32 + b%32][8] f16) instead of
     // row-major rows -- row m = t*aB + b, column k = dir*aH + unit -- so no re-layout pass sits between the layers (f16 operands)
     int aB, aT, aH;
+    // EPI_LSTM_GX: store the gate pre-activations as f16 (same layout, half the bytes: inference; the recurrence's loader wave
+    // streams them and the cell update adds them in f32)
+    int gx16;
 };
 
 // element offset of row m / of the 16-byte chunk (K-tile kt, chunk c8 of its 8) in the hx layout; aH % 64 == 0
@@ -68,6 +71,20 @@ __device__ __forceinline__ void dh_store(const GemmEpi& ep, float* outp, int m, 
 }
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+// EPI_LSTM_GX stores: element index `idx` of the gx layout, as f32 or (ep.gx16) as f16 rounded to nearest even
+__device__ __forceinline__ void gx_store1(float* outp, size_t idx, float v, int gx16) {
+    if (gx16) ((f16_t*)outp)[idx] = (f16_t)v;
+    else outp[idx] = v;
+}
+__device__ __forceinline__ void gx_store4(float* outp, size_t idx, float v0, float v1, float v2, float v3, int gx16) {   // idx % 4 == 0
+    if (gx16) {
+        typedef __attribute__((__vector_size__(4 * sizeof(f16_t)))) f16_t f16x4_;
+        *(f16x4_*)((f16_t*)outp + idx) = f16x4_{(f16_t)v0, (f16_t)v1, (f16_t)v2, (f16_t)v3};
+    } else {
+        *(f32x4*)(outp + idx) = f32x4{v0, v1, v2, v3};
+    }
+}
 
 // Epilogue of ONE 32x32 accumulator tile whose first row / column is (mb, nb).  Unswapped: lane column = n, register
 // rows = m.  Swapped (EPI_LSTM_GX): lane column = m, register rows = n.
@@ -121,12 +138,12 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, int mb, int nb,
             // the 32 rows of this tile share (direction, gate) when they do not straddle a multiple of H
             const int d0 = nb / (4 * H), rem0 = nb - d0 * 4 * H, p0 = rem0 / H, jj0 = rem0 - p0 * H;
             if (jj0 + 32 <= H && nb + 32 <= N) {
-                float* o = outp + tg + (size_t)d0 * nkb * 1024 + p0 * 256;
                 const float* bp = ep.bias + nb;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = (e & 3) + 8 * (e >> 2) + 4 * h, jj = jj0 + row;
-                    o[(size_t)(jj >> 3) * 1024 + (jj & 7) * 32] = acc[e] + bp[row];
+                    const size_t idx = tg + (size_t)d0 * nkb * 1024 + p0 * 256 + (size_t)(jj >> 3) * 1024 + (jj & 7) * 32;
+                    gx_store1(outp, idx, acc[e] + bp[row], ep.gx16);
                 }
             } else {
 #pragma unroll
@@ -134,7 +151,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16& acc, int mb, int nb,
                     const int n = nb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     if (n < N) {
                         const int d = n / (4 * H), rem = n - d * 4 * H, p = rem / H, jj = rem - p * H;
-                        outp[tg + ((size_t)(d * nkb + (jj >> 3)) * 4 + p) * 256 + (jj & 7) * 32] = acc[e] + ep.bias[n];
+                        gx_store1(outp, tg + ((size_t)(d * nkb + (jj >> 3)) * 4 + p) * 256 + (jj & 7) * 32, acc[e] + ep.bias[n], ep.gx16);
                     }
                 }
             }
@@ -314,15 +331,14 @@ __device__ __forceinline__ void epilogue_tile16(const f32x4& acc, int mb, int nb
             const float bv = ep.bias[n];
             const int t = m4 / ep.B, b = m4 - t * ep.B;
             if ((ep.B & 3) == 0 && m4 + 4 <= M) {           // 4 | B: the 4 rows are 4 consecutive chunks of one (t, group)
-                float* o = outp + ((size_t)((b >> 5) * ep.T + t) * 2) * nkb * 1024 + nofs + (b & 31);
-                *(f32x4*)o = f32x4{acc[0] + bv, acc[1] + bv, acc[2] + bv, acc[3] + bv};
+                gx_store4(outp, ((size_t)((b >> 5) * ep.T + t) * 2) * nkb * 1024 + nofs + (b & 31), acc[0] + bv, acc[1] + bv, acc[2] + bv, acc[3] + bv, ep.gx16);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int m = m4 + j;
                     if (m < M) {
                         const int t1 = m / ep.B, b1 = m - t1 * ep.B;
-                        outp[((size_t)((b1 >> 5) * ep.T + t1) * 2) * nkb * 1024 + nofs + (b1 & 31)] = acc[j] + bv;
+                        gx_store1(outp, ((size_t)((b1 >> 5) * ep.T + t1) * 2) * nkb * 1024 + nofs + (b1 & 31), acc[j] + bv, ep.gx16);
                     }
                 }
             }
@@ -497,17 +513,17 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict_
             const int m4 = m0 + wm * 128 + i * 16 + 4 * q;
             if (m4 >= M) continue;
             const int t = m4 / ep.B, b = m4 - t * ep.B;
-            float* o = outp + ((size_t)((b >> 5) * ep.T + t) * 2) * nkb * 1024 + (b & 31);
+            const size_t o = ((size_t)((b >> 5) * ep.T + t) * 2) * nkb * 1024 + (b & 31);
             if (m4 + 4 <= M) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (nok[j]) *(f32x4*)(o + nofs[j]) = f32x4{acc[i][j][0] + bv[j], acc[i][j][1] + bv[j], acc[i][j][2] + bv[j], acc[i][j][3] + bv[j]};
+                    if (nok[j]) gx_store4(outp, o + nofs[j], acc[i][j][0] + bv[j], acc[i][j][1] + bv[j], acc[i][j][2] + bv[j], acc[i][j][3] + bv[j], ep.gx16);
             } else {                                        // 4 | B, so the rows below M still share (t, group)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (nok[j] && m4 + e < M) o[nofs[j] + e] = acc[i][j][e] + bv[j];
+                        if (nok[j] && m4 + e < M) gx_store1(outp, o + nofs[j] + e, acc[i][j][e] + bv[j], ep.gx16);
             }
         }
         return;
@@ -643,7 +659,8 @@ extern "C" int mt_gemm_lstm_gx_dt(const void* X, int ldx, const void* W_ih, int 
     MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx: bias is required (b_ih + b_hh)");
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx: bad dims B=%d T=%d H=%d", B, T, H);
     GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1};
-    return launch(EPI_LSTM_GX, dt, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream);
+    ep.gx16 = (dt & MT_GX_F16) ? 1 : 0;
+    return launch(EPI_LSTM_GX, dt & ~MT_GX_F16, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream);
 }
 extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
                                int B, int T, int H, int K, mt_stream_t stream) {
@@ -652,12 +669,17 @@ extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw
 
 // The same two projections with A read straight from the previous LSTM layer's hx images (f16 operands; hx as
 // mt_lstm_bidir_fwd* writes it, B / T / H of THAT layer, H % 64 == 0): K = 2H, column k = dir*H + unit.
-extern "C" int mt_gemm_lstm_gx_from_hx(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
-                                       int B, int T, int H, int Hprev, mt_stream_t stream) {
+extern "C" int mt_gemm_lstm_gx_from_hx_ex(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
+                                          int B, int T, int H, int Hprev, int gx_f16, mt_stream_t stream) {
     MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx_from_hx: bias is required (b_ih + b_hh)");
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx_from_hx: bad dims B=%d T=%d H=%d", B, T, H);
     GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0.0f, 0, 0, B, T, Hprev};
+    ep.gx16 = gx_f16 ? 1 : 0;
     return launch_hx(EPI_LSTM_GX, hx_prev, W_ih, ldw, T * B, 8 * H, ep, (hipStream_t)stream);
+}
+extern "C" int mt_gemm_lstm_gx_from_hx(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
+                                       int B, int T, int H, int Hprev, mt_stream_t stream) {
+    return mt_gemm_lstm_gx_from_hx_ex(hx_prev, W_ih, ldw, bias, gx, B, T, H, Hprev, 0, stream);
 }
 extern "C" int mt_gemm_logits_from_hx(const float* hx_prev, const void* W, int ldw, const float* bias, float* logits,
                                       int B, int T, int N, int Hprev, mt_stream_t stream) {

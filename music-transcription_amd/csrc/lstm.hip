@@ -131,7 +131,7 @@ __device__ __forceinline__ void vm_settle(u32x4_t& v) { asm volatile("" : "+v"(v
 // them round-robin inside every step ("slots"): while group g's published h travels to its consumers (the ~1 us hand-off that
 // bounds a lone step), the workgroup computes the other groups' slots, and the gather of the next slot is already in flight
 // (measured at H = 512: 1.44 us per step for 32 chunks, 2.6 us for 96).
-template <int NKSW, bool TRAIN = false, bool XP = false, int NG = 1>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4)
+template <int NKSW, bool TRAIN = false, bool XP = false, int NG = 1, bool G16 = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4); G16: gx is f16
 // Register budget: without the fused projection the kernel is held to 128 registers per lane (VGPRs + AGPRs; launch bound of
 // 4 waves per SIMD) so that one of its waves shares a SIMD with the two 192-register waves of the big-tile GEMM: a GEMM of
 // another batch in flight then still gets every CU (tests/test_kernel_budget_cpu.py).
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
     // HBM latency is then nobody's critical path -- in a compute wave's own memory queue those requests sat in front of the h gather
     // (vector-memory loads return in order) and every step waited for HBM instead of for the hand-off.
     constexpr int GX_RING = XP ? 1 : 6;
-    __shared__ __attribute__((aligned(16))) float gring[GX_RING][XP ? 4 : 1024];
+    constexpr int GX_DMA = G16 ? 2 : 4;               // DMA instructions (1 KB each) per slot
+    __shared__ __attribute__((aligned(16))) float gring[GX_RING][XP ? 4 : (G16 ? 512 : 1024)];      // (G16: 1024 f16 per slot)
 #ifdef MT_LSTM_LDS_PAD
     __shared__ char lds_pad[MT_LSTM_LDS_PAD];                          // experiment: inflate the LDS footprint
     if (threadIdx.x == 0) lds_pad[blockIdx.x & 1023] = 1;
@@ -165,22 +166,28 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
         int is = 0, ig = 0;                                         // (step, group) of the next slot to request
         auto request = [&](int n) {
             const int tn = d ? (T - 1 - is) : is;
-            const float* src = a.gx + (size_t)(gbase + ig) * gd_blocks_l * 1024 + (((size_t)tn * 2 + d) * nkb + kb) * 1024 + lane * 4;
-            float* dst = &gring[n % GX_RING][0];
+            // (block of (t, d, kb): 1024 values, 4 KB as f32 / 2 KB as f16; one DMA instruction moves 1 KB)
+            const size_t blk = (size_t)(gbase + ig) * gd_blocks_l + ((size_t)tn * 2 + d) * nkb + kb;
+            const char* src = (const char*)a.gx + blk * (G16 ? 2048 : 4096) + lane * 16;
+            char* dst = (char*)&gring[n % GX_RING][0];
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) __builtin_amdgcn_global_load_lds((gvoid_t*)(src + qq * 256), (lvoid_t*)(dst + qq * 256), 16, 0, 0);
+            for (int qq = 0; qq < GX_DMA; ++qq) __builtin_amdgcn_global_load_lds((gvoid_t*)(src + qq * 1024), (lvoid_t*)(dst + qq * 1024), 16, 0, 0);
             if (++ig == ngh) { ig = 0; ++is; }
         };
         for (int n = 0; n < GX_RING - 1 && n < nslots; ++n) request(n);
+        // (a slot's block has landed one barrier EARLY -- slot n + 1 before slot n's reduce barrier, slot 0 before the first barrier --
+        //  so the compute waves read it at the top of the slot, off the path between the reduce and the cell update)
+        if (GX_RING - 1 <= nslots) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GX_DMA * (GX_RING - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         for (int n = 0; n < nslots; ++n) {
             if (n + GX_RING - 1 < nslots) {
                 request(n + GX_RING - 1);                             // into the ring slot the compute waves read in slot n - 1
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (GX_RING - 1)) : "memory");   // slot n has landed
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GX_DMA * (GX_RING - 2)) : "memory");   // slot n + 1 has landed
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();                             // the slot's reduce barrier: gring[n % GX_RING] is readable behind it
+            __builtin_amdgcn_s_barrier();                             // the slot's reduce barrier: gring[(n + 1) % GX_RING] is readable behind it
             int ab;                                                   // (asm: the compiler would drain every DMA in flight in front of an LDS read)
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ab) : "v"((unsigned)(size_t)(lvoid_t*)&abort_s) : "memory");
             if (ab) return;
@@ -279,6 +286,22 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
                 xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (kx < 2 * nks) ? ((t * 2 + dsel) * nkb) * 512 + ksx * 1024 + lane * 16 : OOB_OFF, 0, 0);
             }
         }
+        float gxv[4];                                               // the loader wave's gx block (landed one barrier ago)
+        if (XP) {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) gxv[pp] = bias4[pp];
+        } else if (G16) {
+            unsigned short raw[4];                                  // (all four reads first, then the conversions)
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) raw[pp] = ((const unsigned short*)gring[ring])[pp * 256 + jl * 32 + b];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) gxv[pp] = (float)__builtin_bit_cast(f16_t, raw[pp]);
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) gxv[pp] = gring[ring][pp * 256 + jl * 32 + b];
+        }
+        ring = ring + 1 == GX_RING ? 0 : ring + 1;
         f32x16 acc, accx;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = accx[e] = 0.0f;
@@ -390,10 +413,9 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
             const f32x4 r0 = *(const f32x4*)(&red[0][lane][4 * wv]), r1 = *(const f32x4*)(&red[1][lane][4 * wv]);
             const f32x4 r2 = *(const f32x4*)(&red[2][lane][4 * wv]), r3 = *(const f32x4*)(&red[3][lane][4 * wv]);
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp)                          // (+ the loader wave's gx block; padded batch rows stay at 0)
-                pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + (XP ? bias4[pp] : (b < Bg ? gring[ring][pp * 256 + jl * 32 + b] : 0.0f));
+            for (int pp = 0; pp < 4; ++pp)                          // (padded batch rows stay at 0)
+                pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + ((XP || b < Bg) ? gxv[pp] : 0.0f);
         }
-        ring = ring + 1 == GX_RING ? 0 : ring + 1;
         // ---- cell update (PyTorch LSTM): c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')
         const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
         c = fmaf(fg, c, ig * gg);
@@ -652,15 +674,19 @@ static int launch_rec16(const LstmArgs& a, hipStream_t st) {
 }
 
 template <int NKSW>
-static int launch_rec(const LstmArgs& a, int ngroups, hipStream_t st) {
+static int launch_rec(const LstmArgs& a, int ngroups, bool g16, hipStream_t st) {
     if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
     else if (a.cx) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, true, false>), dim3(a.H >> 3, 2, ngroups), 320, "mt_lstm_bidir_fwd_train");
     // (H > 512: a workgroup's W_hh slice takes 64 registers per lane and the interleaved variants would spill: one group per workgroup)
-    else if (ngroups == 1 || NKSW > 8) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false>), dim3(a.H >> 3, 2, ngroups), 320, "mt_lstm_bidir_fwd");
     // inference with several batch groups: up to 4 groups interleaved inside one set of workgroups (see NG above)
-    else if (ngroups == 2) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 2>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd");
-    else if (ngroups == 3) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 3>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd");
-    else MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 4>), dim3(a.H >> 3, 2, cdiv(ngroups, 4)), 320, "mt_lstm_bidir_fwd");
+#define MT_REC_PLAIN(G16_)                                                                                                              \
+    if (ngroups == 1 || NKSW > 8) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 1, G16_>), dim3(a.H >> 3, 2, ngroups), 320, "mt_lstm_bidir_fwd"); \
+    else if (ngroups == 2) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 2, G16_>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd");       \
+    else if (ngroups == 3) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 3, G16_>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd");       \
+    else MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, false, false, 4, G16_>), dim3(a.H >> 3, 2, cdiv(ngroups, 4)), 320, "mt_lstm_bidir_fwd");
+    else if (g16) { MT_REC_PLAIN(true) }
+    else { MT_REC_PLAIN(false) }
+#undef MT_REC_PLAIN
     return MT_OK;
 }
 
@@ -701,6 +727,9 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
                "mt_lstm_bidir_fwd: hidden size %d unsupported (multiple of 16, <= 1024)", H);
     MT_REQUIRE(sync_bytes >= mt_lstm_sync_bytes(B, H), MT_EWORKSPACE, "mt_lstm_bidir_fwd: sync workspace too small");
     const int nkb = H >> 3, ng = cdiv(B, 32);
+    const bool g16 = (xcd_local & MT_GX_F16) != 0;
+    xcd_local &= ~MT_GX_F16;
+    MT_REQUIRE(!g16 || (xcd_local == 0 && !cx && !w_ihx), MT_EINVAL, "mt_lstm_bidir_fwd_ex: MT_GX_F16 goes with mode 0 only");
     MT_REQUIRE((size_t)T * 2 * nkb * 512 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_bidir_fwd: T*H too large for one buffer descriptor");
     MT_REQUIRE((((size_t)w_hh | (size_t)w_ihx) & 15) == 0, MT_EINVAL, "mt_lstm_bidir_fwd: weight matrices must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -734,11 +763,11 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
             else if (nksw <= 4) rc = launch_rec16<4>(a, st);
             else if (nksw <= 8) rc = launch_rec16<8>(a, st);
             else rc = launch_rec16<16>(a, st);
-        } else if (nksw <= 1) rc = launch_rec<1>(a, n, st);
-        else if (nksw <= 2) rc = launch_rec<2>(a, n, st);
-        else if (nksw <= 4) rc = launch_rec<4>(a, n, st);
-        else if (nksw <= 8) rc = launch_rec<8>(a, n, st);
-        else rc = launch_rec<16>(a, n, st);
+        } else if (nksw <= 1) rc = launch_rec<1>(a, n, g16, st);
+        else if (nksw <= 2) rc = launch_rec<2>(a, n, g16, st);
+        else if (nksw <= 4) rc = launch_rec<4>(a, n, g16, st);
+        else if (nksw <= 8) rc = launch_rec<8>(a, n, g16, st);
+        else rc = launch_rec<16>(a, n, g16, st);
         if (rc != MT_OK) return rc;
     }
     return MT_OK;
@@ -770,7 +799,8 @@ extern "C" int mt_lstm_bidir_fwd_train(float* gx_inout, const float* w_hh, float
 // mode 0: agent-scope hand-off (placement-independent); mode 2: XCD-local, 16 units per workgroup (lstm_rec16_kernel).
 extern "C" int mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
                                     int B, int T, int H, int mode, mt_stream_t stream) {
-    MT_REQUIRE(mode == 0 || mode == 2, MT_EINVAL, "mt_lstm_bidir_fwd_ex: mode must be 0 (agent-scope hand-off) or 2 (XCD-local, 16 units per workgroup)");
+    MT_REQUIRE(mode == 0 || mode == 2 || mode == MT_GX_F16, MT_EINVAL,
+               "mt_lstm_bidir_fwd_ex: mode must be 0 (agent-scope hand-off; | MT_GX_F16: gx is f16) or 2 (XCD-local, 16 units per workgroup)");
     return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, mode, stream);
 }
 

@@ -11,7 +11,7 @@ int mt_gemm_lstm_gx_dt(const void*, int, const void*, int, const float*, float*,
 int mt_gemm_logits_dt(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
 int mt_lstm_relayout_dt(const float*, void*, int, float*, int, int, int, int, int, int, int, mt_stream_t);
-int mt_gemm_lstm_gx_from_hx(const float*, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
+int mt_gemm_lstm_gx_from_hx_ex(const float*, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
 int mt_gemm_logits_from_hx(const float*, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 size_t mt_lstm_gx_bytes(int, int, int);
@@ -108,6 +108,8 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
     // (needs un-padded hidden units in whole 64-wide K tiles; other sizes keep the re-layout.)  Layer l then writes hx buffer
     // l & 1, so the layer above reads its predecessor's while writing its own.
     const bool from_hx = dt == MT_DT_F16 && H == Hv && H % 64 == 0;
+    // f16 operands + agent-scope recurrence: the gate pre-activations travel GEMM -> recurrence as f16 (MT_GX_F16, include/mt_hip.h)
+    const int gx16 = (dt == MT_DT_F16 && w->lstm_mode == 0) ? MT_GX_F16 : 0;
     for (int l = 0; l < w->layers; ++l) {
         const bool last = l + 1 == w->layers;
         // layers > 0 with packed W_ihx: input projection fused into the recurrence (reads the previous layer's hx directly)
@@ -120,15 +122,15 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
         } else {
             const int K = l == 0 ? p.K0 : p.K1;
             if (l > 0 && from_hx) {
-                if ((rc = mt_gemm_lstm_gx_from_hx((const float*)hcur, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, H, stream)) != MT_OK) return rc;
+                if ((rc = mt_gemm_lstm_gx_from_hx_ex((const float*)hcur, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, H, gx16, stream)) != MT_OK) return rc;
                 char* tmp = hcur; hcur = hnext; hnext = tmp;                       // this layer writes the other buffer
             } else {
                 const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
-                if ((rc = mt_gemm_lstm_gx_dt(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, dt, stream)) != MT_OK) return rc;
+                if ((rc = mt_gemm_lstm_gx_dt(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, dt | gx16, stream)) != MT_OK) return rc;
             }
             if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
             if ((rc = mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * l,
-                                           p.sync_stride, B, T, H, w->lstm_mode, stream)) != MT_OK) return rc;
+                                           p.sync_stride, B, T, H, w->lstm_mode | gx16, stream)) != MT_OK) return rc;
         }
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
         // the next consumer of feature ROWS: a GEMM-projected layer, or the final fc (none when they read hx directly)

@@ -16,7 +16,7 @@ int mt_gemm_batched_f32_dt(const void*, int, long long, long long, const void*, 
 int mt_gemm_batched_h16out_dt(const void*, int, long long, long long, const void*, int, long long, long long, const float*, void*, int,
                               long long, long long, int, int, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
-int mt_gemm_lstm_gx_from_hx(const float*, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
+int mt_gemm_lstm_gx_from_hx_ex(const float*, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
 int mt_lstm_relayout_dt(const float*, void*, int, float*, int, int, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 int mt_attn_softmax_clamped_dt(const float*, int, void*, int, int, long long, float, float, int, mt_stream_t);
@@ -141,9 +141,11 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
         MT_CHECK_HIP(hipEventRecord((hipEvent_t)ev_fork, st));
         MT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, (hipEvent_t)ev_fork, 0));
     }
-    RUN(mt_gemm_lstm_gx_dt(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, dt, ls));
+    // f16 operands + agent-scope recurrence: the gate pre-activations travel GEMM -> recurrence as f16 (MT_GX_F16, include/mt_hip.h)
+    const int gx16 = (dt == MT_DT_F16 && w->lstm_mode == 0) ? MT_GX_F16 : 0;
+    RUN(mt_gemm_lstm_gx_dt(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, dt | gx16, ls));
     REC();
-    RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode, ls));
+    RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode | gx16, ls));
     REC();
     RUN(mt_lstm_relayout_dt((const float*)(ws + p.hx2), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, dt, ls));
     REC();
@@ -165,14 +167,14 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
             const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
             const int K = l == 0 ? p.K0 : p.K1;
             if (l > 0 && from_hx) {
-                RUN(mt_gemm_lstm_gx_from_hx((const float*)hcur, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, Hv, stream));
+                RUN(mt_gemm_lstm_gx_from_hx_ex((const float*)hcur, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, Hv, gx16, stream));
                 char* tmp = hcur; hcur = hnext; hnext = tmp;
             } else {
-                RUN(mt_gemm_lstm_gx_dt(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, dt, stream));
+                RUN(mt_gemm_lstm_gx_dt(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, dt | gx16, stream));
             }
             REC();
             RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * (l + 1),
-                                  p.sync_stride, B, T, p.Hp, w->lstm_mode, stream));
+                                  p.sync_stride, B, T, p.Hp, w->lstm_mode | gx16, stream));
         }
         REC();
         const bool next_fused = !last && w->main_w_ihx[l + 1] && w->lstm_mode == 0 && p.Hp <= 512;

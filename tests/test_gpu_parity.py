@@ -467,9 +467,8 @@ def test_fused_input_projection_matches_goldens(mta, golden_dir, tag):
         plain = model.model(x.cuda(), check_status=True).cpu()
         model.model.fuse_input_projection = True
         fused = model.model(x.cuda(), check_status=True).cpu()
-        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_f16=True))
-    # a different code path with the same answer (with f16 operands both paths multiply the same values; the f16
-    # rounding of every published h absorbs the f32 summation-order noise, so they often agree bit for bit)
+        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_f16=True, gx_f16=False))     # (layers > 0 take no gx buffer: nothing rounded there)
+    # a different code path with the same answer up to the f16 rounding of the plain path's gate pre-activations (layers > 0)
     assert (fused - plain).abs().max().item() < 2e-3
     assert (fused - emu).abs().max().item() < 2e-3
     assert np.abs(fused.numpy() - z[f"{tag}_logits"]).max() < 3e-2
