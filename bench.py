@@ -403,7 +403,37 @@ def section_large(mta, dev, cores, do_cpu):
     stages = _stage_rows(large_stage_table(B, T, N_MELS, HIDDEN, LAYERS), ms)
     _, roof = _roofline_from_stages(stages)
     roof["traffic_source"] = None
+    # the same with 4 batches of 16 per forward (two batch groups of 32 interleaved in each persistent recurrence launch)
+    cos = None
+    try:
+        C = 4
+        wave_c = torch.cat([wave] * C)
+        mel_c = [torch.empty(C * B, 1, N_MELS, T, device=dev) for _ in range(NS)]
+        cmax_c = [torch.empty(C * B, device=dev) for _ in range(NS)]
+
+        def step_c(j):
+            s = j % NS
+            with torch.cuda.stream(streams[s]), torch.no_grad():
+                fe(wave_c, clamp=False, out=mel_c[s], chunk_max=cmax_c[s])
+                return net(mel_c[s], chunk_max_power=cmax_c[s])
+        for j in range(NS + 1):
+            step_c(j)
+        torch.cuda.synchronize()
+        KC = 12
+        t0 = time.perf_counter()
+        for j in range(KC):
+            oc = step_c(j)
+        torch.cuda.synchronize()
+        elc = time.perf_counter() - t0
+        net.raise_on_handoff_timeout(C * B, T)
+        cos = {"value": round(C * B * KC / elc, 2), "unit": "chunks/s", "ms_per_step": round(1e3 * elc / (KC * C), 3),
+               "coscheduled_batches_per_forward": C, "streams_per_gpu": NS, "finite": bool(torch.isfinite(oc).all())}
+        del mel_c, cmax_c
+    except Exception as e:
+        torch.cuda.synchronize()
+        cos = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
     sec = {"workload": "CNNRNNModelLarge inference, batch=16 (BASELINE.json configs[2])", "value": round(B * K / el, 2), "unit": "chunks/s",
+           "coscheduled_4_batches_per_forward": cos,
            "ms_per_step": round(1e3 * el / K, 3), "steps": K, "streams_per_gpu": NS, "dtype": "f16 MFMA operands, f32 accumulate / LSTM state",
            "model_tflops_per_s": round(326.47e9 * B * T / 938.0 * K / el / 1e12, 1), "one_stream_ms_per_step": round(sum(ms), 3),
            "roofline": roof, "stages_one_stream": stages, "finite": bool(torch.isfinite(out).all())}

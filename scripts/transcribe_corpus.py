@@ -20,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per stream in flight (HIP's default of 4 makes streams share)
 
 
 def main():
@@ -33,7 +34,9 @@ def main():
     ap.add_argument("--hidden-size", type=int, default=512)
     ap.add_argument("--num-layers", type=int, default=3)
     ap.add_argument("--threshold", type=float, default=0.5)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=128,
+                    help="chunks per forward (the recurrence interleaves up to four batch groups of 32 in one persistent launch)")
+    ap.add_argument("--streams", type=int, default=4, help="forwards in flight (at most 3 for cnn_rnn_large: two recurrence launches each)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--dump-rolls", help="directory: write <name>.roll.bits.npy (np.packbits of the (88, T_total) roll) per recording")
     args = ap.parse_args()
@@ -90,10 +93,15 @@ def main():
         return y.clamp_(-1, 1).view(nch, CH)
 
     fe = mta.get_frontend(SR, args.n_mels, 512, dev)
-    with torch.no_grad():                   # warm-up: weight packing, workspaces, code objects
+    NS = max(1, min(args.streams, 3 if args.model_type == "cnn_rnn_large" else 6))
+    side = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    with torch.no_grad():                   # warm-up: weight packing, code objects, and every stream's workspace
         w0 = torch.zeros(args.batch, CH, device=dev)
-        m0, c0 = fe(w0, clamp=False)
-        model.model(m0, chunk_max_power=c0)
+        torch.cuda.synchronize()
+        for st in side:
+            with torch.cuda.stream(st):
+                m0, c0 = fe(w0, clamp=False)
+                model.model(m0, chunk_max_power=c0)
     synth_chunks = None if args.wav_dir else {i: synth(i) for i in mine}
     torch.cuda.synchronize()
     if world > 1:
@@ -110,11 +118,18 @@ def main():
         pieces.append(c)
     allc = torch.cat(pieces) if pieces else torch.zeros(0, CH, device=dev)
     n_chunks = allc.shape[0]
+    # the bench's schedule: forwards of --batch chunks, --streams of them in flight (forward f on stream f % streams)
     rolls = []
+    main_stream = torch.cuda.current_stream()
+    for st in side:
+        st.wait_stream(main_stream)                      # (the chunks were assembled on the main stream)
     with torch.no_grad():
-        for s in range(0, n_chunks, args.batch):
-            mel, cmax = fe(allc[s:s + args.batch], clamp=False)
-            rolls.append(mta.predict_from_logits(model.model(mel, chunk_max_power=cmax), args.threshold))
+        for f, s in enumerate(range(0, n_chunks, args.batch)):
+            with torch.cuda.stream(side[f % NS]):
+                mel, cmax = fe(allc[s:s + args.batch], clamp=False)
+                rolls.append(mta.predict_from_logits(model.model(mel, chunk_max_power=cmax), args.threshold))
+    for st in side:
+        main_stream.wait_stream(st)
     allr = torch.cat(rolls) if rolls else torch.zeros(0, 88, 938, device=dev)
     f1s, pos = [], 0
     for i, c in zip(mine, pieces):
