@@ -492,6 +492,39 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict_
 #undef GX_READ_B
 #undef GX_MFMA
 #undef GX_MID
+    if (EPI == EPI_LSTM_GX && ep.gx16 && (ep.B & 31) == 0 && (ep.H & 255) == 0 && m0 + BM2 <= M && n0 + BN2 <= N) {
+        // f16 gx, whole tile, whole batch groups: the tile is 8 row runs (one (t, batch group) each) x 32 column runs (one 8-unit
+        // block each) of 512 contiguous output bytes [unit][chunk].  Straight from the accumulators that would be 32 stores of 8 B
+        // per lane touching sixteen 64-B lines each; staged through the (now free) operand buffers it is 16 stores of 16 B per lane,
+        // 1 KB contiguous per wave instruction -- the K = 1024 projections spent a quarter of their time issuing the former.
+        const int H = ep.H, nkb = H >> 3;
+        const int d = n0 / (4 * H), rem = n0 - d * 4 * H, p = rem / H, jj0 = rem - p * H;      // uniform over the tile (256 | H)
+        char* stg = smem2;
+        typedef __attribute__((__vector_size__(4 * sizeof(f16_t)))) f16_t f16x4_;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float bv = ep.bias[n0 + wn * 64 + j * 16 + c16];
+            const int kbl = wn * 8 + j * 2 + (c16 >> 3), j8 = c16 & 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = wm * 4 + (i >> 1), bl = (i & 1) * 16 + 4 * q;
+                *(f16x4_*)(stg + (r * 32 + kbl) * 512 + (j8 * 32 + bl) * 2) =
+                    f16x4_{(f16_t)(acc[i][j][0] + bv), (f16_t)(acc[i][j][1] + bv), (f16_t)(acc[i][j][2] + bv), (f16_t)(acc[i][j][3] + bv)};
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int l16 = tid & 31, ph = tid >> 5;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int r = it >> 1, kbl = (it & 1) * 16 + ph;
+            const int m = m0 + r * 32, t = m / ep.B, g = (m - t * ep.B) >> 5;
+            const size_t blk = (((size_t)(g * ep.T + t) * 2 + d) * nkb + (jj0 >> 3) + kbl) * 4 + p;
+            const f32x4 v = *(const f32x4*)(stg + (r * 32 + kbl) * 512 + l16 * 16);
+            *(f32x4*)((f16_t*)outp + blk * 256 + l16 * 8) = v;
+        }
+        return;
+    }
     if (EPI == EPI_LSTM_GX && (ep.B & 3) == 0) {
         // gx epilogue with the index arithmetic hoisted: 4 column decompositions and 8 row decompositions per lane
         // instead of one of each per tile (the integer divisions otherwise cost as much as a short K loop)
