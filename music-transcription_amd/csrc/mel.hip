@@ -263,21 +263,27 @@ __global__ __launch_bounds__(NWAVE * 64) void mel_kernel(
             if (it + 1 < ITERS) MEL_ISSUE_LOADS(ti, it + 1);
             else MEL_ISSUE_LOADS(ti + gridDim.x, 0);
             __builtin_amdgcn_sched_barrier(0);
-            // ---- sparse mel projection + dB: lane l reduces filters l + 32 i; uniform trip counts (ELL padded to x4)
-            int row = 0;
+            // ---- sparse mel projection + dB: lane l reduces filters l + 32 i; uniform trip counts (ELL padded to x4).
+            //      The phase is a chain of dependent LDS round trips, not arithmetic: trip counts and row offsets come as
+            //      SCALAR loads from the plan (uniform loop control), and the taps of block j + 4 are requested before the
+            //      multiply-adds of block j.
             for (int i = 0; i < ngrp; ++i) {
                 const int m = l + 32 * i;
-                const int n = grp_s[i];                         // same for every lane; multiple of 4
+                const int n = grp[i], row = grp[32 + i];         // same for every lane; n a multiple of 4 (scalar loads)
                 const float* Xs = X + fstart_s[m];
                 const float* w = well_s + row * 32 + l;
                 float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-                for (int j = 0; j < n; j += 4) {
-                    const float w0 = w[j * 32], w1 = w[(j + 1) * 32], w2 = w[(j + 2) * 32], w3 = w[(j + 3) * 32];
-                    const float x0 = Xs[j], x1 = Xs[j + 1], x2 = Xs[j + 2], x3 = Xs[j + 3];
+                float w0 = w[0], w1 = w[32], w2 = w[64], w3 = w[96];
+                float x0 = Xs[0], x1 = Xs[1], x2 = Xs[2], x3 = Xs[3];
+                for (int j = 4; j < n; j += 4) {
+                    const float v0 = w[j * 32], v1 = w[(j + 1) * 32], v2 = w[(j + 2) * 32], v3 = w[(j + 3) * 32];
+                    const float y0 = Xs[j], y1 = Xs[j + 1], y2 = Xs[j + 2], y3 = Xs[j + 3];
                     a0 = fmaf(w0, x0, a0); a1 = fmaf(w1, x1, a1); a2 = fmaf(w2, x2, a2); a3 = fmaf(w3, x3, a3);
+                    w0 = v0; w1 = v1; w2 = v2; w3 = v3;
+                    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
                 }
+                a0 = fmaf(w0, x0, a0); a1 = fmaf(w1, x1, a1); a2 = fmaf(w2, x2, a2); a3 = fmaf(w3, x3, a3);
                 const float acc = (a0 + a1) + (a2 + a3);
-                row += n;
                 if (m < n_mels && f < T) {
                     vmax = fmaxf(vmax, acc);
                     // 10 log10(x) = (10 log10 2) log2(x); v_log_f32 is good to 1 ulp of log2 -> < 1e-5 dB
