@@ -662,31 +662,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- an un-overlapped pass: ONE batch in flight, so that per-kernel times are kernel efficiencies, not contention
-    one_ms = None
+    # ---- un-overlapped passes: ONE forward in flight, so that per-kernel times are kernel efficiencies, not contention:
+    #      (a) the forward shape of the timed region (C batches of 32 per forward: the kernels the headline runs),
+    #      (b) one batch of 32 per forward
+    one_ms = {}
     if rank == 0 and not args.no_sections:
-        K1 = 10
+        K1 = 8
         fused_hl = bool(net.fuse_input_projection)
         net.fuse_input_projection = False
         mode_hl = mt_model._LSTM_MODE.get(dev_index, 0)
-        mt_model._LSTM_MODE[dev_index] = 0               # one batch in flight: the agent-scope kernel
-        ev1m = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K1)]
-        ev1n = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K1)]
-        with torch.cuda.stream(streams[0]), torch.no_grad():
-            for row in ev1m + ev1n:
-                for e in row:
-                    e.record()
-            for i in range(K1 + 1):
-                ii = max(i - 1, 0)                       # (first iteration = warm-up of the un-fused path, overwritten)
-                ev1m[ii][0].record()
-                fe(wave, clamp=False, out=mel[0][:B], chunk_max=cmax[0][:B])
-                ev1m[ii][1].record()
-                net(mel[0][:B], chunk_max_power=cmax[0][:B], events=ev1n[ii])
-        torch.cuda.synchronize()
-        net.raise_on_handoff_timeout(B, T)
-        one_ms = [float(np.mean([ev1m[i][0].elapsed_time(ev1m[i][1]) for i in range(K1)]))]
-        for s_ in range(nst):
-            one_ms.append(float(np.mean([ev1n[i][s_].elapsed_time(ev1n[i][s_ + 1]) for i in range(K1)])))
+        mt_model._LSTM_MODE[dev_index] = 0               # one forward in flight: the agent-scope kernel
+        for nb in sorted({C, 1}, reverse=True):
+            n = nb * B
+            ev1m = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K1)]
+            ev1n = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K1)]
+            with torch.cuda.stream(streams[0]), torch.no_grad():
+                for row in ev1m + ev1n:
+                    for e in row:
+                        e.record()
+                for i in range(K1 + 1):
+                    ii = max(i - 1, 0)                   # (first iteration = warm-up of this shape, overwritten)
+                    ev1m[ii][0].record()
+                    fe(wave_f[:n], clamp=False, out=mel[0][:n], chunk_max=cmax[0][:n])
+                    ev1m[ii][1].record()
+                    net(mel[0][:n], chunk_max_power=cmax[0][:n], events=ev1n[ii])
+            torch.cuda.synchronize()
+            net.raise_on_handoff_timeout(n, T)
+            row = [float(np.mean([ev1m[i][0].elapsed_time(ev1m[i][1]) for i in range(K1)]))]
+            for s_ in range(nst):
+                row.append(float(np.mean([ev1n[i][s_].elapsed_time(ev1n[i][s_ + 1]) for i in range(K1)])))
+            one_ms[nb] = row
         net.fuse_input_projection = fused_hl
         mt_model._LSTM_MODE[dev_index] = mode_hl
 
@@ -699,12 +704,18 @@ def main():
             ms.append(float(np.mean([ev_net[i][s].elapsed_time(ev_net[i][s + 1]) for i in range(NF)])))
         stages_overlapped = _stage_rows(table, ms)
         dom_key_o, roofline_overlapped = _roofline_from_stages(stages_overlapped)
-        if one_ms is not None:
-            stages = _stage_rows(stage_table(B, T, N_MELS, HIDDEN, LAYERS, fused=False), one_ms)
+        stages_one_batch, roofline_one_batch = None, None
+        if one_ms:
+            stages = _stage_rows(stage_table(BF, T, N_MELS, HIDDEN, LAYERS, fused=False), one_ms[C])
+            if 1 in one_ms and C > 1:
+                stages_one_batch = _stage_rows(stage_table(B, T, N_MELS, HIDDEN, LAYERS, fused=False), one_ms[1])
+                _, roofline_one_batch = _roofline_from_stages(stages_one_batch)
+                roofline_one_batch["measured_in"] = f"un-overlapped pass of this run: one forward over ONE batch of {B} chunks in flight"
         else:
             stages = stages_overlapped
         dom_key, roofline = _roofline_from_stages(stages)
-        roofline["measured_in"] = "1-stream pass of this run (one batch in flight)" if one_ms is not None else "timed region (batches overlap)"
+        roofline["measured_in"] = (f"un-overlapped pass of this run: ONE forward of the timed region's shape ({C} batches of {B} chunks, "
+                                   f"the same kernels) in flight") if one_ms else "timed region (forwards overlap)"
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the committed
         # rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950), and the line says so
@@ -715,7 +726,7 @@ def main():
                 # (the 1-stream pass runs the agent-scope recurrence, mt::lstm_rec_kernel; the XCD-local mt::lstm_rec16_kernel of a
                 #  multi-stream headline is a different kernel)
                 hit = [v for k, v in prof.items() if ("lstm_rec_kernel" in k if dom_key == "lstm_rec" else dom_key.split("_l")[0] in k.replace("::", "_"))]
-                if hit and B == 32:
+                if hit and B == 32 and json.load(open(os.path.join(ROOT, "profiles", fname))).get("batches_per_forward", 1) == C:
                     traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
                     tsrc = f"profiles/{fname} (committed rocprofv3 --pmc passes of this command; not re-measured in this run)"
                     break
@@ -763,6 +774,7 @@ def main():
                                         f"interleaves their batch groups in one persistent launch), {NS} forwards in flight on {NS} streams",
                           "fused_input_projection": bool(net.fuse_input_projection), "lstm_mode": hl_mode},
                "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
+               "roofline_one_batch": roofline_one_batch, "stages_one_batch": stages_one_batch,
                "roofline_overlapped": roofline_overlapped, "stages_overlapped": stages_overlapped, **sections}
         print(json.dumps(out))
     if world > 1:

@@ -7,7 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, pmc, dst = os.path.join(ROOT, "gpurun_out", "refresh"), os.path.join(ROOT, "gpurun_out", "pmc"), os.path.join(ROOT, "profiles")
-names = {"default": "bench_default", "1stream": "bench_1stream", "train": "train_b16", "train_large": "train_large_b16", "large": "large_b16"}
+names = {"default": "bench_default", "1stream": "bench_1stream", "1forward": "bench_1forward", "train": "train_b16", "train_large": "train_large_b16", "large": "large_b16"}
 for k, n in names.items():
     line = os.path.join(src, f"{k}_line.json")
     if os.path.exists(line):
@@ -16,7 +16,7 @@ for k, n in names.items():
     stats = sorted(glob.glob(os.path.join(src, f"p_{k}", "*", "*_kernel_stats.csv")), key=os.path.getsize)
     if stats:                                       # (the profiler writes one file per process: the bench itself is the largest)
         shutil.copy(stats[-1], os.path.join(dst, f"{R}_{n}_kernel_stats.csv"))
-for f in ("pmc_traffic.json", "pmc_mfma_util.json"):
+for f in ("pmc_traffic.json", "pmc_mfma_util.json", "pmc_traffic_b32.json", "pmc_mfma_util_b32.json"):
     if os.path.exists(os.path.join(pmc, f)):
         shutil.copy(os.path.join(pmc, f), os.path.join(dst, f"{R}_{f}"))
 print("\n".join(sorted(os.listdir(dst))))

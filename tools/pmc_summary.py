@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/rNN_pmc_traffic.json.
 
-usage: pmc_summary.py <fetch_dir> <write_dir> <out.json> "<command string>"
+usage: pmc_summary.py <fetch_dir> <write_dir> <out.json> "<command string>" [batches per forward of that command]
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB;
 on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so streaming reads are doubled; WRITE_SIZE is exact.
@@ -30,6 +30,7 @@ def per_kernel(d, counter):
 
 def main():
     fetch_dir, write_dir, out, cmd = sys.argv[1:5]
+    bpf = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     kernels = {}
     for name in sorted(set(fe) | set(wr)):
@@ -43,7 +44,7 @@ def main():
             "WRITE_SIZE_KB_mean": w,
             "hbm_bytes_per_launch_corrected": 2.0 * f * 1024.0 + w * 1024.0,
         }
-    json.dump({"command": cmd,
+    json.dump({"command": cmd, "batches_per_forward": bpf,
                "note": "per-launch means over all launches of the kernel name; corrected = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE halves streaming reads)",
                "kernels": kernels}, open(out, "w"), indent=1)
     print("wrote", out, len(kernels), "kernels")

@@ -6,12 +6,14 @@ mkdir -p $O
 cd $R
 timeout -k 10 300 python bench.py > $O/default_line.json 2> $O/default.err
 timeout -k 10 200 python bench.py --streams 1 --cosched 1 --no-cpu-baseline --no-sections > $O/1stream_line.json 2>/dev/null
+timeout -k 10 200 python bench.py --streams 1 --cosched 4 --no-cpu-baseline --no-sections > $O/1forward_line.json 2>/dev/null
 timeout -k 10 200 python bench.py --mode train --batch 16 --steps 10 --warmup 2 > $O/train_line.json 2>/dev/null
 timeout -k 10 200 python bench.py --mode train --model cnn_rnn_large --batch 16 --steps 5 --warmup 1 > $O/train_large_line.json 2>/dev/null
 timeout -k 10 200 python bench.py --model cnn_rnn_large --batch 16 > $O/large_line.json 2>/dev/null
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_default -- python3 $R/bench.py --no-cpu-baseline > $O/p_default.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_1stream -- python3 $R/bench.py --streams 1 --cosched 1 --no-cpu-baseline --no-sections > $O/p_1stream.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_1forward -- python3 $R/bench.py --streams 1 --cosched 4 --no-cpu-baseline --no-sections > $O/p_1forward.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_train -- python3 $R/bench.py --mode train --batch 16 --steps 10 --warmup 2 > $O/p_train.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_train_large -- python3 $R/bench.py --mode train --model cnn_rnn_large --batch 16 --steps 5 --warmup 1 > $O/p_train_large.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_large -- python3 $R/bench.py --model cnn_rnn_large --batch 16 > $O/p_large.log 2>&1
