@@ -140,6 +140,45 @@ def test_lstm_layer_matches_oracle(mta, B, T, H, K, mode):
     assert torch.equal(X1[:M, :2 * H], want.bfloat16())
 
 
+@pytest.mark.parametrize("B,T,H,K", [(3, 20, 16, 64), (32, 40, 512, 1024), (96, 24, 512, 1024), (70, 11, 32, 64), (150, 9, 64, 64), (64, 36, 256, 512)])
+def test_f16_gate_preactivations_equal_the_rounded_f32_ones(mta, B, T, H, K):
+    """MT_GX_F16 (include/mt_hip.h): the projection GEMM stores W_ih x + b as f16 -- bit for bit the round-to-nearest-even of what
+    it stores as f32, in the same layout, through every epilogue (per-element, 16-B rows, the LDS-staged whole-tile path at
+    B % 32 == 0 and H % 256 == 0) -- and the recurrence fed with them (one to four interleaved batch groups, its loader wave
+    streaming 2-KB blocks) publishes exactly the h of the f32 recurrence fed with those rounded values."""
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr, DT_F16, GX_F16
+    g = torch.Generator().manual_seed(B * 7 + T * 3 + H)
+    bound = 1.0 / np.sqrt(H)
+    M = T * B
+    Mp, Np = (M + 255) // 256 * 256, (8 * H + 127) // 128 * 128
+    X = torch.zeros(Mp, K); X[:M] = torch.randn(M, K, generator=g)
+    Wp = torch.zeros(Np, K); Wp[:8 * H] = (torch.rand(8 * H, K, generator=g) * 2 - 1) * bound
+    X, Wp = X.half().cuda(), Wp.half().cuda()
+    bg = ((torch.rand(8 * H, generator=g) * 2 - 1) * bound).cuda()
+    whh = ((torch.rand(2, 4 * H, H, generator=g) * 2 - 1) * bound).contiguous().cuda()
+    n_gx = lib.mt_lstm_gx_bytes(B, T, H) // 4
+    gx32 = torch.zeros(n_gx, device="cuda")
+    gx16 = torch.zeros(n_gx, device="cuda")                        # (the f16 form fills the first half)
+    s = stream_ptr()
+    check(lib.mt_gemm_lstm_gx_dt(ptr(X), K, ptr(Wp), K, ptr(bg), ptr(gx32), B, T, H, K, DT_F16, s))
+    check(lib.mt_gemm_lstm_gx_dt(ptr(X), K, ptr(Wp), K, ptr(bg), ptr(gx16), B, T, H, K, DT_F16 | GX_F16, s))
+    torch.cuda.synchronize()
+    got16 = gx16.view(torch.float16)[:n_gx]
+    assert torch.equal(got16, gx32.half())                         # (padded batch rows: both untouched zeros)
+    assert float(gx16.view(torch.float16)[n_gx:].abs().max()) == 0.0      # nothing written past the f16 image
+    outs = []
+    for gxb, mode in ((gx32.half().float(), 0), (gx16, GX_F16)):
+        hx = torch.full((lib.mt_lstm_hx_bytes(B, T, H) // 4,), float("nan"), device="cuda")
+        sync = torch.empty(lib.mt_lstm_sync_bytes(B, H), dtype=torch.uint8, device="cuda")
+        y = torch.empty(B, T, 2 * H, device="cuda")
+        check(lib.mt_lstm_bidir_fwd_ex(ptr(gxb), ptr(whh), ptr(hx), ptr(sync), sync.numel(), B, T, H, mode, s))
+        check(lib.mt_lstm_unpack_f32(ptr(hx), ptr(y), B, T, H, s))
+        torch.cuda.synchronize()
+        assert int(sync[:4].view(torch.int32).item()) == 0, "hand-off timeout"
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all() and float(outs[0].abs().max()) > 0.01
+
+
 # ------------------------------------------------------------------ whole model
 @pytest.mark.parametrize("tag", ["small_a", "small_b"])
 def test_cnnrnn_small_vs_reference_golden(mta, golden_dir, tag):
