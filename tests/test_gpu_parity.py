@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI of libmt_hip.so) against the CPU oracle
 on the same seeded inputs, and against the committed reference-generated goldens."""
+import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -637,3 +639,28 @@ def test_oversubscribed_persistent_launches_fail_fast(mta):
         net._ws.clear()
         assert torch.equal(net(mel), ref)                                        # and the model keeps working
         net.raise_on_handoff_timeout()
+
+
+# ------------------------------------------------------------------ the driver's command
+def test_bench_line_contract(tmp_path):
+    """`python bench.py --steps K --warmup W` prints ONE JSON line with the contract's fields; K steps of 32 chunks are timed
+    whether or not K is a multiple of the batches per forward (the left-over steps run as one smaller forward)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "stages"):
+        assert k in d, k
+    assert d["steps"] == 10 and d["warmup"] == 4 and d["n_gpus"] == 1 and d["unit"] == "chunks/s" and d["value"] > 1000
+    assert abs(d["value"] - 32 * 10 / (d["ms_per_step"] * 10 / 1e3)) / d["value"] < 1e-3
+    c = d["config"]
+    assert c["batch_per_gpu"] == 32 and c["coscheduled_batches_per_forward"] == 4 and c["streams_per_gpu"] == 4 and "workload" in c
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
+    assert {"configs1_other_schedules", "configs2_large_b16", "configs3_train_b16"} <= set(d)
+    assert "error" not in d["configs2_large_b16"] and "error" not in d["configs3_train_b16"]
