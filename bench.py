@@ -633,12 +633,25 @@ def main():
             return net(mel[s][:n], chunk_max_power=cmax[s][:n], events=None if i is None else ev_net[i])
 
     log(f"rank {rank}/{world}: setup done, B={B} x {C} per forward, T={T}, {NS} streams; warmup {W}, steps {K}")
-    for j in range(max((W + C - 1) // C, NS if W else 0)):
-        forward(j)
-    if REM and W:
-        forward(0, nb=REM)                           # (its workspace shape, before the timed region)
-        forward(1)
-    torch.cuda.synchronize()
+    from music_transcription_amd._lib import MtError
+    while True:
+        try:
+            for j in range(max((W + C - 1) // C, NS if W else 0)):
+                forward(j)
+            if REM and W:
+                forward(0, nb=REM)                       # (its workspace shape, before the timed region)
+                forward(1)
+            torch.cuda.synchronize()
+            break
+        except MtError as e:
+            # the library refuses a persistent launch that could not be resident next to the ones in flight (csrc/residency.hip):
+            # run the timed region with one forward less in flight rather than not at all
+            torch.cuda.synchronize()
+            if NS == 1:
+                raise
+            NS -= 1
+            net._ws.clear()
+            log(f"{NS + 1} forwards in flight refused ({str(e)[:160]}): continuing with {NS}")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
