@@ -664,3 +664,23 @@ def test_bench_line_contract(tmp_path):
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
     assert {"configs1_other_schedules", "configs2_large_b16", "configs3_train_b16"} <= set(d)
     assert "error" not in d["configs2_large_b16"] and "error" not in d["configs3_train_b16"]
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """The driver's multi-GPU command line (torch.distributed.run, one rank per GPU, barrier + MAX of the elapsed time, rank 0
+    prints the line), rehearsed with two ranks folded onto this box's one GPU over gloo (MT_BENCH_BACKEND): `value` counts both
+    ranks' chunks."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "9", "--warmup", "2", "--streams", "1", "--cosched", "2",
+           "--no-sections", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 9 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 32 * 9 / (d["ms_per_step"] * 9 / 1e3)) / d["value"] < 1e-3
+    assert d["config"]["coscheduled_batches_per_forward"] == 2 and d["config"]["streams_per_gpu"] == 1
