@@ -39,19 +39,26 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float* __restrict__ me
             p[r][c] = in ? fmaxf(m[(size_t)f * T + tt], floor_db) : 0.0f;   // zero padding is applied after the clamp
         }
     }
+    // the two pre-pool rows of a position share every weight: one packed FMA (v_pk_fma_f32) serves both -- the kernel is bound
+    // by vector-ALU issue (576 multiply-adds per position), not by its 68 B of traffic per position
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f2_t pp[3][3][1];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) pp[kh][kw][0] = f2_t{p[kh][kw], p[kh + 1][kw]};
     unsigned packed[16];
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
-        float a0 = bias[c], a1 = bias[c];
+        f2_t a = f2_t{bias[c], bias[c]};
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const float wv = w[c * 9 + kh * 3 + kw];
-                a0 = fmaf(wv, p[kh][kw], a0);
-                a1 = fmaf(wv, p[kh + 1][kw], a1);
+                a = __builtin_elementwise_fma(f2_t{wv, wv}, pp[kh][kw][0], a);
             }
-        const float v = fmaxf(fmaxf(a0, a1), 0.0f);
+        const float v = fmaxf(fmaxf(a.x, a.y), 0.0f);
         if (c & 1) packed[c >> 1] |= ((unsigned)f32_to_h16<DT>(v)) << 16;
         else packed[c >> 1] = f32_to_h16<DT>(v);
     }
