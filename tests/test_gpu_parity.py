@@ -203,6 +203,26 @@ def test_cnnrnn_small_vs_reference_golden(mta, golden_dir, tag):
     assert flips < 0.02
 
 
+@pytest.mark.parametrize("hidden,B", [(48, 70), (64, 100), (80, 33)])
+def test_cnnrnn_odd_sizes_with_interleaved_batch_groups(mta, hidden, B):
+    """Hidden sizes that are not whole 64-wide K tiles (the layer-to-layer projections then read re-laid-out rows, not the hx
+    images) and batches of 2 - 4 batch groups with a ragged last one (the recurrence interleaves them; its padded rows carry no
+    data): against the oracle with the same rounding points, and chunk for chunk against a forward over a slice of the batch."""
+    nm, L, T = 32, 2, 24
+    sd = R.make_state_dict("cnn_rnn", nm, hidden, L, seed=hidden)
+    model = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=hidden, num_layers=L, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    x = _mel_in(B, nm, T, seed=B)
+    with torch.no_grad():
+        got = model.model(x.cuda(), check_status=True).cpu()
+        emu = R.cnnrnn_forward(sd, x, R.Opts(gemm_f16=True))
+        part = model.model(x[40:40 + 20].contiguous().cuda(), check_status=True).cpu() if B >= 60 else model.model(x[:5].contiguous().cuda(), check_status=True).cpu()
+    assert got.shape == (B, 88, T) and torch.isfinite(got).all()
+    assert (got - emu).abs().max().item() < 2e-3
+    ref_slice = got[40:60] if B >= 60 else got[:5]
+    assert (part - ref_slice).abs().max().item() < 1e-3            # (GEMM tile order differs with M: f32 summation order only)
+
+
 def test_cnnrnn_canonical_vs_reference_golden(mta, golden_dir):
     c = np.load(os.path.join(golden_dir, "canonical_models.npz"))
     for tag in ("small_937", "small_938"):
