@@ -108,6 +108,29 @@ def test_large_small_configs_vs_reference_golden(mta, golden_dir, tag):
         assert (gk - torch.from_numpy(z[f"{tag}_{k}"])).abs().max().item() < 3e-2, k   # vs the fp32 reference (bf16 operands)
 
 
+@pytest.mark.parametrize("hidden,B", [(32, 40), (64, 70)])
+def test_large_with_interleaved_batch_groups(mta, hidden, B):
+    """CNNRNNModelLarge over 2 - 3 batch groups with a ragged last one (both recurrences interleave them inside one persistent
+    launch each): against the oracle with the same rounding points, all three heads, and chunk for chunk against a forward over a
+    slice of the batch."""
+    nm, L, T = 32, 2, 24
+    sd = R.make_state_dict("cnn_rnn_large", nm, hidden, L, seed=hidden + 1)
+    model = mta.TranscriptionModel("cnn_rnn_large", n_mels=nm, hidden_size=hidden, num_layers=L, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    x = _mel_in(B, nm, T, B)
+    with torch.no_grad():
+        got = model(x.cuda(), return_all_heads=True)
+        model.model.raise_on_handoff_timeout(B, T)
+        emu = R.cnnrnn_large_forward(sd, x, return_all_heads=True, o=R.Opts(gemm_f16=True))
+        part = model(x[33:38].contiguous().cuda(), return_all_heads=True)
+        model.model.raise_on_handoff_timeout(5, T)
+    for k in ("frame", "onset", "offset"):
+        gk = got[k].cpu()
+        assert gk.shape == (B, 88, T) and torch.isfinite(gk).all()
+        assert (gk - emu[k]).abs().max().item() < 1e-2, k
+        assert (part[k].cpu() - gk[33:38]).abs().max().item() < 5e-3, k
+
+
 def test_large_variants_vs_reference_golden(mta, golden_dir):
     z = np.load(os.path.join(golden_dir, "small_models.npz"))
     x = _mel_in(2, 32, 30, 6)
