@@ -14,8 +14,8 @@
 // Decomposition.  W_hh (4H x H fp32, 4 MB at H = 512) does not fit one CU, so a direction
 // is sliced over S = H/8 workgroups; workgroup kb owns hidden units 8kb..8kb+7 (32 gate rows)
 // and keeps its 32 x H slice of W_hh in REGISTERS as MFMA A-operands for the whole sequence.
-// Per step every workgroup needs the full h_{t-1} (H x 32 batch, 64 KB at H = 512), produced
-// by all S workgroups of its direction: an all-gather through L2 per step.
+// Per step every workgroup needs the full h_{t-1} (H x 32 batch as f16: 32 KB at H = 512), produced
+// by all S workgroups of its direction: an all-gather through the memory system per step.
 //   * v_mfma_f32_32x32x16_f16 per 16-wide k-step: D[gate row][batch] += W[row][k] * h[k][batch],
 //     K split over the 4 waves, partial tiles summed through LDS;
 //   * gate rows are ordered row = 8q + 4h + p  <->  unit 2q + h, gate p, so that after the
@@ -24,9 +24,14 @@
 //   * h_t is published in the exact MFMA B-operand layout, as f16
 //     (hx[g][t][d][k-step][lane = (k half)*32 + batch][8 f16], 512 B per workgroup per
 //     step), so consumers fetch it with one 16-B load per lane per k-step;
-//   * the published blocks of ALL steps are kept: they are the layer's output, re-laid out for
-//     the next GEMM by lstm_relayout_kernel, so nothing else is stored on the critical path and
-//     no slot is ever reused (no WAR hazard between steps).
+//   * the published blocks of ALL steps are kept: they are the layer's output -- the next layer's projection GEMM and
+//     the final fc read their A tiles straight from these images (gemm.hip, AHX; lstm_relayout_kernel only where the
+//     hidden size is not whole 64-wide K tiles, and in training) -- so nothing else is stored on the critical path and
+//     no slot is ever reused (no WAR hazard between steps);
+//   * the gate pre-activations gx (f32, or f16 with MT_GX_F16) never pass through the compute waves' memory queues: a
+//     fifth wave streams them into an LDS ring by LDS-DMA (see lstm_rec_kernel);
+//   * up to four batch groups of 32 chunks share one set of workgroups and are walked round-robin inside every step
+//     (NG), so that one group's hand-off round trip is filled with the others' work.
 // Hand-off (agent-scope variant, the default).  The workgroup's 512-B block is assembled in LDS and written by ONE
 // wave as one 16-B-per-lane sc1 (write-through) store -- and that is all the producer does: there is no flag.  hx is
 // filled with the poison pattern 0xFFFFFFFF (never a hidden state: |h| < 1, and 0xFFFF is an f16 NaN) before every
@@ -133,8 +138,9 @@ __device__ __forceinline__ void vm_settle(u32x4_t& v) { asm volatile("" : "+v"(v
 // (measured at H = 512: 1.44 us per step for 32 chunks, 2.6 us for 96).
 template <int NKSW, bool TRAIN = false, bool XP = false, int NG = 1, bool G16 = false>   // NKSW: 16-wide k-steps per wave: ceil(H/16/4); G16: gx is f16
 // Register budget: without the fused projection the kernel is held to 128 registers per lane (VGPRs + AGPRs; launch bound of
-// 4 waves per SIMD) so that one of its waves shares a SIMD with the two 192-register waves of the big-tile GEMM: a GEMM of
-// another batch in flight then still gets every CU (tests/test_kernel_budget_cpu.py).
+// 4 waves per SIMD): a workgroup is five waves, so three workgroups share a CU (43 CUs per launch at H = 512) and the GEMMs of
+// other forwards in flight get the rest of the chip -- capped at two or one per CU the default schedule loses 15 %
+// (tests/test_kernel_budget_cpu.py pins the bound).
 __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void lstm_rec_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[4][64][20];       // [k-slice wave][lane][16 regs + pad]: 80-B lane stride, conflict-free b128
     __shared__ __attribute__((aligned(16))) f16_t hs[32][8];           // [batch][unit]
@@ -145,10 +151,6 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
     constexpr int GX_RING = XP ? 1 : 6;
     constexpr int GX_DMA = G16 ? 2 : 4;               // DMA instructions (1 KB each) per slot
     __shared__ __attribute__((aligned(16))) float gring[GX_RING][XP ? 4 : (G16 ? 512 : 1024)];      // (G16: 1024 f16 per slot)
-#ifdef MT_LSTM_LDS_PAD
-    __shared__ char lds_pad[MT_LSTM_LDS_PAD];                          // experiment: inflate the LDS footprint
-    if (threadIdx.x == 0) lds_pad[blockIdx.x & 1023] = 1;
-#endif
     __shared__ int abort_s;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int H = a.H, T = a.T, nkb = H >> 3, nks = H >> 4;
@@ -253,11 +255,7 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
     // slots back: they have usually landed; if not, the poison check sends the wave into the ordinary re-issue loop)
     typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
     u32x4 hq[NKSW];
-#ifdef MT_LSTM_NOPF
-    const bool pf = false;
-#else
     const bool pf = NG > 1 && ngh > 1;
-#endif
     int ring = 0;                                     // gring slot of the current (step, group) slot
     for (int s = 0; s < T; ++s) {
         const int t = d ? (T - 1 - s) : s;

@@ -17,11 +17,12 @@ def _alloc(n):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_two_recurrence_workgroups_fit_a_cu(tmp_path):
-    """A plain recurrence workgroup is five waves (4 compute + the gx loader), so one SIMD of its CU carries two of them.  Two such
-    workgroups per CU -- 64 CUs per launch at H = 512, four forwards in flight (csrc/residency.hip) -- need
-    4 x allocation <= 512 on that SIMD: every inference variant at H = 512 (NG = 1..4 interleaved batch groups, gx as f32 or f16)
-    stays within 128 registers, and none of them spills."""
+def test_three_recurrence_workgroups_fit_a_cu(tmp_path):
+    """A plain recurrence workgroup is five waves (4 compute + the gx loader).  At 128 registers a SIMD holds 4 waves, a CU 16:
+    three workgroups per CU -- 43 CUs per launch at H = 512, which is what leaves the rest of the chip to the GEMMs of the other
+    forwards in flight (csrc/residency.hip, DESIGN.md section 4: capped at two per CU the default schedule loses 15 %).  Every
+    inference variant at H = 512 (NG = 1..4 interleaved batch groups, gx as f32 or f16) stays within 128 registers, and none of
+    them spills."""
     out = tmp_path / "lstm.s"
     subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                     os.path.join(CSRC, "lstm.hip"), "-o", str(out)], check=True, capture_output=True, timeout=900)
