@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- 30 s audio chunks/s through the MI355X hot path (mel frontend + CNNRNNModel forward).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--cosched 4] [--streams 4] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch of `--batch` synthetic 30 s / 16 kHz chunks
 already resident in HBM (BASELINE.json configs[1]: CNNRNNModel (36M) inference, batch = 32):
-    waveform (B, 480000) f32 -> mt_mel_db_f32 -> conv1 -> conv2 -> 3 x (bf16 MFMA input projection
-    -> persistent fp32 bi-LSTM recurrence -> re-layout) -> fc -> logits (B, 88, 938) f32.
+    waveform (B, 480000) f32 -> mt_mel_db_f32 -> conv1 -> conv2 -> 3 x (f16 MFMA input projection
+    -> persistent bi-LSTM recurrence, f32 state) -> fc -> logits (B, 88, 938) f32.
+The K timed steps are issued `--cosched` at a time as one forward (the recurrence interleaves the batch
+groups of the co-scheduled batches inside one persistent launch), `--streams` forwards in flight.
 Chunks are independent (main.py:258-266 keeps no cross-chunk state), so N GPUs run N independent
-batches with no data-path collective (weak scaling); the only collectives are the timing barrier
+schedules with no data-path collective (weak scaling); the only collectives are the timing barrier
 and a MAX over ranks of the elapsed time.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the kernel that dominates the step, timed with HIP events on the launch stream
-                  inside the timed region (events recorded natively by mt_cnnrnn_forward_ex);
+  roofline     -- the kernel that dominates the step, timed with HIP events on the launch stream (recorded
+                  natively by mt_cnnrnn_forward_ex) in an un-overlapped pass of this run: ONE forward of the
+                  timed region's shape in flight (roofline_one_batch: one batch of 32; roofline_overlapped: the
+                  timed region itself, forwards overlapping);
   stages       -- the same for every kernel of the step;
   cpu_baseline -- the CPU oracle (a port of the reference path, oracle/*.py) timed on this node's
-                  host cores on a bounded sample of the same workload, rank 0, N = 1 only.
+                  host cores on a bounded sample of the same workload (batch 1 and batch 8), rank 0, N = 1 only;
+  configs1_other_schedules, configs2_large_b16, configs3_train_b16 -- the neighbouring BASELINE configs and
+                  schedules, each with its own throughput / roofline / cpu_baseline.
 """
 import argparse
 import json
