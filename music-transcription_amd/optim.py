@@ -48,6 +48,59 @@ def allreduce_mean_(flat_grads: torch.Tensor) -> torch.Tensor:
     return flat_grads
 
 
+class EarlyBucket:
+    """Data-parallel overlap of the gradient all-reduce with the backward pass (the reference has none: single GPU).  The
+    training step's backward produces the gradients top-down -- fc, then the LSTM layers L-1 .. 1, then layer 0 and the
+    convolutions -- and parameters sit in the flat buffer in model order, so the gradients of [LSTM layers >= 1, fc] are one
+    contiguous TAIL of the flat gradient, complete while layer 0's backward recurrence (the longest kernel of the step), its
+    84-MB weight-gradient GEMM and the convolution backward still run.  `reduce_early` folds those gradients into the flat buffer
+    on the stream that produced them and starts their all-reduce on a communication stream; FusedAdamClip.step() then reduces
+    only the head of the buffer and waits for the tail's.  Used by train_step.backward_train when the optimizer attached one
+    to the model (world size > 1)."""
+
+    def __init__(self, flat_grads: torch.Tensor, named_views):
+        self.g = flat_grads
+        self.where = {name: (o, k, p) for name, (p, o, k) in named_views.items()}
+        self.comm = torch.cuda.Stream(device=flat_grads.device)
+        self.pending = None                       # (start, end, work, event) of the tail reduce in flight
+        self.early_params = set()
+
+    def reduce_early(self, grads: dict, stream) -> set:
+        """grads: name -> gradient tensor (complete in `stream`'s order).  Returns the names taken over (their gradient now lives
+        in the flat buffer; autograd must be given None for them).  Nothing is taken unless the names form the buffer's tail."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or self.pending is not None:
+            return set()
+        items = [(self.where[n], t) for n, t in grads.items() if n in self.where and t is not None]
+        if not items:
+            return set()
+        start = min(o for (o, k, p), _ in items)
+        if sum(k for (o, k, p), _ in items) != self.g.numel() - start:
+            return set()                          # not a contiguous tail of the flat buffer: leave everything to step()
+        with torch.cuda.stream(stream):
+            for (o, k, p), t in items:
+                self.g[o:o + k].add_(t.reshape(-1))            # accumulate, as autograd would have
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ev)
+            work = dist.all_reduce(self.g[start:], op=dist.ReduceOp.SUM, async_op=True)
+            done = torch.cuda.Event()
+            done.record(self.comm)
+        self.pending = (start, work, done)
+        self.early_params = {id(p) for (o, k, p), _ in items}
+        return {n for n in grads if n in self.where and grads[n] is not None}
+
+    def finish(self, stream) -> int:
+        """Wait (in `stream`'s order) for the tail reduce; returns where the un-reduced head ends (numel if nothing was early)."""
+        if self.pending is None:
+            return self.g.numel()
+        start, work, done = self.pending
+        work.wait()
+        stream.wait_event(done)
+        self.pending = None
+        return start
+
+
 class FusedAdamClip:
     """clip_grad_norm_ + Adam (coupled L2) in libmt_hip.so over flat buffers.  step() returns a (2,) device tensor
     {grad norm before clipping, 1.0 if the step was taken / 0.0 if skipped for a non-finite norm}: no host sync."""
@@ -63,6 +116,7 @@ class FusedAdamClip:
         self._views = getattr(flat_grads, "_mt_views", None)
         self.ws = torch.empty(lib.mt_adam_workspace_bytes(), dtype=torch.uint8, device=flat_params.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=flat_params.device)
+        self.early = None                 # EarlyBucket, attached by train.make_optimizer for data-parallel runs
 
     def zero_grad(self):
         self.g.zero_()
@@ -76,7 +130,9 @@ class FusedAdamClip:
         base = self.g.data_ptr()
         for p, o, k in self._views:
             view = self.g[o:o + k].view_as(p)
-            if p.grad is None:
+            if p.grad is None and self.early is not None and id(p) in self.early.early_params:
+                pass                                  # its gradient already sits (reduced) in the flat buffer
+            elif p.grad is None:
                 view.zero_()
             elif p.grad.data_ptr() != base + 4 * o:
                 view.copy_(p.grad)
@@ -92,7 +148,15 @@ class FusedAdamClip:
     def step(self, sync_grads: bool = True):
         self._reattach_grad_views()
         if sync_grads:
-            allreduce_mean_(self.g)
+            if self.early is not None:
+                head = self.early.finish(torch.cuda.current_stream(self.g.device))      # the tail was reduced under the backward pass
+                self.early.early_params = set()
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    if head > 0:
+                        dist.all_reduce(self.g[:head], op=dist.ReduceOp.SUM)
+                    self.g.div_(dist.get_world_size())
+            else:
+                allreduce_mean_(self.g)
         self.t += 1
         with torch.cuda.device(self.p.device):
             check(lib.mt_adam_clip_step(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), self.p.numel(), self.lr, self.betas[0],

@@ -10,12 +10,13 @@ gradient is all-reduced (mean) over RCCL before the clip -- the data-parallel st
 from __future__ import annotations
 
 import math
+import os
 from typing import Iterable, List, Tuple
 
 import torch
 import torch.distributed as dist
 
-from .optim import FusedAdamClip, flatten_parameters
+from .optim import EarlyBucket, FusedAdamClip, flatten_parameters
 
 
 def _world_size() -> int:
@@ -27,7 +28,15 @@ def make_optimizer(model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-
     """optim.Adam(model.parameters(), lr, eps=1e-8, weight_decay=1e-5) of scripts/train_cnn.py:290, fused with
     clip_grad_norm_ (train_transcriber.py:134).  Parameters become views of one flat buffer."""
     flat, grads = flatten_parameters(model.parameters())
-    return FusedAdamClip(flat, grads, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_grad_norm)
+    opt = FusedAdamClip(flat, grads, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_grad_norm)
+    if _world_size() > 1 and os.environ.get("MT_DP_EARLY_BUCKET", "1") != "0":
+        # data parallel: the gradients of the upper LSTM layers and the fc are all-reduced under the rest of the backward pass
+        net = getattr(model, "model", model)
+        by_id = {id(p): (p, o, k) for p, o, k in grads._mt_views}
+        named = {n: by_id[id(p)] for n, p in net.named_parameters() if id(p) in by_id}
+        opt.early = EarlyBucket(grads, named)
+        net._grad_sync = opt.early
+    return opt
 
 
 def train_one_epoch(model, dataloader: Iterable, optimizer: FusedAdamClip, device, max_grad_norm: float = 1.0,

@@ -371,6 +371,14 @@ def backward_train(model, sv, dlogits: torch.Tensor, debug: dict = None) -> Dict
                     _gather4(gb, di * 4 * Hp, bb2, (1, 1, 4, H), (0, 0, Hp, 1))
                     g[f"rnn.weight_ih_l{l}{suf}"], g[f"rnn.weight_hh_l{l}{suf}"] = wi, wh
                     g[f"rnn.bias_ih_l{l}{suf}"], g[f"rnn.bias_hh_l{l}{suf}"] = bb, bb2
+            if l == 1 and getattr(model, "_grad_sync", None) is not None:
+                # data parallel: everything above layer 0 (LSTM layers >= 1 and the fc: the tail of the flat gradient) is complete
+                # in the side stream's order -- its all-reduce starts now, under layer 0's recurrence, weight-gradient GEMM and the
+                # convolution backward (optim.EarlyBucket)
+                early = {k: v for k, v in g.items() if k.startswith("fc.") or (k.startswith("rnn.") and not k.split("_l")[-1].startswith("0"))}
+                for k in model._grad_sync.reduce_early(early, side):
+                    keep.append(g[k])                    # (read on the side stream: stays referenced until the streams have joined)
+                    g[k] = None
         # ---- conv2: BN + ReLU + pool backward, dgrad (flipped-weight conv), wgrad (split-K GEMM over positions)
         sums = torch.zeros(512, device=dev, dtype=torch.float64)
         dz2, dz2lo = torch.empty(Npos, 64, **bf), torch.empty(Npos, 64, **bf)

@@ -393,19 +393,26 @@ def test_preprocess_and_cache_end_to_end(mta, tmp_path):
 
 def test_data_parallel_training_two_ranks(mta):
     """Two ranks (torch.distributed.run, gloo between processes that share this box's GPU), different data per rank:
-    after three steps of all-reduce(mean) + fused clip/Adam every rank holds bit-identical parameters."""
+    after three steps of all-reduce(mean) + fused clip/Adam every rank holds bit-identical parameters -- the same ones whether the
+    gradients of the upper LSTM layers and the fc are reduced early, under the rest of the backward pass, or all at once."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29533", os.path.join(root, "tests", "tools", "dp_check.py")], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
-    assert out["world"] == 2 and out["identical_parameters"], out
-    assert all(np.isfinite(out["losses_rank0"])) and len(out["losses_rank0"]) == 3
+    outs = {}
+    for early in ("1", "0"):          # with the tail of the flat gradient all-reduced under the backward pass (optim.EarlyBucket), and without
+        env = dict(os.environ, MT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MT_DP_EARLY_BUCKET=early)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29533", os.path.join(root, "tests", "tools", "dp_check.py")], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["world"] == 2 and out["identical_parameters"], out
+        assert all(np.isfinite(out["losses_rank0"])) and len(out["losses_rank0"]) == 3
+        outs[early] = out
+    assert outs["1"]["early_bucket_reduces"] == 3 and outs["0"]["early_bucket_reduces"] == 0
+    # the same sums in a different order of collectives: identical parameters
+    assert outs["1"]["checksum"] == outs["0"]["checksum"] and outs["1"]["losses_rank0"] == outs["0"]["losses_rank0"]
 
 
 def test_full_size_training_step_configs3(mta):

@@ -31,6 +31,14 @@ for _ in range(3):
     mel = torch.rand(B, 1, nm, T, generator=g) * 60.0 - 70.0
     roll = (torch.rand(B, 88, T, generator=g) < 0.1).float()
     batches.append((mel, roll, torch.tensor([T, T - 5, T - 11])))
+n_early = [0]
+if opt.early is not None:                                           # count the early reduces actually taken
+    _orig = opt.early.reduce_early
+    def _counting(grads, stream):
+        took = _orig(grads, stream)
+        n_early[0] += 1 if took else 0
+        return took
+    opt.early.reduce_early = _counting
 avg, losses = mta.train_one_epoch(model, batches, opt, dev)
 flat = torch.cat([p.detach().reshape(-1).double() for p in model.parameters()])
 mine = torch.tensor([flat.sum().item(), flat.abs().sum().item(), (flat * torch.arange(flat.numel(), device=dev)).sum().item()], dtype=torch.float64)
@@ -40,5 +48,6 @@ allv = [torch.zeros(3, dtype=torch.float64, device=where) for _ in range(world)]
 dist.all_gather(allv, mine)
 if rank == 0:
     same = all(torch.equal(allv[0].cpu(), v.cpu()) for v in allv)
-    print(json.dumps({"world": world, "identical_parameters": bool(same), "losses_rank0": losses, "checksum": allv[0].tolist()}))
+    print(json.dumps({"world": world, "identical_parameters": bool(same), "losses_rank0": losses, "checksum": allv[0].tolist(),
+                      "early_bucket_reduces": n_early[0]}))
 dist.destroy_process_group()
