@@ -14,4 +14,4 @@ from .optim import FusedAdamClip, flatten_parameters, allreduce_mean_           
 from .train import make_optimizer, train_one_epoch                                            # noqa: F401  (train.evaluate = validation loss)
 from .data import CachedMaestroDataset, collate_fn, write_cache_chunk, write_cache_metadata   # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -12,7 +12,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace mt
 
-extern "C" int mt_version(void) { return 100; }
+extern "C" int mt_version(void) { return 200; }
 extern "C" const char* mt_last_error(void) { return mt::g_err; }
 extern "C" int mt_device_count(void) {
     int n = 0;
