@@ -13,9 +13,11 @@ for k, n in names.items():
     if os.path.exists(line):
         txt = [l for l in open(line).read().strip().splitlines() if l.startswith("{")]
         open(os.path.join(dst, f"{R}_{n}_line.json"), "w").write(txt[-1] + "\n")
-    stats = sorted(glob.glob(os.path.join(src, f"p_{k}", "*", "*_kernel_stats.csv")), key=os.path.getsize)
-    if stats:                                       # (the profiler writes one file per process: the bench itself is the largest)
-        shutil.copy(stats[-1], os.path.join(dst, f"{R}_{n}_kernel_stats.csv"))
+    stats = glob.glob(os.path.join(src, f"p_{k}", "*", "*_kernel_stats.csv"))
+    if stats:                                       # (one file per process: of the latest run's files the bench itself is the largest)
+        newest = max(os.path.getmtime(f) for f in stats)
+        latest = [f for f in stats if newest - os.path.getmtime(f) < 300]
+        shutil.copy(max(latest, key=os.path.getsize), os.path.join(dst, f"{R}_{n}_kernel_stats.csv"))
 for f in ("pmc_traffic.json", "pmc_mfma_util.json", "pmc_traffic_b32.json", "pmc_mfma_util_b32.json"):
     if os.path.exists(os.path.join(pmc, f)):
         shutil.copy(os.path.join(pmc, f), os.path.join(dst, f"{R}_{f}"))
