@@ -438,10 +438,16 @@ def section_large(mta, dev, cores, do_cpu):
     except Exception as e:
         torch.cuda.synchronize()
         cos = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
-    sec = {"workload": "CNNRNNModelLarge inference, batch=16 (BASELINE.json configs[2])", "value": round(B * K / el, 2), "unit": "chunks/s",
-           "coscheduled_4_batches_per_forward": cos,
-           "ms_per_step": round(1e3 * el / K, 3), "steps": K, "streams_per_gpu": NS, "dtype": "f16 MFMA operands, f32 accumulate / LSTM state",
-           "model_tflops_per_s": round(326.47e9 * B * T / 938.0 * K / el / 1e12, 1), "one_stream_ms_per_step": round(sum(ms), 3),
+    one = {"value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_step": round(1e3 * el / K, 3), "steps": K, "streams_per_gpu": NS}
+    best = cos if (cos and "value" in cos and cos["value"] > one["value"]) else None
+    sec = {"workload": "CNNRNNModelLarge inference, batch=16 (BASELINE.json configs[2]); a step = one batch of 16 chunks",
+           "value": best["value"] if best else one["value"], "unit": "chunks/s",
+           "ms_per_step": best["ms_per_step"] if best else one["ms_per_step"],
+           "scheduling": (f"{best['coscheduled_batches_per_forward']} steps per forward (two batch groups of 32 interleaved in each persistent recurrence "
+                          f"launch), {NS} forwards in flight") if best else f"one step per forward, {NS} forwards in flight",
+           "one_batch_per_forward": one, "coscheduled_4_batches_per_forward": cos,
+           "dtype": "f16 MFMA operands, f32 accumulate / LSTM state",
+           "model_tflops_per_s": round(326.47e9 * T / 938.0 * (best["value"] if best else one["value"]) / 1e12, 1), "one_stream_ms_per_step": round(sum(ms), 3),
            "roofline": roof, "stages_one_stream": stages, "finite": bool(torch.isfinite(out).all())}
     if do_cpu:
         from oracle import frontend_ref, model_ref

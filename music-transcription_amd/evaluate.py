@@ -28,7 +28,7 @@ def _f1(tp, fp, fn) -> float:
 
 
 @torch.no_grad()
-def collect_logits(model, dataset, indices: Sequence[int], device="cuda", max_batch: int = 32):
+def collect_logits(model, dataset, indices: Sequence[int], device="cuda", max_batch: int = 128):
     """Forward every sample once; returns [(index, logits (88, T) on device, roll (88, T) on device)]."""
     by_len = defaultdict(list)
     for i in indices:

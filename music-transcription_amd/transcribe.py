@@ -162,7 +162,7 @@ def notes_from_logits_device(logits: torch.Tensor, threshold: float = THRESHOLD,
 
 
 @torch.no_grad()
-def transcribe_chunks_to_notes(model: "TranscriptionModel", chunks, threshold: float = THRESHOLD, batch: int = 32, n_mels: int = N_MELS,
+def transcribe_chunks_to_notes(model: "TranscriptionModel", chunks, threshold: float = THRESHOLD, batch: int = 128, n_mels: int = N_MELS,
                                device: str = "cuda") -> List[Tuple[int, float, float]]:
     """(n, 480000) waveform chunks -> notes; mel, forward, threshold, concatenation and run-length all on the GPU."""
     fe = get_frontend(SR, n_mels, HOP_LENGTH, device)
@@ -222,7 +222,7 @@ def load_model(model_path: str, device: str = "cuda", model_type: str = MODEL_TY
 
 
 @torch.no_grad()
-def transcribe_chunks(model: TranscriptionModel, chunks, threshold: float = THRESHOLD, batch: int = 32,
+def transcribe_chunks(model: TranscriptionModel, chunks, threshold: float = THRESHOLD, batch: int = 128,
                       n_mels: int = N_MELS, device: str = "cuda") -> np.ndarray:
     """(n, 480000) waveform chunks (device tensor, or numpy) -> (88, n * T) {0,1} roll; mel + forward + threshold all on the GPU."""
     fe = get_frontend(SR, n_mels, HOP_LENGTH, device)
