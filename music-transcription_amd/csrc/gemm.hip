@@ -48,7 +48,7 @@ struct GemmEpi {
     // row-major rows -- row m = t*aB + b, column k = dir*aH + unit -- so no re-layout pass sits between the layers (f16 operands)
     int aB, aT, aH;
     // EPI_LSTM_GX: store the gate pre-activations as f16 (same layout, half the bytes: inference; the recurrence's loader wave
-    // streams them and the cell update adds them in f32); 2 = the same with non-temporal stores
+    // streams them and the cell update adds them in f32)
     int gx16;
 };
 
@@ -311,9 +311,9 @@ constexpr int G256_LDS = 2 * (BM2 + BN2) * BK * 2;
 // run one barrier ahead of the upper half's and a SIMD holds one wave of each half, so while one is in its MFMA block
 // the other fetches its fragments.  The next tile's DMA is issued in phases 0-1 (two phases old when phase 3 waits for
 // it); each phase retires its own fragment reads before its first barrier, so a buffer is never restaged while a
-// lagging wave still reads it.  (Two phases of 32 MFMAs per K-tile: equal at K = 5120, 5 % faster at K = 1024 alone, but 202 VGPRs.  The
-// kernel is kept within 192 -- 2 waves x 192 + one 120-VGPR wave of a plain recurrence workgroup fill a SIMD's 512 -- so that
-// it can share a CU with a resident recurrence of another batch in flight; tests/test_kernel_budget_cpu.py guards the count.)
+// lagging wave still reads it.  (Two phases of 32 MFMAs per K-tile, re-measured in round 2 with the gx16 epilogue: 0 ... 4 % at K = 1024, nothing
+// at K = 5120: not kept.  The kernel's 128 KB of LDS leave no room for a second workgroup or a recurrence workgroup on its CU, so its
+// register count -- 200 with the epilogue's bias values held through the main loop -- is not a co-residency matter any more.)
 // A wave's 128 x 64 outputs are 8 x 4 tiles of 16 x 16 (C: column = lane & 15,
 // rows 4 (lane >> 4) + j); fragment reads stay conflict-free under the same swizzle (lane = row & 15, 16-B chunk
 // 4 ks + (lane >> 4)).
@@ -527,10 +527,7 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict_
             const int m = m0 + r * 32, t = m / ep.B, g = (m - t * ep.B) >> 5;
             const size_t blk = (((size_t)(g * ep.T + t) * 2 + d) * nkb + (jj0 >> 3) + kbl) * 4 + p;
             const f32x4 v = *(const f32x4*)(stg + (r * 32 + kbl) * 512 + l16 * 16);
-            // (an output larger than the caches -- several co-scheduled batches -- streams past them: non-temporal stores, K = 1024 at
-            //  M = 120 064: 1.05 -> 0.96 ms; at M = 30 016 the plain store is the faster one by 3 %)
-            if (ep.gx16 > 1) __builtin_nontemporal_store(v, (f32x4*)((f16_t*)outp + blk * 256 + l16 * 8));
-            else *(f32x4*)((f16_t*)outp + blk * 256 + l16 * 8) = v;
+            *(f32x4*)((f16_t*)outp + blk * 256 + l16 * 8) = v;
         }
         return;
     }
@@ -701,7 +698,7 @@ extern "C" int mt_gemm_lstm_gx_dt(const void* X, int ldx, const void* W_ih, int 
     MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx: bias is required (b_ih + b_hh)");
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx: bad dims B=%d T=%d H=%d", B, T, H);
     GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1};
-    ep.gx16 = (dt & MT_GX_F16) ? ((size_t)T * B * 8 * H * 2 > ((size_t)400 << 20) ? 2 : 1) : 0;      // 2: larger than the caches
+    ep.gx16 = (dt & MT_GX_F16) ? 1 : 0;
     return launch(EPI_LSTM_GX, dt & ~MT_GX_F16, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream);
 }
 extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
@@ -716,7 +713,7 @@ extern "C" int mt_gemm_lstm_gx_from_hx_ex(const float* hx_prev, const void* W_ih
     MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx_from_hx: bias is required (b_ih + b_hh)");
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx_from_hx: bad dims B=%d T=%d H=%d", B, T, H);
     GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0.0f, 0, 0, B, T, Hprev};
-    ep.gx16 = gx_f16 ? ((size_t)T * B * 8 * H * 2 > ((size_t)400 << 20) ? 2 : 1) : 0;
+    ep.gx16 = gx_f16 ? 1 : 0;
     return launch_hx(EPI_LSTM_GX, hx_prev, W_ih, ldw, T * B, 8 * H, ep, (hipStream_t)stream);
 }
 extern "C" int mt_gemm_lstm_gx_from_hx(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
