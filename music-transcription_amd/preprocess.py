@@ -62,8 +62,15 @@ def read_maestro_csv(root_dir: str, split: Optional[str] = None, year=None, subs
 
 
 def wav_duration(path: str) -> float:
-    """Duration from the header (librosa.get_duration(path=...)): frames / native rate."""
+    """Duration from the header (librosa.get_duration(path=...)): frames / native rate.  A missing `.wav` falls back to the `.mp3`
+    beside it (data/dataset.py:68-70), whose duration comes from a host decode (transcribe.decode_compressed_host)."""
     import wave
+    from .transcribe import decode_compressed_host, resolve_audio_path
+    path = resolve_audio_path(path)
+    with open(path, "rb") as fh:
+        if fh.read(4) not in (b"RIFF", b"RIFX", b"RF64"):
+            rate, data = decode_compressed_host(path)
+            return data.shape[0] / float(rate)
     try:
         with wave.open(path, "rb") as w:
             return w.getnframes() / float(w.getframerate())

@@ -60,16 +60,66 @@ def resample_plan(rate_in: int, rate_out: int, n_in: int):
 _PLAN_FILTERS = {}
 
 
+def resolve_audio_path(path: str) -> str:
+    """The reference's fallback for corpora distributed as mp3 (data/dataset.py:68-70,:119-121,:175-177): a missing `x.wav` is
+    looked up as `x.mp3`."""
+    if not os.path.exists(path) and path.endswith(".wav") and os.path.exists(path[:-4] + ".mp3"):
+        return path[:-4] + ".mp3"
+    return path
+
+
+def decode_compressed_host(path: str):
+    """Compressed audio (mp3 / flac / ogg ...) -> (sample rate, (frames, channels) float32 / int16 PCM) on the host, through
+    whichever decoder is installed -- soundfile, audioread (what librosa.load falls back to, main.py:76), torchaudio; none of them
+    ships in this image, where the call raises.  The PCM then takes the same path as a WAV file: one H2D copy, channel mean and
+    polyphase resampling on the GPU (csrc/resample.hip)."""
+    errors = []
+    try:
+        import soundfile
+        data, rate = soundfile.read(path, dtype="float32", always_2d=True)
+        return int(rate), np.ascontiguousarray(data, dtype=np.float32)
+    except ImportError as e:
+        errors.append(f"soundfile: {e}")
+    except Exception as e:                                  # (libsndfile builds without mp3 support)
+        errors.append(f"soundfile: {e}")
+    try:
+        import audioread
+        with audioread.audio_open(path) as f:
+            rate, ch = int(f.samplerate), int(f.channels)
+            pcm = np.frombuffer(b"".join(f), dtype="<i2")
+        return rate, np.ascontiguousarray(pcm.reshape(-1, ch))
+    except ImportError as e:
+        errors.append(f"audioread: {e}")
+    except Exception as e:
+        errors.append(f"audioread: {e}")
+    try:
+        import torchaudio
+        wav, rate = torchaudio.load(path)                   # (channels, frames) float32
+        return int(rate), np.ascontiguousarray(wav.t().numpy(), dtype=np.float32)
+    except ImportError as e:
+        errors.append(f"torchaudio: {e}")
+    except Exception as e:
+        errors.append(f"torchaudio: {e}")
+    raise ValueError(f"{path}: not a WAV file and no host decoder could read it ({'; '.join(errors)})")
+
+
 def load_audio_device(path: str, sr: int = SR, device="cuda") -> torch.Tensor:
-    """WAV file -> mono float32 at `sr` ON THE DEVICE (librosa.load(path, sr=sr, mono=True) of main.py:76): the PCM frames
+    """Audio file -> mono float32 at `sr` ON THE DEVICE (librosa.load(path, sr=sr, mono=True) of main.py:76): the PCM frames
     go to the GPU as they are (memory-mapped read, one H2D copy) and csrc/resample.hip does the channel mean, the PCM
-    scaling and the polyphase resampling.  WAV only (PCM 16/24/32-bit or float32); not soxr-exact."""
+    scaling and the polyphase resampling.  WAV (PCM 8/16/24/32-bit or float32) is read directly; anything else goes through
+    decode_compressed_host; a missing `.wav` falls back to the `.mp3` beside it as the reference does.  Not soxr-exact."""
     from scipy.io import wavfile
     from . import _lib
-    try:
-        rate, data = wavfile.read(path, mmap=True)
-    except ValueError as e:
-        raise ValueError(f"{path}: only WAV input is supported in this build ({e})")
+    path = resolve_audio_path(path)
+    with open(path, "rb") as fh:
+        is_wav = fh.read(4) in (b"RIFF", b"RIFX", b"RF64")
+    if is_wav:
+        try:
+            rate, data = wavfile.read(path, mmap=True)
+        except ValueError as e:
+            raise ValueError(f"{path}: unreadable WAV file ({e})")
+    else:
+        rate, data = decode_compressed_host(path)
     if data.ndim == 1:
         data = data[:, None]
     if data.dtype == np.int16:

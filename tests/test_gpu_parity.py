@@ -704,3 +704,21 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 9 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 32 * 9 / (d["ms_per_step"] * 9 / 1e3)) / d["value"] < 1e-3
     assert d["config"]["coscheduled_batches_per_forward"] == 2 and d["config"]["streams_per_gpu"] == 1
+
+
+def test_compressed_audio_takes_the_wav_device_path(mta, tmp_path, monkeypatch):
+    """A file that is not a WAV container is decoded on the host (stub decoder: none ships in this image) and then resampled on the
+    GPU exactly like the WAV holding the same PCM (channel mean + polyphase resampling, csrc/resample.hip)."""
+    import types
+    from scipy.io import wavfile
+    from music_transcription_amd import transcribe as tr
+    w = FR.synth_audio(1, 44100 * 2, seed=9, sr=44100)[0]
+    pcm = np.stack([w, 0.25 * w], 1).astype(np.float32)
+    wavfile.write(str(tmp_path / "a.wav"), 44100, pcm)
+    (tmp_path / "b.mp3").write_bytes(b"ID3\x03" + bytes(128))
+    stub = types.ModuleType("soundfile")
+    stub.read = lambda path, dtype="float32", always_2d=True: (pcm, 44100)
+    monkeypatch.setitem(sys.modules, "soundfile", stub)
+    ya = tr.load_audio_device(str(tmp_path / "a.wav"), 16000, "cuda")
+    yb = tr.load_audio_device(str(tmp_path / "b.wav"), 16000, "cuda")          # (missing .wav -> the .mp3 beside it)
+    assert ya.shape == yb.shape and ya.numel() == 32000 and torch.equal(ya, yb) and float(ya.abs().max()) > 0.01

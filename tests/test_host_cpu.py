@@ -267,3 +267,27 @@ def test_two_rank_gloo_gradient_mean(tmp_path, mta):
     outs = [p.communicate(timeout=180) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2000:]
+
+
+def test_compressed_audio_goes_through_a_host_decoder(mta, tmp_path, monkeypatch):
+    """data/dataset.py:68-70: a missing x.wav is looked up as x.mp3; anything that is not a WAV container is decoded on the host by
+    whichever decoder is installed (none in this image: a stub stands in for `soundfile`), and without one the error says so."""
+    import sys
+    import types
+    from music_transcription_amd import transcribe as tr
+    from music_transcription_amd import preprocess as pp
+    mp3 = tmp_path / "rec.mp3"
+    mp3.write_bytes(b"ID3\x03" + bytes(64))
+    assert tr.resolve_audio_path(str(tmp_path / "rec.wav")) == str(mp3)
+    assert tr.resolve_audio_path(str(tmp_path / "other.wav")) == str(tmp_path / "other.wav")
+    for name in ("soundfile", "audioread", "torchaudio"):
+        monkeypatch.setitem(sys.modules, name, None)              # import -> ImportError
+    with pytest.raises(ValueError, match="no host decoder"):
+        tr.decode_compressed_host(str(mp3))
+    pcm = (np.arange(44100 * 2, dtype=np.float32).reshape(-1, 2) % 7) / 7.0
+    stub = types.ModuleType("soundfile")
+    stub.read = lambda path, dtype="float32", always_2d=True: (pcm, 44100)
+    monkeypatch.setitem(sys.modules, "soundfile", stub)
+    rate, data = tr.decode_compressed_host(str(mp3))
+    assert rate == 44100 and data.shape == (44100, 2) and data.dtype == np.float32
+    assert abs(pp.wav_duration(str(tmp_path / "rec.wav")) - 1.0) < 1e-9          # through the .wav -> .mp3 fallback
