@@ -697,26 +697,31 @@ def main():
         net.fuse_input_projection = False
         mode_hl = mt_model._LSTM_MODE.get(dev_index, 0)
         mt_model._LSTM_MODE[dev_index] = 0               # one forward in flight: the agent-scope kernel
-        for nb in sorted({C, 1}, reverse=True):
-            n = nb * B
-            ev1m = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K1)]
-            ev1n = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K1)]
-            with torch.cuda.stream(streams[0]), torch.no_grad():
-                for row in ev1m + ev1n:
-                    for e in row:
-                        e.record()
-                for i in range(K1 + 1):
-                    ii = max(i - 1, 0)                   # (first iteration = warm-up of this shape, overwritten)
-                    ev1m[ii][0].record()
-                    fe(wave_f[:n], clamp=False, out=mel[0][:n], chunk_max=cmax[0][:n])
-                    ev1m[ii][1].record()
-                    net(mel[0][:n], chunk_max_power=cmax[0][:n], events=ev1n[ii])
+        try:
+            for nb in sorted({C, 1}, reverse=True):
+                n = nb * B
+                ev1m = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(K1)]
+                ev1n = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(K1)]
+                with torch.cuda.stream(streams[0]), torch.no_grad():
+                    for row in ev1m + ev1n:
+                        for e in row:
+                            e.record()
+                    for i in range(K1 + 1):
+                        ii = max(i - 1, 0)                   # (first iteration = warm-up of this shape, overwritten)
+                        ev1m[ii][0].record()
+                        fe(wave_f[:n], clamp=False, out=mel[0][:n], chunk_max=cmax[0][:n])
+                        ev1m[ii][1].record()
+                        net(mel[0][:n], chunk_max_power=cmax[0][:n], events=ev1n[ii])
+                torch.cuda.synchronize()
+                net.raise_on_handoff_timeout(n, T)
+                row = [float(np.mean([ev1m[i][0].elapsed_time(ev1m[i][1]) for i in range(K1)]))]
+                for s_ in range(nst):
+                    row.append(float(np.mean([ev1n[i][s_].elapsed_time(ev1n[i][s_ + 1]) for i in range(K1)])))
+                one_ms[nb] = row
+        except Exception as e:                          # the headline line must not depend on these passes
             torch.cuda.synchronize()
-            net.raise_on_handoff_timeout(n, T)
-            row = [float(np.mean([ev1m[i][0].elapsed_time(ev1m[i][1]) for i in range(K1)]))]
-            for s_ in range(nst):
-                row.append(float(np.mean([ev1n[i][s_].elapsed_time(ev1n[i][s_ + 1]) for i in range(K1)])))
-            one_ms[nb] = row
+            log(f"un-overlapped passes failed ({type(e).__name__}: {str(e)[:200]}): stages fall back to the timed region's")
+            one_ms = {}
         net.fuse_input_projection = fused_hl
         mt_model._LSTM_MODE[dev_index] = mode_hl
 
@@ -763,7 +768,10 @@ def main():
         cpu = None
         cores = host_cores()
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline_small(model, wave, logits[:B], cores)
+            try:
+                cpu = cpu_baseline_small(model, wave, logits[:B], cores)
+            except Exception as e:                      # (reported, never fatal for the line)
+                cpu = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         sections = {}
         if world == 1 and not args.no_sections:
             mt_model._LSTM_MODE[dev_index] = 0           # the sections below run the agent-scope recurrence
