@@ -353,11 +353,20 @@ int    mt_roll_to_notes(const float* src, int src_mode, float threshold, int NB,
  * clip_grad_norm_(max_norm) + torch.optim.Adam with coupled L2 weight decay over flat f32 buffers
  * (train_transcriber.py:134-144, train_cnn.py:290); a NaN/Inf gradient norm skips the step (:137-142).
  * step = 1-based step count.  stats (2 floats, may be NULL) = {norm before clipping, 1 if stepped else 0}.
- * With data parallelism, all-reduce (mean) `grads` over RCCL before calling this.                         */
+ * With data parallelism, all-reduce `grads` over RCCL before calling this: the mean, or (_ex) the SUM with
+ * grad_scale = 1 / world -- the scale is applied on the fly in the norm and in the update, `grads` is not written.
+ * _ex, keep_ranges: HOST array of n_keep <= 16 ascending disjoint [lo, hi) element ranges (NULL / 0 = everything).
+ * Only those elements are counted in the norm, clipped and updated; the rest keep params and moments -- torch's
+ * behaviour for parameters whose .grad is None (the onset / offset heads under the reference's frame-only loss,
+ * train_transcriber.py:119 + cnn_rnn_model.py:343-349: no weight decay, no moment update).                  */
 size_t mt_adam_workspace_bytes(void);
 int    mt_adam_clip_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                          float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                          int step, float* stats, void* workspace, size_t workspace_bytes, mt_stream_t stream);
+int    mt_adam_clip_step_ex(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                            int step, float grad_scale, const long long* keep_ranges, int n_keep,
+                            float* stats, void* workspace, size_t workspace_bytes, mt_stream_t stream);
 
 /* ------------------------------------------------------------------ training step
  * The kernels behind `loss.backward()` of train/train_transcriber.py:130 for CNNRNNModel in train mode

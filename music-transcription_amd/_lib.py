@@ -124,6 +124,7 @@ _SIGS = {
     "mt_cnnrnn_large_forward_ev": (i32, [C.POINTER(CnnRnnLargeWeights), vp, vp, i32, i32, vp, vp, sz, C.POINTER(vp), i32, vp]),
     "mt_adam_workspace_bytes": (sz, []),
     "mt_adam_clip_step": (i32, [vp, vp, vp, vp, ll] + [C.c_float] * 6 + [i32, vp, vp, sz, vp]),
+    "mt_adam_clip_step_ex": (i32, [vp, vp, vp, vp, ll] + [C.c_float] * 6 + [i32, C.c_float, vp, i32, vp, vp, sz, vp]),
     "mt_bce_workspace_bytes": (sz, []),
     "mt_bce_masked_fwd_bwd": (i32, [vp, vp, vp, C.c_longlong, C.c_float, i32, vp, vp, vp, sz, i32, i32, i32, vp]),
     "mt_onset_offset_targets": (i32, [vp, vp, vp, C.c_longlong, i32, vp]),

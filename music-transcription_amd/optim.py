@@ -40,9 +40,14 @@ def flatten_parameters(params: Iterable[torch.nn.Parameter]):
     return flat, grads
 
 
+def _world() -> int:
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def allreduce_mean_(flat_grads: torch.Tensor) -> torch.Tensor:
-    """Gradient mean over ranks: one all-reduce of the flat buffer (RCCL on GPUs, gloo on CPU tensors)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """Gradient mean over ranks: one all-reduce of the flat buffer (RCCL on GPUs, gloo on CPU tensors).  (Host-side helper
+    and what the CPU tests check; FusedAdamClip.step() all-reduces the SUM and folds 1 / world into the fused kernel.)"""
+    if _world() > 1:
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
         flat_grads.div_(dist.get_world_size())
     return flat_grads
@@ -56,7 +61,12 @@ class EarlyBucket:
     84-MB weight-gradient GEMM and the convolution backward still run.  `reduce_early` folds those gradients into the flat buffer
     on the stream that produced them and starts their all-reduce on a communication stream; FusedAdamClip.step() then reduces
     only the head of the buffer and waits for the tail's.  Used by train_step.backward_train when the optimizer attached one
-    to the model (world size > 1)."""
+    to the model (world size > 1).
+
+    Contract: ONE backward per optimizer step, with optimizer.zero_grad() (or model.zero_grad()) in front of it, as the
+    reference's loop does (train_transcriber.py:113-144).  A second backward before step() (gradient accumulation) is not
+    taken over: its gradients go through autograd as usual and step() raises, because the tail would then hold a
+    rank-summed microbatch plus a local one."""
 
     def __init__(self, flat_grads: torch.Tensor, named_views):
         self.g = flat_grads
@@ -64,11 +74,15 @@ class EarlyBucket:
         self.comm = torch.cuda.Stream(device=flat_grads.device)
         self.pending = None                       # (start, end, work, event) of the tail reduce in flight
         self.early_params = set()
+        self.stale = False                        # a backward ran while a tail reduce was pending
 
     def reduce_early(self, grads: dict, stream) -> set:
         """grads: name -> gradient tensor (complete in `stream`'s order).  Returns the names taken over (their gradient now lives
         in the flat buffer; autograd must be given None for them).  Nothing is taken unless the names form the buffer's tail."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or self.pending is not None:
+        if _world() <= 1:
+            return set()
+        if self.pending is not None:
+            self.stale = True                     # a second backward before step(): see the class docstring
             return set()
         items = [(self.where[n], t) for n, t in grads.items() if n in self.where and t is not None]
         if not items:
@@ -78,7 +92,10 @@ class EarlyBucket:
             return set()                          # not a contiguous tail of the flat buffer: leave everything to step()
         with torch.cuda.stream(stream):
             for (o, k, p), t in items:
-                self.g[o:o + k].add_(t.reshape(-1))            # accumulate, as autograd would have
+                if p.grad is None:                # zero_grad(set_to_none=True) detached the view: the tail may hold last
+                    self.g[o:o + k].copy_(t.reshape(-1))       # step's reduced gradient -> overwrite, never add
+                else:
+                    self.g[o:o + k].add_(t.reshape(-1))        # accumulate, as autograd would have
             ev = torch.cuda.Event()
             ev.record(stream)
         with torch.cuda.stream(self.comm):
@@ -92,6 +109,10 @@ class EarlyBucket:
 
     def finish(self, stream) -> int:
         """Wait (in `stream`'s order) for the tail reduce; returns where the un-reduced head ends (numel if nothing was early)."""
+        if self.stale:
+            self.stale = False
+            raise RuntimeError("EarlyBucket: two backward passes before one optimizer.step() -- the early all-reduce of the "
+                               "gradient tail supports one backward per step (set MT_DP_EARLY_BUCKET=0 for gradient accumulation)")
         if self.pending is None:
             return self.g.numel()
         start, work, done = self.pending
@@ -117,9 +138,39 @@ class FusedAdamClip:
         self.ws = torch.empty(lib.mt_adam_workspace_bytes(), dtype=torch.uint8, device=flat_params.device)
         self.stats = torch.zeros(2, dtype=torch.float32, device=flat_params.device)
         self.early = None                 # EarlyBucket, attached by train.make_optimizer for data-parallel runs
+        # torch.optim.Adam and clip_grad_norm_ skip parameters whose .grad is None: after the loop's zero_grad() those are the
+        # parameters the backward pass did not reach (the onset / offset heads under the reference's frame-only loss,
+        # train_transcriber.py:119).  Here p.grad is always a view of the flat buffer, so "reached" is recorded by a
+        # post-accumulate hook per parameter and the fused kernel gets the flat ranges of the reached ones (keep ranges).
+        self._touched = set()
+        self.skip_untouched = True
+        if self._views:
+            for p, _, _ in self._views:
+                p.register_post_accumulate_grad_hook(lambda q, _t=self._touched: _t.add(id(q)))
 
     def zero_grad(self):
         self.g.zero_()
+        self._touched.clear()
+
+    def _keep_ranges(self):
+        """Ascending merged [lo, hi) ranges of the parameters that received a gradient since the last zero_grad() / step();
+        None = everything (no view table, every parameter was reached, or NO backward pass ran at all: gradients written
+        into the p.grad views by hand, as the optimizer unit test does, count as present for every parameter)."""
+        if not self._views or not self.skip_untouched:
+            return None
+        early = self.early.early_params if self.early is not None else ()
+        if not self._touched and not early:
+            return None
+        out = []
+        for p, o, k in self._views:
+            if id(p) in self._touched or id(p) in early:
+                if out and out[-1][1] == o:
+                    out[-1][1] = o + k
+                else:
+                    out.append([o, o + k])
+        if len(out) == 1 and out[0] == [0, self.g.numel()]:
+            return None
+        return out
 
     def _reattach_grad_views(self):
         """`model.zero_grad()` (set_to_none=True, as the reference's loop calls it) or an assignment to p.grad detaches a
@@ -146,21 +197,31 @@ class FusedAdamClip:
         self.t = max(0, self.t - 1)
 
     def step(self, sync_grads: bool = True):
+        """One clip + Adam step.  With torch.distributed initialised (and sync_grads) the flat gradient is all-reduced as a
+        SUM and the 1 / world of the mean is applied inside the fused kernel (no extra pass over the buffer): after step()
+        the flat gradient buffer holds the rank SUM, not the mean."""
+        import ctypes as C
         self._reattach_grad_views()
-        if sync_grads:
+        keep = self._keep_ranges()
+        scale = 1.0
+        if sync_grads and _world() > 1:
+            head = self.g.numel()
             if self.early is not None:
                 head = self.early.finish(torch.cuda.current_stream(self.g.device))      # the tail was reduced under the backward pass
                 self.early.early_params = set()
-                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                    if head > 0:
-                        dist.all_reduce(self.g[:head], op=dist.ReduceOp.SUM)
-                    self.g.div_(dist.get_world_size())
-            else:
-                allreduce_mean_(self.g)
+            if head > 0:
+                dist.all_reduce(self.g[:head], op=dist.ReduceOp.SUM)
+            scale = 1.0 / _world()
+        if keep is None:
+            kr, nk = None, 0
+        else:
+            flat_ranges = [v for r in keep for v in r]
+            kr, nk = (C.c_longlong * len(flat_ranges))(*flat_ranges), len(keep)
         self.t += 1
         with torch.cuda.device(self.p.device):
-            check(lib.mt_adam_clip_step(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), self.p.numel(), self.lr, self.betas[0],
-                                        self.betas[1], self.eps, self.wd, self.max_norm, self.t, ptr(self.stats), ptr(self.ws),
-                                        self.ws.numel(), _lib.stream_ptr()), "mt_adam_clip_step")
+            check(lib.mt_adam_clip_step_ex(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), self.p.numel(), self.lr, self.betas[0],
+                                           self.betas[1], self.eps, self.wd, self.max_norm, self.t, scale, kr, nk, ptr(self.stats),
+                                           ptr(self.ws), self.ws.numel(), _lib.stream_ptr()), "mt_adam_clip_step_ex")
+        self._touched.clear()
         WEIGHTS_EPOCH[0] += 1
         return self.stats

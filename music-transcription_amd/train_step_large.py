@@ -657,9 +657,9 @@ class CnnRnnLargeTrainFn(torch.autograd.Function):
     """logits [NH][B][88][T] = CNNRNNModelLarge(x) in train mode; backward returns the gradient of every parameter."""
 
     @staticmethod
-    def forward(ctx, model, x, p_drop, seed, p2d, names, *params):
+    def forward(ctx, model, x, p_drop, seed, p2d, names, frame_only, *params):
         logits, sv = forward_train_large(model, x, p_drop, seed, p2d)
-        ctx.model, ctx.sv, ctx.names = model, sv, names
+        ctx.model, ctx.sv, ctx.names, ctx.frame_only = model, sv, names, frame_only
         model._train_sync = (sv["sync_all"], sv["sync_stride"])
         return logits
 
@@ -667,7 +667,15 @@ class CnnRnnLargeTrainFn(torch.autograd.Function):
     def backward(ctx, dlogits):
         g = backward_train_large(ctx.model, ctx.sv, dlogits)
         ctx.sv = None
-        return (None, None, None, None, None, None) + tuple(g[n] for n in ctx.names)
+        if ctx.frame_only:
+            # model(mel) of the reference's loop returns the frame logits only (cnn_rnn_model.py:343-349,
+            # train_transcriber.py:119): the onset / offset heads are not part of the graph, their .grad stays None and
+            # torch.optim.Adam never touches them (no weight decay either).  Exact-zero gradients would not be the same
+            # thing: Adam's normalisation turns g' = wd * p into a step of ~lr * sign(p).
+            for n in ctx.names:
+                if n.startswith(("onset_head.", "offset_head.")):
+                    g[n] = None
+        return (None, None, None, None, None, None, None) + tuple(g[n] for n in ctx.names)
 
 
 def train_forward_large(model, x: torch.Tensor, return_all_heads: bool = False):
@@ -677,7 +685,8 @@ def train_forward_large(model, x: torch.Tensor, return_all_heads: bool = False):
     p2d = tuple(float(v) for v in getattr(model, "dropout2d_p", DROPOUT2D_P))
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (p > 0.0 or any(v > 0.0 for v in p2d)) else 0
     if torch.is_grad_enabled():
-        out = CnnRnnLargeTrainFn.apply(model, x, p, seed, p2d, names, *params)
+        frame_only = bool(model.use_onset_offset_heads and not return_all_heads)
+        out = CnnRnnLargeTrainFn.apply(model, x, p, seed, p2d, names, frame_only, *params)
     else:
         out, sv = forward_train_large(model, x, p, seed, p2d)
         model._train_sync = (sv["sync_all"], sv["sync_stride"])
