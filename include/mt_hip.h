@@ -141,6 +141,18 @@ int    mt_gemm_lstm_gx_dt(const void* X, int ldx, const void* W_ih, int ldw, con
                           int B, int T, int H, int K, int dt, mt_stream_t stream);
 int    mt_gemm_logits_dt(const void* X, int ldx, const void* W, int ldw, const float* bias, float* logits,
                          int B, int T, int N, int K, int dt, mt_stream_t stream);
+/* The two input projections with MT_GEMM_SCHED_BYTES of device scratch (`sched`, 16-byte aligned; zeroed by the call on
+ * `stream`; nothing else may touch it until the launch has finished: one block per GEMM call of a forward in flight).  With it,
+ * and for f16 gx (MT_GX_F16 / gx_f16) with B % 32 == 0, 256 | H and an even number >= 16 of 64-wide K-tiles, the projection runs
+ * as PERSISTENT tiles: a workgroup walks a dynamic sequence of 256 x 256 tiles as one K-stream and the finished tile's f16
+ * output leaves under the next tile's main loop (csrc/gemm.hip, gemm256p_kernel).  sched == NULL or any other shape: the
+ * one-tile-per-workgroup kernels, bit-identical results.                                                                   */
+#define MT_GEMM_SCHED_BYTES 64
+size_t mt_gemm_sched_bytes(void);
+int    mt_gemm_lstm_gx_sched(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
+                             int B, int T, int H, int K, int dt, void* sched, mt_stream_t stream);
+int    mt_gemm_lstm_gx_from_hx_sched(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
+                                     int B, int T, int H, int Hprev, int gx_f16, void* sched, mt_stream_t stream);
 
 /* ------------------------------------------------------------------ bidirectional LSTM recurrence
  * nn.LSTM(batch_first, bidirectional) as the reference runs it (cnn_rnn_model.py:45-52,

@@ -97,6 +97,9 @@ _SIGS = {
     "mt_gemm_logits_from_hx": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_bf16_f32acc": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_gemm_lstm_gx": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
+    "mt_gemm_sched_bytes": (sz, []),
+    "mt_gemm_lstm_gx_sched": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "mt_gemm_lstm_gx_from_hx_sched": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "mt_gemm_lstm_dh": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),
     "mt_gemm_logits": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "mt_lstm_gx_bytes": (sz, [i32, i32, i32]),

@@ -608,6 +608,369 @@ __global__ __launch_bounds__(512) void gemm256x_kernel(const bf16_t* __restrict_
             epilogue_tile16<EPI, DT>(acc[i][j], m0 + wm * 128 + i * 16, n0 + wn * 64 + j * 16, c16, q, M, N, ep, outp);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent form of gemm256x_kernel for the f16 gate-pre-activation output (EPI_LSTM_GX with gx16; B % 32 == 0, 256 | H).
+// Why: one 256 x 256 tile leaves 128 KB of output, and a CU's store path moves ~10 B / clk: 5-6 us per tile during which
+// the CU's matrix pipe idles -- with one workgroup per CU (128 KB of LDS) nothing else can run there.  At K = 1024 that was a
+// third of the launch (0.30 ms against 0.22 without any epilogue at M = 30 016).  Here a workgroup walks a sequence of tiles as
+// ONE K-tile stream: the DMA of the next tile's first K-tile is issued under the last K-tile of the current one, the finished
+// accumulators are converted to f16 (+ bias) into 64 parked registers per lane, and those leave as two 8-byte stores per K-tile
+// of the NEXT tile (right behind its DMA wait, so they have a whole K-tile before the next `vmcnt(0)` sees them): the store
+// path works while the matrix pipe does.
+// Tiles come from 8 queues, one per XCD (the workgroup reads its XCC id and pulls from that queue first, then steals from the
+// next ones): a queue is a contiguous run of the grouped tile order, so the tiles in flight on one XCD share A / W panels
+// through its L2 whichever workgroup pulls them.  Dynamic, because with several forwards in flight the persistent recurrence
+// launches of other streams hold CUs for milliseconds: a statically assigned tile would wait for a workgroup that is not
+// resident.  A workgroup leaves after `tiles_per_wg` tiles (the grid is total / tiles_per_wg workgroups), so CUs return to the
+// dispatcher every few hundred microseconds -- the recurrence launches of other forwards must get their workgroups resident.
+// The queue heads (8 words) are zeroed by the launch function on the stream.  Speed only: any pull order is correct.
+constexpr int GP_LDS = G256_LDS + 64;
+
+template <int DT, bool AHX, int GP_PARK>
+__global__ __launch_bounds__(512) void gemm256p_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+                                                       int M, int N, int K, GemmEpi ep, unsigned* __restrict__ qhead, int tiles_per_wg, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    int* lds_next = (int*)(smem2 + G256_LDS);
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int wm = wv >> 2, wn = wv & 3;
+    const int tiles_m = (M + BM2 - 1) / BM2, tiles_n = N / BN2, total = tiles_m * tiles_n;
+    const int qq = total >> 3, rmd = total & 7;
+    const int a_last = ((M + 127) & ~127) - 1;
+    const int nk = K / BK;
+    const int H = ep.H, nkb = H >> 3;
+#define GP_QLO(x) ((x) * qq + min((x), rmd))
+#define GP_QCNT(x) (qq + ((x) < rmd ? 1 : 0))
+    // grouped tile order (as gemm256x_kernel): groups of GM tile rows, column-major inside a group
+#define GP_DECODE(pid, m0_, n0_)                                                                              \
+    {                                                                                                         \
+        constexpr int GM_ = 4;                                                                                \
+        const int per_group_ = GM_ * tiles_n, grp_ = (pid) / per_group_, first_m_ = grp_ * GM_;               \
+        const int gm_ = min(GM_, tiles_m - first_m_), in_grp_ = (pid) - grp_ * per_group_;                    \
+        m0_ = (first_m_ + in_grp_ % gm_) * BM2;                                                               \
+        n0_ = (in_grp_ / gm_) * BN2;                                                                          \
+    }
+
+    // ---- first tile: wave 0 pulls synchronously (own XCD's queue first)
+    int fq = 0;                                    // the queue this workgroup currently pulls from
+    if (wv == 0) {
+        int got = -1;
+        if (lane == 0) {
+            const int xcc = __builtin_amdgcn_s_getreg(20 /*HW_REG_XCC_ID*/ | (0 << 6) | ((4 - 1) << 11)) & 7;
+            for (int a = 0; a < 8 && got < 0; ++a) {
+                const int x = (xcc + a) & 7;
+                const unsigned id = __hip_atomic_fetch_add(qhead + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (id < (unsigned)GP_QCNT(x)) got = GP_QLO(x) + (int)id + (x << 24);
+            }
+            lds_next[0] = got;
+        }
+    }
+    __syncthreads();
+    int cur = __builtin_amdgcn_readfirstlane(lds_next[0]);       // (an LDS load is per-lane to the compiler: keep tile state scalar)
+    if (cur < 0) return;                            // nothing left (a late workgroup)
+    fq = __builtin_amdgcn_readfirstlane((cur >> 24) & 7);
+    cur &= 0xFFFFFF;
+    __syncthreads();
+
+    typedef __attribute__((address_space(3))) void lvoid_t;
+    const int drow = lane >> 3, dslot = lane & 7;
+    // DMA addressing through buffer descriptors: a 32-bit per-lane offset per staged row group (the swizzled 16-byte chunk of
+    // its row) + a wave-uniform scalar offset (tile origin, K-tile) -- 8 address registers instead of 16 64-bit pointers.
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, -1, 0x00020000);
+    unsigned voffA[4], voffW[4];
+    unsigned sbaseA = 0, sbaseW = 0;                 // scalar byte offsets of the DMA tile's origin
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row_ = wv * 32 + j * 8 + drow, chunk_ = dslot ^ ((row_ >> 1) & 7);
+        voffW[j] = (unsigned)row_ * (unsigned)ldw * 2u + (unsigned)chunk_ * 16u;
+    }
+#define GP_SET_DMA_TILE(pid)                                                                                  \
+    {                                                                                                         \
+        int dm0_, dn0_;                                                                                       \
+        GP_DECODE(pid, dm0_, dn0_)                                                                            \
+        sbaseW = (unsigned)dn0_ * (unsigned)ldw * 2u;                                                         \
+        sbaseA = AHX ? 0u : (unsigned)dm0_ * (unsigned)lda * 2u;                                              \
+        int ln_ = lane;                                                                                       \
+        asm volatile("" : "+v"(ln_));      /* recompute the lane terms here: hoisted, they cost ~8 registers through the K loop */ \
+        const int drow_ = ln_ >> 3, dslot_ = ln_ & 7;                                                         \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                    \
+            const int row_ = wv * 32 + j_ * 8 + drow_, chunk_ = dslot_ ^ ((row_ >> 1) & 7);                   \
+            if (AHX) voffA[j_] = (unsigned)(hx_row_off(ep, min(dm0_ + row_, M - 1)) + (chunk_ >> 1) * 512 + (chunk_ & 1) * 256) * 2u; \
+            else voffA[j_] = (unsigned)(min(dm0_ + row_, a_last) - dm0_) * (unsigned)lda * 2u + (unsigned)chunk_ * 16u; \
+        }                                                                                                     \
+    }
+    // scalar byte offset of K-tile kt inside a row (plain rows) / inside the hx images (AHX: hx_chunk_off's uniform part)
+#define GP_KOFF_A(kt) (AHX ? (unsigned)(((kt) / (ep.aH >> 6)) * (ep.aH >> 4) + ((kt) % (ep.aH >> 6)) * 4) * 1024u : (unsigned)(kt) * 128u)
+#define GP_DMA1(kt, buf, J)                                                                                   \
+    {                                                                                                         \
+        char* la_ = smem2 + (buf) * (BM2 + BN2) * BK * 2 + (wv * 32 + (J) * 8) * 128;                         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lvoid_t*)la_, 16, voffA[J], sbaseA + GP_KOFF_A(kt), 0, 0);            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lvoid_t*)(la_ + BM2 * BK * 2), 16, voffW[J], sbaseW + (unsigned)(kt) * 128u, 0, 0); \
+    }
+    // Fragment read addresses: every A / W row a lane reads is (wave-uniform row) + c16, so the swizzle term is the lane's own:
+    // byte offset = uniform + ldsL[ks] + 2048 * (tile index), ldsL[1] = ldsL[0] ^ 64.  The uniform part goes through an opaque
+    // scalar so that the eight (buffer, k-step, operand) base registers are not kept alive through the whole K loop.
+#define GP_READ_A(I0, ks)                                                                                      \
+    {                                                                                                          \
+        int so_ = buf * (BM2 + BN2) * BK * 2 + wm * 16384 + (I0) * 2048;                                       \
+        asm volatile("" : "+s"(so_));                                                                          \
+        const char* pa_ = smem2 + (ldsL[ks] + so_);                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) fa[i_] = *(const bf16x8*)(pa_ + i_ * 2048);           \
+    }
+#define GP_READ_B(ks)                                                                                          \
+    {                                                                                                          \
+        int so_ = buf * (BM2 + BN2) * BK * 2 + BM2 * BK * 2 + wn * 8192;                                       \
+        asm volatile("" : "+s"(so_));                                                                          \
+        const char* pb_ = smem2 + (ldsL[ks] + so_);                                                            \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) fb[j_] = *(const bf16x8*)(pb_ + j_ * 2048);           \
+    }
+#define GP_MID(I0)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                       \
+            acc[(I0) + i_][j_] = mfma_16x16x32<DT>(fa[i_], fb[j_], acc[(I0) + i_][j_]);                        \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 fa[4], fb[4];
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    int ldsL[2];
+    ldsL[0] = c16 * 128 + ((q ^ ((c16 >> 1) & 7)) << 4);
+    ldsL[1] = ldsL[0] ^ 64;
+
+    // the previous tile's output: f16 (+ bias) as 16-byte pieces [unit][8 consecutive chunks].  An accumulator tile gives a lane 4
+    // consecutive chunks of one unit (8 bytes); the two 16-row tiles of a 32-row run are re-paired across lanes l <-> l + 16 with
+    // v_permlane16_swap so that lanes with even q hold chunks 8 (q / 2) .. + 7 of the first tile's rows and lanes with odd q the same
+    // of the second tile's: ONE 16-byte store per lane and run instead of two 8-byte ones.  (The store path takes ~70 cycles per
+    // wave-instruction whatever its width -- MI355X_MICROARCH.md, epilogue store tail: halving the instruction count is what
+    // counts.)  GP_PARK of the wave's 4 row runs wait in registers (4 x 16 bytes each); the others leave at the tile boundary.
+    typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_;
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_;
+    u32x4_ parked[GP_PARK][4];
+    int p_run[4] = {-1, -1, -1, -1};                 // byte offset of this wave's 4 row runs (one (t, batch group) each); -1 = past M
+    int p_col = 0;                                   // byte offset of the wave's first 8-unit block (direction, gate, unit)
+    bool have_parked = false;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ep.out, 0, -1, 0x00020000);
+    const int lane_off = (c16 >> 3) * 2048 + (c16 & 7) * 64 + (q & 1) * 32 + (q >> 1) * 16;
+#define GP_STORE16(a, j)                                                                                       \
+    if (p_run[a] >= 0) __builtin_amdgcn_raw_buffer_store_b128(parked[a][j], orsrc, lane_off, p_run[a] + p_col + (j) * 4096, 0);
+    // the piece of row run kt0 / 4 (a wave-uniform choice between static registers), column block j
+#define GP_STORE_RUN(j)                                                                                        \
+    {                                                                                                          \
+        if (kt0 == 0) { GP_STORE16(0, j) }                                                                     \
+        else if (kt0 == 4 || GP_PARK < 3) { GP_STORE16(1, j) }                                                 \
+        else { GP_STORE16(GP_PARK - 1, j) }                                                                    \
+    }
+    // In-loop store schedule: ONE piece per wave and K-tile during the first 4 GP_PARK K-tiles of the next tile.
+    //   dbg & 2 == 0: behind the K-tile's DMA wait (phase 3), so the plain vmcnt(0) of the next K-tile finds it a K-tile old;
+    //   dbg & 2     : in phase 1 + wave % 3 -- the workgroup's 8 stores of a K-tile spread over three phases -- behind the
+    //                 wave's last DMA request of the K-tile, and the DMA wait leaves exactly that one store in flight
+    //                 (`vmcnt(1)`: the counter retires in issue order, loads, LDS-DMA and stores alike).
+    const int st_phase = (dbg & 2) ? 1 + wv % 3 : 4;
+    int cm0, cn0;                                    // the tile being accumulated
+    GP_DECODE(cur, cm0, cn0)
+    GP_SET_DMA_TILE(cur)
+    float gxb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gxb[j] = ep.bias[cn0 + wn * 64 + j * 16 + c16];
+
+    // next-tile pull of wave 0 (one attempt per K-tile during K-tiles 0..7, resolved behind that K-tile's DMA wait)
+    int fnext = -2, ftries = 0;                      // -2 unresolved, -1 none
+    unsigned fret = 0;
+    bool fpend = false;
+    int done_tiles = 0;
+
+    GP_DMA1(0, 0, 0) GP_DMA1(0, 0, 1) GP_DMA1(0, 0, 2) GP_DMA1(0, 0, 3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();               // the stagger; balanced after the loop
+    for (;;) {
+        int next = -1;
+        // (4 K-tiles per trip of the loop, not 16: the body is ~2 300 instructions, and a body beyond the instruction cache cost
+        //  more than the whole epilogue it hides)
+        for (int kt0 = 0; kt0 < nk; kt0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kt = kt0 + u;
+                const int buf = u & 1;                                 // nk is even: the stream's buffer parity = kt's
+                const bool last = kt + 1 == nk;
+                const int p_run_sel = p_run[kt0 == 0 ? 0 : ((kt0 == 4 || GP_PARK < 3) ? 1 : GP_PARK - 1)];
+                int dk = kt + 1;                                       // K-tile the DMA fetches during this one
+                if (last) {
+                    next = __builtin_amdgcn_readfirstlane(lds_next[0]);
+                    dk = 0;
+                    if (next >= 0) GP_SET_DMA_TILE(next)
+                }
+                const bool more = !last || next >= 0;
+                // wave 0: pull the next tile's id (K-tiles 0..7), publish it in K-tile 9
+                if (kt < 8 && wv == 0 && fnext == -2) {
+                    // Soft quota: after `tiles_per_wg` tiles the workgroup leaves IF plenty of tiles remain in its queue (a
+                    // fresh workgroup of the over-provisioned grid -- or another stream's recurrence -- gets the CU); near the
+                    // end nobody leaves, so the tail is one tile, not one quota.  (A racy plain read of the head: only speed.)
+                    bool leave = false;
+                    if (done_tiles + 1 >= tiles_per_wg) {
+                        const unsigned head = __hip_atomic_load(qhead + fq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        leave = (int)head + 3 * tiles_per_wg < GP_QCNT(fq);
+                    }
+                    if (leave) {
+                        fnext = -1;
+                    } else {
+                        if (lane == 0) {
+                            const unsigned one_ = 1u;
+                            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(fret) : "v"(qhead + fq), "v"(one_) : "memory");
+                        }
+                        fpend = true;
+                    }
+                }
+                if (kt == 9 && wv == 0 && lane == 0) lds_next[0] = fnext;
+                GP_READ_B(0) GP_READ_A(0, 0)
+                if (more) { GP_DMA1(dk, buf ^ 1, 0) GP_DMA1(dk, buf ^ 1, 1) }
+                GP_MID(0)
+                GP_READ_A(4, 0)
+                if (more) { GP_DMA1(dk, buf ^ 1, 2) GP_DMA1(dk, buf ^ 1, 3) }
+                // (dbg & 2) counted form: the previous tile's output leaves two stores per K-tile right BEHIND this K-tile's DMA
+                // requests, and the wait below leaves exactly those two in flight (vmcnt counts in issue order): a store has until
+                // the NEXT K-tile's wait, 7 phases, to be acknowledged
+                const bool st_now = kt0 < 4 * GP_PARK && have_parked && !(dbg & 1);       // row run kt0 / 4, column block u
+                if (st_now && st_phase == 1) { GP_STORE_RUN(u) }
+                GP_MID(4)
+                GP_READ_B(1) GP_READ_A(0, 1)
+                if (st_now && st_phase == 2) { GP_STORE_RUN(u) }
+                GP_MID(0)
+                GP_READ_A(4, 1)
+                if (st_now && st_phase == 3) { GP_STORE_RUN(u) }
+                if (st_now && st_phase < 4 && p_run_sel >= 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (wv == 0 && fpend) {
+                    asm volatile("" : "+v"(fret));
+                    const unsigned id = (unsigned)__builtin_amdgcn_readfirstlane((int)fret);
+                    if (id < (unsigned)GP_QCNT(fq)) fnext = __builtin_amdgcn_readfirstlane(GP_QLO(fq) + (int)id);
+                    else { fq = __builtin_amdgcn_readfirstlane((fq + 1) & 7); if (++ftries >= 8) fnext = -1; }
+                    fpend = false;
+                }
+                // the previous tile's output leaves two stores per K-tile, behind the wait (a whole K-tile until the next one)
+                if (st_now && st_phase == 4) { GP_STORE_RUN(u) }
+                GP_MID(4)
+            }
+        }
+        // ---- tile boundary: park this tile's output (f16, + bias), restart the accumulators
+        {
+            typedef __attribute__((__vector_size__(4 * sizeof(f16_t)))) f16_t f16x4_;
+            const int d = cn0 / (4 * H), rem = cn0 - d * 4 * H, p = rem / H, jj0 = rem - p * H;      // uniform over the tile (256 | H)
+            p_col = ((d * nkb + (jj0 >> 3) + wn * 8) * 4 + p) * 512;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int m = cm0 + (wm * 4 + a) * 32;
+                const int t = m / ep.B, g = (m - t * ep.B) >> 5;
+                p_run[a] = m < M ? ((g * ep.T + t) * 2) * nkb * 2048 : -1;
+            }
+#pragma unroll
+            for (int a = 3; a >= 0; --a) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float bv = gxb[j];
+                    const f16x4_ h0 = f16x4_{(f16_t)(acc[2 * a][j][0] + bv), (f16_t)(acc[2 * a][j][1] + bv), (f16_t)(acc[2 * a][j][2] + bv), (f16_t)(acc[2 * a][j][3] + bv)};
+                    const f16x4_ h1 = f16x4_{(f16_t)(acc[2 * a + 1][j][0] + bv), (f16_t)(acc[2 * a + 1][j][1] + bv), (f16_t)(acc[2 * a + 1][j][2] + bv), (f16_t)(acc[2 * a + 1][j][3] + bv)};
+                    acc[2 * a][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    acc[2 * a + 1][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    const u32x2_ A_ = __builtin_bit_cast(u32x2_, h0), B_ = __builtin_bit_cast(u32x2_, h1);
+                    // rows 16-31 / 48-63 of A_ <-> rows 0-15 / 32-47 of B_
+                    const auto sx = __builtin_amdgcn_permlane16_swap(A_[0], B_[0], false, false);
+                    const auto sy = __builtin_amdgcn_permlane16_swap(A_[1], B_[1], false, false);
+                    const u32x4_ piece = u32x4_{sx[0], sy[0], sx[1], sy[1]};
+                    if (a < GP_PARK) {
+                        parked[a][j] = piece;
+                    } else if (p_run[a] >= 0 && !(dbg & 4)) {
+                        __builtin_amdgcn_raw_buffer_store_b128(piece, orsrc, lane_off, p_run[a] + p_col + j * 4096, 0);
+                    }
+                }
+            }
+            have_parked = true;
+        }
+        ++done_tiles;
+        if (next < 0) break;
+        cur = next;
+        GP_DECODE(cur, cm0, cn0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gxb[j] = ep.bias[cn0 + wn * 64 + j * 16 + c16];
+        fnext = -2; ftries = 0;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    // ---- the last tile's output
+    if (dbg & 4) return;
+#pragma unroll
+    for (int a = 0; a < GP_PARK; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { GP_STORE16(a, j) }
+#undef GP_QLO
+#undef GP_QCNT
+#undef GP_DECODE
+#undef GP_SET_DMA_TILE
+#undef GP_DMA1
+#undef GP_KOFF_A
+#undef GP_READ_A
+#undef GP_READ_B
+#undef GP_MID
+#undef GP_STORE16
+#undef GP_STORE_RUN
+}
+
+// The persistent kernel applies to: f16 gx output, whole batch groups, 256 | H (a tile's columns share direction and gate), N a
+// multiple of 256, an even number (>= 16) of K-tiles, a gx buffer addressable with 31-bit byte offsets.  sched = 8 queue heads
+// in device memory that nothing else touches until the launch has finished (zeroed here, on the stream).
+static bool persist_ok(const GemmEpi& ep, int M, int N, int K, const void* sched) {
+    // OPT-IN (MT_GEMM_PERSIST=1).  Measured (tools/gemm_persist_bench.py, M = 120 064, K = 1024): with no output stores at all the
+    // persistent stream runs 0.83 ms against the one-tile kernel's 1.02 (prologue latency and epilogue gone), but WITH the stores
+    // it is 1.04 -- trickled two per K-tile, staggered over waves and phases, behind counted waits, 8- or 16-byte wide: the 983 MB
+    // of output cost the same 0.2 ms whether they leave in a burst behind the tile or under the next tile's main loop.  The
+    // main loop already keeps the CU's vector-memory path busy (64 KB of LDS-DMA per K-tile = ~18 B/clk/CU), and the stores
+    // go through that same path: overlap with the matrix pipe does not buy back path time.  Kept as an option and as the record.
+    static const bool allow = getenv("MT_GEMM_PERSIST") && atoi(getenv("MT_GEMM_PERSIST")) == 1;
+    if (!allow || !sched || !ep.gx16 || (ep.B & 31) || (ep.H & 255) || (N & 255) || K % (4 * BK) || K / BK < 16 || M < 4096) return false;
+    const long long gx_bytes = (long long)(ep.B / 32) * ep.T * 2 * (ep.H / 8) * 2048;
+    return gx_bytes < 0x7FFFFFFFll && cdiv(M, BM2) * (N / BN2) < (1 << 24);
+}
+template <int DT, bool AHX>
+static int launch_persist(const bf16_t* a, int lda, const bf16_t* w, int ldw, int M, int N, int K, const GemmEpi& ep, void* sched, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<DT, AHX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS));
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<DT, AHX, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS));
+        attr_set = true;
+    }
+    static const int park = getenv("MT_GEMM_PARK") ? atoi(getenv("MT_GEMM_PARK")) : 2;
+    const int total = cdiv(M, BM2) * (N / BN2);
+    // a workgroup's lifetime ~ 0.4 ms (a K-tile takes ~1.7 us): long enough that one tile in `tpw` ends without overlap, short
+    // enough that CUs return to the dispatcher for other streams' persistent recurrence launches
+    static const int tpw_env = getenv("MT_GEMM_TPW") ? atoi(getenv("MT_GEMM_TPW")) : 0;
+    const int tpw = tpw_env > 0 ? tpw_env : max(2, min(16, (int)(400.0 / (1.7 * (K / BK)) + 0.5)));
+    int n_cu = 256;
+    {
+        int devi = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&devi) == hipSuccess && hipGetDeviceProperties(&prop, devi) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    }
+    static const int dbg = getenv("MT_GEMM_PDBG") ? atoi(getenv("MT_GEMM_PDBG")) : 0;
+    // workgroups that leave on their quota are replaced from the grid's surplus; a workgroup that finds the queues empty returns at once
+    const int grid = min(total, n_cu + cdiv(total, tpw));
+    MT_CHECK_HIP(hipMemsetAsync(sched, 0, 64, st));
+    if (park == 3) hipLaunchKernelGGL((gemm256p_kernel<DT, AHX, 3>), dim3(grid), dim3(512), GP_LDS, st, a, lda, w, ldw, M, N, K, ep, (unsigned*)sched, tpw, dbg);
+    else hipLaunchKernelGGL((gemm256p_kernel<DT, AHX, 2>), dim3(grid), dim3(512), GP_LDS, st, a, lda, w, ldw, M, N, K, ep, (unsigned*)sched, tpw, dbg);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
 template <int EPI, int DT>
 static int launch256(const bf16_t* a, int lda, const bf16_t* w, int ldw, int M, int N, int K, const GemmEpi& ep, hipStream_t st, int batch) {
     static bool attr_set = false;
@@ -642,12 +1005,13 @@ static int launch_dt(int epi, const bf16_t* a, int lda, const bf16_t* w, int ldw
 }
 
 // A read from hx images (f16 operands): the layer-to-layer input projection and the final fc, no re-layout pass in front of them
-static int launch_hx(int epi, const void* hx, const void* W, int ldw, int M, int N, GemmEpi ep, hipStream_t st) {
+static int launch_hx(int epi, const void* hx, const void* W, int ldw, int M, int N, GemmEpi ep, hipStream_t st, void* sched = nullptr) {
     MT_REQUIRE(hx && W && ep.out && ep.aB > 0 && ep.aT > 0 && ep.aH >= 64 && ep.aH % 64 == 0 && M == ep.aB * ep.aT, MT_EINVAL,
                "gemm (A from hx): bad dims B=%d T=%d H=%d (H must be a multiple of 64)", ep.aB, ep.aT, ep.aH);
     const int K = 2 * ep.aH;
     MT_REQUIRE(ldw >= K && ldw % 8 == 0, MT_EINVAL, "gemm (A from hx): ldw=%d < K=%d", ldw, K);
     const bf16_t* a = (const bf16_t*)hx; const bf16_t* w = (const bf16_t*)W;
+    if (epi == EPI_LSTM_GX && persist_ok(ep, M, N, K, sched)) return launch_persist<MT_DT_F16, true>(a, K, w, ldw, M, N, K, ep, sched, st);
     if (epi == EPI_LSTM_GX && M >= 1024 && N >= 512 && N % 128 == 0 && (long long)cdiv(M, BM2) * cdiv(N, BN2) >= 128) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -664,7 +1028,8 @@ static int launch_hx(int epi, const void* hx, const void* W, int ldw, int M, int
     return MT_OK;
 }
 
-static int launch(int epi, int dt, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st, int batch = 1) {
+static int launch(int epi, int dt, const void* A, int lda, const void* W, int ldw, int M, int N, int K, GemmEpi ep, hipStream_t st, int batch = 1,
+                  void* sched = nullptr) {
     MT_REQUIRE(A && W && ep.out, MT_EINVAL, "gemm: null pointer");
     MT_REQUIRE_DT(dt, "gemm");
     // (lda < K is allowed: rows then overlap -- a 1x1 convolution over 32 channels-last channels runs as K = 64 with zero
@@ -672,6 +1037,9 @@ static int launch(int epi, int dt, const void* A, int lda, const void* W, int ld
     MT_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && lda > 0 && ldw >= K && lda % 8 == 0 && ldw % 8 == 0, MT_EINVAL,
                "gemm: bad dims M=%d N=%d K=%d lda=%d ldw=%d (K must be a multiple of %d)", M, N, K, lda, ldw, BK);
     const bf16_t* a = (const bf16_t*)A; const bf16_t* w = (const bf16_t*)W;
+    if (epi == EPI_LSTM_GX && batch == 1 && persist_ok(ep, M, N, K, sched))
+        return dt == MT_DT_F16 ? launch_persist<MT_DT_F16, false>(a, lda, w, ldw, M, N, K, ep, sched, st)
+                               : launch_persist<MT_DT_BF16, false>(a, lda, w, ldw, M, N, K, ep, sched, st);
     return dt == MT_DT_F16 ? launch_dt<MT_DT_F16>(epi, a, lda, w, ldw, M, N, K, ep, st, batch)
                            : launch_dt<MT_DT_BF16>(epi, a, lda, w, ldw, M, N, K, ep, st, batch);
 }
@@ -693,13 +1061,21 @@ extern "C" int mt_gemm_bf16_f32acc(const void* A, int lda, const void* W, int ld
     return mt_gemm_f32acc_dt(A, lda, W, ldw, bias, C, ldc, M, N, K, MT_DT_BF16, stream);
 }
 
-extern "C" int mt_gemm_lstm_gx_dt(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
-                                  int B, int T, int H, int K, int dt, mt_stream_t stream) {
+// `_sched`: the same projection with MT_GEMM_SCHED_BYTES of device scratch for the persistent-tile kernel's tile queues (zeroed
+// here on the stream; must not be touched by anything else until the launch has finished -- one block per GEMM call of a forward).
+// NULL, or a shape the persistent kernel does not cover, runs the one-tile-per-workgroup kernels: same results.
+extern "C" size_t mt_gemm_sched_bytes(void) { return MT_GEMM_SCHED_BYTES; }
+extern "C" int mt_gemm_lstm_gx_sched(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
+                                     int B, int T, int H, int K, int dt, void* sched, mt_stream_t stream) {
     MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx: bias is required (b_ih + b_hh)");
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx: bad dims B=%d T=%d H=%d", B, T, H);
     GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1};
     ep.gx16 = (dt & MT_GX_F16) ? 1 : 0;
-    return launch(EPI_LSTM_GX, dt & ~MT_GX_F16, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream);
+    return launch(EPI_LSTM_GX, dt & ~MT_GX_F16, X, ldx, W_ih, ldw, T * B, 8 * H, K, ep, (hipStream_t)stream, 1, sched);
+}
+extern "C" int mt_gemm_lstm_gx_dt(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
+                                  int B, int T, int H, int K, int dt, mt_stream_t stream) {
+    return mt_gemm_lstm_gx_sched(X, ldx, W_ih, ldw, bias, gx, B, T, H, K, dt, nullptr, stream);
 }
 extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw, const float* bias, float* gx,
                                int B, int T, int H, int K, mt_stream_t stream) {
@@ -708,13 +1084,17 @@ extern "C" int mt_gemm_lstm_gx(const void* X, int ldx, const void* W_ih, int ldw
 
 // The same two projections with A read straight from the previous LSTM layer's hx images (f16 operands; hx as
 // mt_lstm_bidir_fwd* writes it, B / T / H of THAT layer, H % 64 == 0): K = 2H, column k = dir*H + unit.
-extern "C" int mt_gemm_lstm_gx_from_hx_ex(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
-                                          int B, int T, int H, int Hprev, int gx_f16, mt_stream_t stream) {
+extern "C" int mt_gemm_lstm_gx_from_hx_sched(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
+                                             int B, int T, int H, int Hprev, int gx_f16, void* sched, mt_stream_t stream) {
     MT_REQUIRE(bias, MT_EINVAL, "mt_gemm_lstm_gx_from_hx: bias is required (b_ih + b_hh)");
     MT_REQUIRE(B > 0 && T > 0 && H > 0 && H % 8 == 0, MT_EINVAL, "mt_gemm_lstm_gx_from_hx: bad dims B=%d T=%d H=%d", B, T, H);
     GemmEpi ep{gx, bias, 0, B, T, H, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0.0f, 0, 0, B, T, Hprev};
     ep.gx16 = gx_f16 ? 1 : 0;
-    return launch_hx(EPI_LSTM_GX, hx_prev, W_ih, ldw, T * B, 8 * H, ep, (hipStream_t)stream);
+    return launch_hx(EPI_LSTM_GX, hx_prev, W_ih, ldw, T * B, 8 * H, ep, (hipStream_t)stream, sched);
+}
+extern "C" int mt_gemm_lstm_gx_from_hx_ex(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
+                                          int B, int T, int H, int Hprev, int gx_f16, mt_stream_t stream) {
+    return mt_gemm_lstm_gx_from_hx_sched(hx_prev, W_ih, ldw, bias, gx, B, T, H, Hprev, gx_f16, nullptr, stream);
 }
 extern "C" int mt_gemm_lstm_gx_from_hx(const float* hx_prev, const void* W_ih, int ldw, const float* bias, float* gx,
                                        int B, int T, int H, int Hprev, mt_stream_t stream) {

@@ -13,6 +13,8 @@ int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int,
 int mt_lstm_relayout_dt(const float*, void*, int, float*, int, int, int, int, int, int, int, mt_stream_t);
 int mt_gemm_lstm_gx_from_hx_ex(const float*, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
 int mt_gemm_logits_from_hx(const float*, const void*, int, const float*, float*, int, int, int, int, mt_stream_t);
+int mt_gemm_lstm_gx_sched(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, void*, mt_stream_t);
+int mt_gemm_lstm_gx_from_hx_sched(const float*, const void*, int, const float*, float*, int, int, int, int, int, void*, mt_stream_t);
 int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 size_t mt_lstm_gx_bytes(int, int, int);
 size_t mt_lstm_hx_bytes(int, int, int);
@@ -22,7 +24,7 @@ size_t mt_lstm_sync_bytes(int, int);
 namespace mt {
 struct CnnRnnPlan {
     int F1, Fo2, K0, K1, M, Mpad, Hp;
-    size_t act1, x0, x1, gx, hx, hx2, sync, sync_stride, total;
+    size_t act1, x0, x1, gx, hx, hx2, sync, sync_stride, sched, total;
 };
 static CnnRnnPlan plan(const mt_cnnrnn_weights* w, int B, int T) {
     CnnRnnPlan p;
@@ -40,6 +42,7 @@ static CnnRnnPlan plan(const mt_cnnrnn_weights* w, int B, int T) {
     p.hx2 = o;  o += align_up(mt_lstm_hx_bytes(B, T, p.Hp), 256);      // ping-pong partner for the fused-projection layers
     p.sync_stride = align_up(mt_lstm_sync_bytes(B, p.Hp), 256);
     p.sync = o; o += p.sync_stride * w->layers;
+    p.sched = o; o += align_up((size_t)MT_GEMM_SCHED_BYTES * w->layers, 256);      // tile queues of the persistent projection GEMMs, one block per layer
     p.total = o;
     return p;
 }
@@ -122,11 +125,13 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
         } else {
             const int K = l == 0 ? p.K0 : p.K1;
             if (l > 0 && from_hx) {
-                if ((rc = mt_gemm_lstm_gx_from_hx_ex((const float*)hcur, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, H, gx16, stream)) != MT_OK) return rc;
+                if ((rc = mt_gemm_lstm_gx_from_hx_sched((const float*)hcur, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, H, gx16,
+                                                        ws + p.sched + (size_t)MT_GEMM_SCHED_BYTES * l, stream)) != MT_OK) return rc;
                 char* tmp = hcur; hcur = hnext; hnext = tmp;                       // this layer writes the other buffer
             } else {
                 const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
-                if ((rc = mt_gemm_lstm_gx_dt(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, dt | gx16, stream)) != MT_OK) return rc;
+                if ((rc = mt_gemm_lstm_gx_sched(X, K, w->w_ih[l], K, w->b_gates[l], (float*)(ws + p.gx), B, T, H, K, dt | gx16,
+                                                ws + p.sched + (size_t)MT_GEMM_SCHED_BYTES * l, stream)) != MT_OK) return rc;
             }
             if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
             if ((rc = mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * l,

@@ -18,6 +18,8 @@ int mt_gemm_batched_h16out_dt(const void*, int, long long, long long, const void
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
 int mt_gemm_lstm_gx_from_hx_ex(const float*, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
 int mt_lstm_relayout_dt(const float*, void*, int, float*, int, int, int, int, int, int, int, mt_stream_t);
+int mt_gemm_lstm_gx_sched(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, void*, mt_stream_t);
+int mt_gemm_lstm_gx_from_hx_sched(const float*, const void*, int, const float*, float*, int, int, int, int, int, void*, mt_stream_t);
 int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 int mt_attn_softmax_clamped_dt(const float*, int, void*, int, int, long long, float, float, int, mt_stream_t);
 int mt_attn_transpose_v(const void*, int, int, void*, int, int, int, int, int, mt_stream_t);
@@ -30,7 +32,7 @@ size_t mt_lstm_sync_bytes(int, int);
 namespace mt {
 struct LargePlan {
     int F1, F2, F3, K0, K1, M, Mpad, Tr, Tp, Hp, Hlp, comb, Cp, Hs, dp, ld3, Ca;
-    size_t act1, r1a, r1, r2a, r2, x0, x1, gx, hx, gx2, hx2, hx3, sync, sync_stride, rb, r32, qkv, S, P, VT, ao, proj, ln, sh, total;
+    size_t act1, r1a, r1, r2a, r2, x0, x1, gx, hx, gx2, hx2, hx3, sync, sync_stride, sched, rb, r32, qkv, S, P, VT, ao, proj, ln, sh, total;
 };
 static LargePlan lplan(const mt_cnnrnn_large_weights* w, int B, int T) {
     LargePlan p;
@@ -61,6 +63,7 @@ static LargePlan lplan(const mt_cnnrnn_large_weights* w, int B, int T) {
     p.hx3 = take(mt_lstm_hx_bytes(B, T, Hmax));            // ping-pong partner of hx for layers with the fused input projection
     p.sync_stride = align_up(mt_lstm_sync_bytes(B, Hmax), 256);
     p.sync = take(p.sync_stride * (w->layers + 1));
+    p.sched = take((size_t)MT_GEMM_SCHED_BYTES * (w->layers + 1));     // tile queues of the persistent projection GEMMs (local LSTM + one per layer)
     p.rb = take((size_t)p.Mpad * p.Cp * 2);
     p.r32 = take((size_t)p.M * p.comb * 4);
     p.qkv = take((size_t)p.Tr * B * p.ld3 * 2);
@@ -143,7 +146,7 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
     }
     // f16 operands + agent-scope recurrence: the gate pre-activations travel GEMM -> recurrence as f16 (MT_GX_F16, include/mt_hip.h)
     const int gx16 = (dt == MT_DT_F16 && w->lstm_mode == 0) ? MT_GX_F16 : 0;
-    RUN(mt_gemm_lstm_gx_dt(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, dt | gx16, ls));
+    RUN(mt_gemm_lstm_gx_sched(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, dt | gx16, ws + p.sched, ls));
     REC();
     RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode | gx16, ls));
     REC();
@@ -167,10 +170,12 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
             const void* X = l == 0 ? ws + p.x0 : ws + p.x1;
             const int K = l == 0 ? p.K0 : p.K1;
             if (l > 0 && from_hx) {
-                RUN(mt_gemm_lstm_gx_from_hx_ex((const float*)hcur, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, Hv, gx16, stream));
+                RUN(mt_gemm_lstm_gx_from_hx_sched((const float*)hcur, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, Hv, gx16,
+                                                  ws + p.sched + (size_t)MT_GEMM_SCHED_BYTES * (l + 1), stream));
                 char* tmp = hcur; hcur = hnext; hnext = tmp;
             } else {
-                RUN(mt_gemm_lstm_gx_dt(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, dt | gx16, stream));
+                RUN(mt_gemm_lstm_gx_sched(X, K, w->main_w_ih[l], K, w->main_b[l], (float*)(ws + p.gx), B, T, p.Hp, K, dt | gx16,
+                                          ws + p.sched + (size_t)MT_GEMM_SCHED_BYTES * (l + 1), stream));
             }
             REC();
             RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * (l + 1),
