@@ -254,6 +254,29 @@ def _roofline_from_stages(stages, share_of=None):
                      "share_of_step": round(g["ms"] / total, 3), "mfma_dtype": ref["mfma_dtype"]}
 
 
+# dominant-stage key of a section -> substring of the kernel's name in the committed PMC profile of that section's command
+_PMC_KERNEL_OF = {"lstm_bptt": "lstm_bptt_kernel", "lstm_rec_train": "lstm_rec_kernel", "lstm_rec": "lstm_rec_kernel", "gemm_lstm_gx": "gemm256",
+                  "convg_freq_aware_7x3": "convg_kernel", "convg_res_block1": "convg_kernel", "convg_res_block2": "convg_kernel",
+                  "attention_layernorm": "attn", "conv1_kernel": "conv1_kernel", "heads": "gemm"}
+
+
+def _pmc_traffic(fnames, dom_key):
+    """HBM bytes per launch of the section's dominant kernel from a committed rocprofv3 --pmc summary (tools/refresh_pmc.sh):
+    PMC counters cannot be read from inside the process.  Where one kernel NAME covers several stages (convg_kernel), the
+    launches of that name with the most bytes are taken (the 7x3 conv is the largest convg launch)."""
+    sub = _PMC_KERNEL_OF.get(dom_key, dom_key)
+    for fname in fnames:
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
+        except Exception:
+            continue
+        hit = [v for k, v in prof.items() if sub in k]
+        if hit:
+            best = max(hit, key=lambda v: v["hbm_bytes_per_launch_corrected"])
+            return round(best["hbm_bytes_per_launch_corrected"]), f"profiles/{fname} (committed rocprofv3 --pmc passes of this section's command; not re-measured in this run)"
+    return None, None
+
+
 def _stage_rows(table, ms):
     stages = []
     for (name, bound, work, unit), t_ms in zip(table, ms):
@@ -407,8 +430,8 @@ def section_large(mta, dev, cores, do_cpu):
     torch.cuda.synchronize()
     ms = [float(np.mean([evs[i][k].elapsed_time(evs[i][k + 1]) for i in range(K1)])) for k in range(nst)]
     stages = _stage_rows(large_stage_table(B, T, N_MELS, HIDDEN, LAYERS), ms)
-    _, roof = _roofline_from_stages(stages)
-    roof["traffic_source"] = None
+    dom, roof = _roofline_from_stages(stages)
+    roof["traffic"], roof["traffic_source"] = _pmc_traffic(("r03_pmc_traffic_large.json",), dom)
     # the same with 8 batches of 16 per forward (four batch groups of 32 interleaved in each persistent recurrence launch)
     cos = None
     try:
@@ -521,7 +544,8 @@ def section_train(mta, dev, cores, do_cpu):
             if nm_ in spans:
                 table.append((nm_, bound, work, "FLOP")); ms.append(float(np.mean(spans[nm_])))
     stages = _stage_rows(table, ms)
-    _, roof = _roofline_from_stages(stages, share_of=1e3 * el / K)
+    dom, roof = _roofline_from_stages(stages, share_of=1e3 * el / K)
+    roof["traffic"], roof["traffic_source"] = _pmc_traffic(("r03_pmc_traffic_train.json",), dom)
     sec = {"workload": "CNNRNNModel training step, batch=16 cached-format chunks, 1 GPU (BASELINE.json configs[3] per-GPU shape)",
            "value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_step": round(1e3 * el / K, 3), "steps": K,
            "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "model_tflops_per_s": round(3.0 * 72.76e9 * B * T / 938.0 * K / el / 1e12, 1),
@@ -538,6 +562,48 @@ def section_train(mta, dev, cores, do_cpu):
         sec["cpu_baseline"] = {"value": round(nb / dt, 3), "unit": "chunks/s", "cores": cores, "kind": "port",
                                "sample": f"1 step on {nb} chunks: fp32 torch-CPU train-mode forward + autograd backward + clip + Adam (oracle.train_steps), {cores} threads"}
     return sec
+
+
+def section_corpus(mta, dev, cores, do_cpu):
+    """BASELINE.json configs[4] on one GPU: the whole synthetic "MAESTRO test split" (177 recordings, 20 h, gamma-distributed
+    lengths) through music_transcription_amd.corpus.transcribe_shard -- the code path of scripts/transcribe_corpus.py --
+    with CNNRNNModelLarge 320/512/3 (main.py:16-20's model): slabs of 128 chunks cut across recordings, 3 forwards in flight,
+    notes extracted on the device (only the note lists reach the host), framewise F1 against a Bernoulli(0.04) reference roll.
+    Weights are random (no checkpoint exists): the frame head's bias is shifted so that ~0.3 % of the cells are active, which
+    gives a trained model's note count (a few thousand per recording) instead of millions of one-frame notes."""
+    import torch
+    from music_transcription_amd import corpus
+    n_rec, hours = 177, 20.0
+    durations = corpus.synthetic_corpus(n_rec, hours, seed=0)
+    model = seeded_model(mta, "cnn_rnn_large", str(dev)).eval()
+    t1 = time.perf_counter()
+    chunks = {i: corpus.synth_recording(i, durations[i], dev) for i in range(n_rec)}        # 4.6 GB resident before the timed region
+    torch.cuda.synchronize()
+    t_synth = time.perf_counter() - t1
+    fe = mta.get_frontend(SR, N_MELS, HOP, str(dev))
+    with torch.no_grad():                                                                   # calibrate the output bias on one slab
+        mel, cmax = fe(torch.cat([chunks[i] for i in range(6)])[:64], clamp=False)
+        lg = model.model(mel, chunk_max_power=cmax)
+        shift = float(torch.quantile(lg.flatten()[::97].float(), 0.997))
+        model.model.frame_head.bias.sub_(shift)              # (in place through autograd's version counter: the packed weights are rebuilt)
+    gens = {}
+
+    def ref_roll(i, T_total):
+        g = gens.setdefault("g", torch.Generator(device=dev))
+        g.manual_seed(i)
+        return (torch.rand(88, T_total, device=dev, generator=g) < 0.04).float()
+    res = corpus.transcribe_shard(model, list(range(n_rec)), lambda i: chunks[i], n_mels=N_MELS, device=dev, batch=128, streams=3,
+                                  threshold=0.5, want_notes=True, reference_roll_of=ref_roll)
+    n, wall = res["chunks"], res["wall_s"]
+    f1 = list(res["f1"].values())
+    return {"workload": f"offline corpus transcription, {n_rec} synthetic recordings / {hours:g} h of 16 kHz audio, CNNRNNModelLarge, 1 GPU "
+                        "(BASELINE.json configs[4]; on 8 GPUs the recordings are LPT-sharded over the ranks, no data-path collective)",
+            "value": round(n / wall, 1), "unit": "chunks/s", "wall_s": round(wall, 3), "chunks": n, "slabs_of_128": res["slabs"],
+            "audio_hours_per_wall_second": round(hours / wall, 2), "notes": res["n_notes"], "finite": res["finite"],
+            "mean_f1_vs_random_reference": round(float(sum(f1) / max(len(f1), 1)), 5),
+            "d2h": "note lists only (two ints per note + 88 counts per recording); rolls and logits stay on the GPU",
+            "timed": "slab assembly across recordings, mel + forward of every slab (3 streams), per-recording notes (mt_roll_to_notes) and F1 counts; "
+                     f"not timed: synthesis of the audio ({t_synth:.1f} s, resident in HBM), weight packing"}
 
 
 def main():
@@ -603,9 +669,20 @@ def main():
         os.environ["MT_LSTM_MODE"] = "2"
     # seeded synthetic input: noise + decaying piano-range sinusoids; seed = 1234 + rank.
     # Four distinct chunks tiled to the batch keep host-side synthesis short; the kernels see B chunks.
-    base = synth_audio(min(B, 4), N_SAMPLES, seed=1234 + rank)
-    wave = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B].copy()).to(dev)
-    wave_f = torch.cat([wave] * C) if C > 1 else wave
+    # Eight chunks are synthesised on the host (that is what takes time there); the other chunks of a forward are DISTINCT
+    # signals derived from them on the device: a circular time shift, a gain and fresh seeded noise per copy, so that no two of
+    # the C x B chunks of a forward are equal (every kernel works on data, not on repeats a cache could serve).
+    base = torch.from_numpy(synth_audio(min(B, 8), N_SAMPLES, seed=1234 + rank)).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    parts = []
+    for c in range((C * B + len(base) - 1) // len(base)):
+        w = base if c == 0 else torch.roll(base, shifts=7919 * c, dims=1) * (0.55 + 0.03 * (c % 13))
+        if c:
+            w = w + 0.02 * torch.randn(w.shape, device=dev, generator=gen)
+        parts.append(w.clamp_(-1.0, 1.0) if c else w)
+    wave_f = torch.cat(parts)[:C * B].contiguous()
+    wave = wave_f[:B]
+    del parts
     model = seeded_model(mta, "cnn_rnn", str(dev))
     model.eval()
     net = model.model
@@ -625,16 +702,28 @@ def main():
     cmax = [torch.empty(BF, device=dev) for _ in range(NS)]
 
     nst = 3 + 3 * LAYERS
-    NF, REM = K // C, K % C                          # full forwards of C steps, steps left over for one smaller forward
-    ev_mel = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(NF)]
-    ev_net = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(NF)]
-    for row in ev_mel + ev_net:          # create the underlying hipEvent_t handles before the timed region
-        for e in row:
-            e.record()
 
-    def forward(j, i=None, nb=C):
-        """One whole pass (mel + forward) over nb batches of B chunks, issued on stream j % NS."""
-        s = j % NS
+    def plan_forwards(ns):
+        """The K timed steps as forwards [(stream, batches)]: whole rounds of ns forwards of C batches, and the batches left
+        over (fewer than a round) dealt EVENLY over the streams as smaller forwards that run side by side -- a finite job
+        must not end on one full-size forward running alone (K = 20 at 4 x 4: one round of 4 x 4 and a last round of 4 x 1;
+        a forward of one batch takes a third of the time of a forward of four: its recurrences interleave nothing)."""
+        rounds, rem = divmod(K, C * ns)
+        out = [(s_, C) for _ in range(rounds) for s_ in range(ns)]
+        tail = [rem // ns + (1 if s_ < rem % ns else 0) for s_ in range(ns)]
+        return out + [(s_, nb_) for s_, nb_ in enumerate(tail) if nb_]
+
+    def make_events(n):
+        ev_m = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(n)]
+        ev_n = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(n)]
+        for row in ev_m + ev_n:          # create the underlying hipEvent_t handles before the timed region
+            for e in row:
+                e.record()
+        return ev_m, ev_n
+
+    def forward(j, i=None, nb=C, s=None):
+        """One whole pass (mel + forward) over nb batches of B chunks, issued on stream s (default j % NS)."""
+        s = j % NS if s is None else s
         n = nb * B
         with torch.cuda.stream(streams[s]), torch.no_grad():
             if i is not None:
@@ -648,11 +737,11 @@ def main():
     from music_transcription_amd._lib import MtError
     while True:
         try:
+            sched = plan_forwards(NS)
+            for nb_ in sorted({nb_ for _, nb_ in sched}):        # every forward shape of the timed region (workspaces), then the warm-up
+                forward(0, nb=nb_)
             for j in range(max((W + C - 1) // C, NS if W else 0)):
                 forward(j)
-            if REM and W:
-                forward(0, nb=REM)                       # (its workspace shape, before the timed region)
-                forward(1)
             torch.cuda.synchronize()
             break
         except MtError as e:
@@ -664,22 +753,24 @@ def main():
             NS -= 1
             net._ws.clear()
             log(f"{NS + 1} forwards in flight refused ({str(e)[:160]}): continuing with {NS}")
+    sched = plan_forwards(NS)
+    assert sum(nb_ for _, nb_ in sched) == K
+    NF = len(sched)
+    ev_mel, ev_net = make_events(NF)
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(NF):
-        logits = forward(i, i)
-    if REM:
-        logits = forward(NF, nb=REM)
+    for i, (s_, nb_) in enumerate(sched):
+        logits = forward(i, i, nb=nb_, s=s_)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    net.raise_on_handoff_timeout(BF, T)
-    if REM:
-        net.raise_on_handoff_timeout(REM * B, T)
+    for nb_ in sorted({nb_ for _, nb_ in sched}):
+        net.raise_on_handoff_timeout(nb_ * B, T)
     hl_mode = int(mt_model._LSTM_MODE.get(dev_index, 0))        # what the timed region actually ran (census may have refused mode 2)
     log(f"timed region: {elapsed:.3f} s for {K} steps")
     if world > 1:
@@ -728,10 +819,13 @@ def main():
     if rank == 0:
         # ---- per-kernel times from the events recorded inside the timed region (several batches in flight: kernels of
         #      different steps overlap, so these are NOT kernel efficiencies -- those come from the 1-stream pass below)
-        table = stage_table(BF, T, N_MELS, HIDDEN, LAYERS, fused=bool(net.fuse_input_projection))
-        ms = [float(np.mean([ev_mel[i][0].elapsed_time(ev_mel[i][1]) for i in range(NF)]))]
+        sizes = [nb_ for _, nb_ in sched]
+        nb_o = max(set(sizes), key=sizes.count)             # the commonest forward size of the timed region
+        idx_o = [i for i, nb_ in enumerate(sizes) if nb_ == nb_o]
+        table = stage_table(nb_o * B, T, N_MELS, HIDDEN, LAYERS, fused=bool(net.fuse_input_projection))
+        ms = [float(np.mean([ev_mel[i][0].elapsed_time(ev_mel[i][1]) for i in idx_o]))]
         for s in range(nst):
-            ms.append(float(np.mean([ev_net[i][s].elapsed_time(ev_net[i][s + 1]) for i in range(NF)])))
+            ms.append(float(np.mean([ev_net[i][s].elapsed_time(ev_net[i][s + 1]) for i in idx_o])))
         stages_overlapped = _stage_rows(table, ms)
         dom_key_o, roofline_overlapped = _roofline_from_stages(stages_overlapped)
         stages_one_batch, roofline_one_batch = None, None
@@ -750,7 +844,7 @@ def main():
         # rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950), and the line says so
         traffic, tsrc = None, None
-        for fname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
                 # (the 1-stream pass runs the agent-scope recurrence, mt::lstm_rec_kernel; the XCD-local mt::lstm_rec16_kernel of a
@@ -786,7 +880,7 @@ def main():
             # (the training section first: the HIP runtime deals a process's streams onto its hardware queues in creation order,
             #  and after the streams of the Large section the training step's side stream ends up sharing a queue with the
             #  stream it is meant to overlap -- 630 instead of 700 chunks/s)
-            for name, fn in (("configs3_train_b16", section_train), ("configs2_large_b16", section_large)):
+            for name, fn in (("configs3_train_b16", section_train), ("configs2_large_b16", section_large), ("configs4_corpus", section_corpus)):
                 t1 = time.perf_counter()
                 try:
                     sections[name] = fn(mta, dev, cores, not args.no_cpu_baseline)
@@ -796,6 +890,13 @@ def main():
                 log(f"section {name}: {time.perf_counter() - t1:.1f} s")
                 torch.cuda.empty_cache()
 
+        # every kernel's fraction of its roofline in one compact object (survives a truncated log): the headline forward's stages,
+        # the Large forward's and the training step's timed launches
+        roofline["all"] = {s_["kernel"]: s_["frac"] for s_ in stages if s_["work_per_launch"] > 0}
+        for sec_name, key in (("configs2_large_b16", "stages_one_stream"), ("configs3_train_b16", "stages_timed")):
+            sec_ = sections.get(sec_name)
+            if isinstance(sec_, dict) and key in sec_:
+                roofline["all_" + sec_name.split("_")[1]] = {s_["kernel"]: s_["frac"] for s_ in sec_[key] if s_["work_per_launch"] > 0}
         out = {"metric": "30 s audio chunks/sec (mel+CNNRNN forward)", "value": round(world * B * K / elapsed, 2),
                "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -806,8 +907,11 @@ def main():
                                       "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
                           "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)",
                           "coscheduled_batches_per_forward": C, "streams_per_gpu": NS, "batches_in_flight": C * NS,
-                          "scheduling": f"a step = one batch of {B} chunks; {C} steps are issued as one forward over {BF} chunks (the recurrence "
-                                        f"interleaves their batch groups in one persistent launch), {NS} forwards in flight on {NS} streams",
+                          "forwards_in_timed_region": {f"{nb_}x{B}": sizes.count(nb_) for nb_ in sorted(set(sizes))},
+                          "scheduling": f"a step = one batch of {B} chunks; the {K} timed steps are issued as forwards over {C} batches (the recurrence interleaves "
+                                        f"their batch groups in one persistent launch), dealt round-robin over {NS} streams: "
+                                        f"{NS} forwards in flight; the batches beyond whole rounds of {NS} x {C} run as a last round of smaller forwards side by side.  One batch of {B} per forward, the literal configs[1] schedule: configs1_other_schedules.b32_streams_3",
+                          "distinct_chunks_per_forward": True,
                           "fused_input_projection": bool(net.fuse_input_projection), "lstm_mode": hl_mode},
                "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
                "roofline_one_batch": roofline_one_batch, "stages_one_batch": stages_one_batch,

@@ -140,36 +140,31 @@ class FusedAdamClip:
         self.early = None                 # EarlyBucket, attached by train.make_optimizer for data-parallel runs
         # torch.optim.Adam and clip_grad_norm_ skip parameters whose .grad is None: after the loop's zero_grad() those are the
         # parameters the backward pass did not reach (the onset / offset heads under the reference's frame-only loss,
-        # train_transcriber.py:119).  Here p.grad is always a view of the flat buffer, so "reached" is recorded by a
-        # post-accumulate hook per parameter and the fused kernel gets the flat ranges of the reached ones (keep ranges).
-        self._touched = set()
+        # train_transcriber.py:119).  Here p.grad is always a view of the flat buffer, so the training step's autograd function
+        # records which parameters it returned no gradient for (`net._params_without_grad`, names) and the fused kernel gets the
+        # flat ranges of all the others (keep ranges).  `net` is attached by train.make_optimizer.
+        self.net = None
         self.skip_untouched = True
-        if self._views:
-            for p, _, _ in self._views:
-                p.register_post_accumulate_grad_hook(lambda q, _t=self._touched: _t.add(id(q)))
 
     def zero_grad(self):
         self.g.zero_()
-        self._touched.clear()
+        if self.net is not None:
+            self.net._params_without_grad = set()
 
     def _keep_ranges(self):
-        """Ascending merged [lo, hi) ranges of the parameters that received a gradient since the last zero_grad() / step();
-        None = everything (no view table, every parameter was reached, or NO backward pass ran at all: gradients written
-        into the p.grad views by hand, as the optimizer unit test does, count as present for every parameter)."""
-        if not self._views or not self.skip_untouched:
+        """Ascending merged [lo, hi) ranges of the parameters that take part in this step: all of them, minus those the last
+        backward pass produced no gradient for; None = everything."""
+        skip_names = getattr(self.net, "_params_without_grad", None) if self.net is not None else None
+        if not self._views or not self.skip_untouched or not skip_names:
             return None
-        early = self.early.early_params if self.early is not None else ()
-        if not self._touched and not early:
-            return None
+        skip = {id(p) for n, p in self.net.named_parameters() if n in skip_names}
         out = []
         for p, o, k in self._views:
-            if id(p) in self._touched or id(p) in early:
+            if id(p) not in skip:
                 if out and out[-1][1] == o:
                     out[-1][1] = o + k
                 else:
                     out.append([o, o + k])
-        if len(out) == 1 and out[0] == [0, self.g.numel()]:
-            return None
         return out
 
     def _reattach_grad_views(self):
@@ -222,6 +217,7 @@ class FusedAdamClip:
             check(lib.mt_adam_clip_step_ex(ptr(self.p), ptr(self.g), ptr(self.m), ptr(self.v), self.p.numel(), self.lr, self.betas[0],
                                            self.betas[1], self.eps, self.wd, self.max_norm, self.t, scale, kr, nk, ptr(self.stats),
                                            ptr(self.ws), self.ws.numel(), _lib.stream_ptr()), "mt_adam_clip_step_ex")
-        self._touched.clear()
+        if self.net is not None:
+            self.net._params_without_grad = set()
         WEIGHTS_EPOCH[0] += 1
         return self.stats

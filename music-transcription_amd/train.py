@@ -29,6 +29,7 @@ def make_optimizer(model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-
     clip_grad_norm_ (train_transcriber.py:134).  Parameters become views of one flat buffer."""
     flat, grads = flatten_parameters(model.parameters())
     opt = FusedAdamClip(flat, grads, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_grad_norm)
+    opt.net = getattr(model, "model", model)       # the training step records there which parameters got no gradient (optim._keep_ranges)
     if _world_size() > 1 and os.environ.get("MT_DP_EARLY_BUCKET", "1") != "0":
         # data parallel: the gradients of the upper LSTM layers and the fc are all-reduced under the rest of the backward pass
         net = getattr(model, "model", model)

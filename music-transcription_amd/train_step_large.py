@@ -675,6 +675,8 @@ class CnnRnnLargeTrainFn(torch.autograd.Function):
             for n in ctx.names:
                 if n.startswith(("onset_head.", "offset_head.")):
                     g[n] = None
+        # (FusedAdamClip reads this: p.grad is a view of its flat buffer there, never None)
+        ctx.model._params_without_grad = set(getattr(ctx.model, "_params_without_grad", ())) | {n for n in ctx.names if g[n] is None}
         return (None, None, None, None, None, None, None) + tuple(g[n] for n in ctx.names)
 
 

@@ -38,6 +38,7 @@ def main():
                     help="chunks per forward (the recurrence interleaves up to four batch groups of 32 in one persistent launch)")
     ap.add_argument("--streams", type=int, default=4, help="forwards in flight (at most 3 for cnn_rnn_large: two recurrence launches each)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out-dir", help="directory: write <name>.mid per recording (notes extracted on the device)")
     ap.add_argument("--dump-rolls", help="directory: write <name>.roll.bits.npy (np.packbits of the (88, T_total) roll) per recording")
     args = ap.parse_args()
 
@@ -92,71 +93,56 @@ def main():
         y[n:] = 0.0                         # zero-pad the last chunk in the waveform domain (main.py:93-95)
         return y.clamp_(-1, 1).view(nch, CH)
 
-    fe = mta.get_frontend(SR, args.n_mels, 512, dev)
+    from music_transcription_amd import corpus
     NS = max(1, min(args.streams, 3 if args.model_type == "cnn_rnn_large" else 6))
-    side = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-    with torch.no_grad():                   # warm-up: weight packing, code objects, and every stream's workspace
-        w0 = torch.zeros(args.batch, CH, device=dev)
-        torch.cuda.synchronize()
-        for st in side:
-            with torch.cuda.stream(st):
-                m0, c0 = fe(w0, clamp=False)
-                model.model(m0, chunk_max_power=c0)
-    synth_chunks = None if args.wav_dir else {i: synth(i) for i in mine}
+    synth_chunks = None if args.wav_dir else {i: corpus.synth_recording(i, durations[i], dev, args.seed) for i in mine}   # resident, not timed
+
+    def chunks_of(i):
+        if args.wav_dir:                    # file read + H2D + GPU resample + split are part of the end-to-end time
+            return tr.split_into_chunks_device(tr.load_audio_device(os.path.join(args.wav_dir, names[i] + ".wav"), SR, dev))[0]
+        return synth_chunks[i]
+
+    def reference_roll_of(i, T_total):
+        ref_path = os.path.join(args.wav_dir, names[i] + ".roll.npy") if args.wav_dir else None
+        if ref_path and os.path.exists(ref_path):
+            return torch.from_numpy(np.load(ref_path)).float().to(dev)
+        return (torch.rand(88, T_total, device=dev, generator=torch.Generator(device=dev).manual_seed(i)) < 0.04).float()
+
+    def midi_path_of(i):
+        if not args.out_dir:
+            return None
+        os.makedirs(args.out_dir, exist_ok=True)
+        return os.path.join(args.out_dir, names[i] + ".mid")
+
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    # chunks are independent (main.py:258-266 keeps no cross-chunk state): batch them ACROSS recordings
-    owners, pieces = [], []
-    for i in mine:
-        if args.wav_dir:                    # file read + H2D + GPU resample are part of the end-to-end time
-            c, _ = tr.split_into_chunks_device(tr.load_audio_device(os.path.join(args.wav_dir, names[i] + ".wav"), SR, dev))
-        else:
-            c = synth_chunks[i]
-        owners += [i] * c.shape[0]
-        pieces.append(c)
-    allc = torch.cat(pieces) if pieces else torch.zeros(0, CH, device=dev)
-    n_chunks = allc.shape[0]
-    # the bench's schedule: forwards of --batch chunks, --streams of them in flight (forward f on stream f % streams)
-    rolls = []
-    main_stream = torch.cuda.current_stream()
-    for st in side:
-        st.wait_stream(main_stream)                      # (the chunks were assembled on the main stream)
-    with torch.no_grad():
-        for f, s in enumerate(range(0, n_chunks, args.batch)):
-            with torch.cuda.stream(side[f % NS]):
-                mel, cmax = fe(allc[s:s + args.batch], clamp=False)
-                rolls.append(mta.predict_from_logits(model.model(mel, chunk_max_power=cmax), args.threshold))
-    for st in side:
-        main_stream.wait_stream(st)
-    allr = torch.cat(rolls) if rolls else torch.zeros(0, 88, 938, device=dev)
-    f1s, pos = [], 0
-    for i, c in zip(mine, pieces):
-        roll = allr[pos:pos + c.shape[0]].permute(1, 0, 2).reshape(88, -1)                          # (88, T_total)
-        pos += c.shape[0]
-        ref_path = os.path.join(args.wav_dir, names[i] + ".roll.npy") if args.wav_dir else None
-        if ref_path and os.path.exists(ref_path):
-            ref = torch.from_numpy(np.load(ref_path)).float().to(dev)
-        else:
-            ref = (torch.rand(roll.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(i)) < 0.04).float()
-        if args.dump_rolls:
-            os.makedirs(args.dump_rolls, exist_ok=True)
-            np.save(os.path.join(args.dump_rolls, names[i] + ".roll.bits.npy"), np.packbits(roll.cpu().numpy().astype(np.uint8), axis=1))
-        L = min(ref.shape[1], roll.shape[1])
-        f1s.append(mta.framewise_f1(roll[None, :, :L].contiguous(), ref[None, :, :L].contiguous())[0])
-    torch.cuda.synchronize()
-    model.model.raise_on_handoff_timeout(sync=False)     # a timed-out recurrence leaves NaN logits = all-zero rolls: fail loudly
+    res = corpus.transcribe_shard(model, mine, chunks_of, n_mels=args.n_mels, device=dev, batch=args.batch, streams=NS,
+                                  threshold=args.threshold, want_notes=True, reference_roll_of=reference_roll_of, midi_path_of=midi_path_of)
+    if args.dump_rolls:                     # (debug / tests: the rolls are rebuilt from the notes -- they never left the GPU as rolls)
+        os.makedirs(args.dump_rolls, exist_ok=True)
+        fs = SR / 512
+        for i in mine:
+            T_total = res["chunks_per_recording"][i] * 938
+            notes = res["notes"].get(i, [])
+            roll = np.zeros((88, T_total), dtype=np.uint8)
+            for pch, a_, b_ in notes:
+                roll[pch - 21, int(round(a_ * fs)):int(round(b_ * fs))] = 1
+            np.save(os.path.join(args.dump_rolls, names[i] + ".roll.bits.npy"), np.packbits(roll, axis=1))
     if world > 1:
         dist.barrier()
     wall = time.perf_counter() - t0
+    f1s = [res["f1"].get(i, 0.0) for i in mine]
+    n_chunks = res["chunks"]
+    n_notes = gather_values([rank], [float(res["n_notes"])], world)
     allf1 = gather_values(mine, f1s, len(names))
     tot_chunks = gather_values([rank], [float(n_chunks)], world)
     if rank == 0:
         print(json.dumps({"workload": "offline corpus transcription (BASELINE.json configs[4])", "recordings": len(names),
                           "audio_hours": round(sum(durations) / 3600.0, 2) if not args.wav_dir else None, "n_gpus": world,
                           "chunks": int(sum(tot_chunks)), "wall_s": round(wall, 3), "chunks_per_s": round(sum(tot_chunks) / wall, 1),
-                          "mean_f1": float(np.mean(allf1)), "per_recording_f1": [float(v) for v in allf1], "model": args.model_type, "data": "wav" if args.wav_dir else "synthetic"}))
+                          "notes": int(sum(n_notes)), "mean_f1": float(np.mean(allf1)), "per_recording_f1": [float(v) for v in allf1], "model": args.model_type, "data": "wav" if args.wav_dir else "synthetic"}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -14,7 +14,21 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch1 -- python3 $R/$CMD1 > $O/fetch1.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write1 -- python3 $R/$CMD1 > $O/write1.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/mfma1 -- python3 $R/$CMD1 > $O/mfma1.log 2>&1
+# the Large forward (BASELINE configs[2]) and the training step (configs[3]): the kernels the sections' rooflines name
+CMDL="bench.py --model cnn_rnn_large --batch 16 --steps 3 --warmup 1 --streams 1"
+CMDT="bench.py --mode train --batch 16 --steps 3 --warmup 1"
+for tag in L T; do
+  if [ $tag = L ]; then CMD="$CMDL"; else CMD="$CMDT"; fi
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch$tag -- python3 $R/$CMD > $O/fetch$tag.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write$tag -- python3 $R/$CMD > $O/write$tag.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/mfma$tag -- python3 $R/$CMD > $O/mfma$tag.log 2>&1
+done
 cd $R
+python3 tools/pmc_summary.py $O/fetchL $O/writeL $O/pmc_traffic_large.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 $CMDL" 1 > $O/traffic_lt.txt
+python3 tools/pmc_mfma_summary.py $O/mfmaL $O/pmc_mfma_util_large.json "rocprofv3 --kernel-trace --pmc MfmaUtil -- python3 $CMDL" > $O/mfma_lt.txt
+python3 tools/pmc_summary.py $O/fetchT $O/writeT $O/pmc_traffic_train.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 $CMDT" 1 >> $O/traffic_lt.txt
+python3 tools/pmc_mfma_summary.py $O/mfmaT $O/pmc_mfma_util_train.json "rocprofv3 --kernel-trace --pmc MfmaUtil -- python3 $CMDT" >> $O/mfma_lt.txt
+rm -rf $O/fetchL $O/writeL $O/mfmaL $O/fetchT $O/writeT $O/mfmaT
 python3 tools/pmc_summary.py $O/fetch $O/write $O/pmc_traffic.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 $CMD4" 4 > $O/traffic.txt
 python3 tools/pmc_mfma_summary.py $O/mfma $O/pmc_mfma_util.json "rocprofv3 --kernel-trace --pmc MfmaUtil -- python3 $CMD4" > $O/mfma.txt
 python3 tools/pmc_summary.py $O/fetch1 $O/write1 $O/pmc_traffic_b32.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 $CMD1" 1 >> $O/traffic.txt
