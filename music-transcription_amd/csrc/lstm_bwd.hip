@@ -19,6 +19,15 @@
 // launch and the consumers' loads poll the poison pattern (no flags, one round trip per step).  Bounded spins.
 // 3.6 us/step at H = 512 (4.07 with 4-wave workgroups, 4.3 with the all-gather formulation, 10.2 before the prefetch
 // pipeline and the flagless hand-off).
+// Round 3, per-phase clock of a step at B = 16, T = 937 (tools/bptt_diag.py, -DMT_BPTT_DIAG): sleep + gather 1.97 us (0.58 failed
+// polls per step), fetch issue + cell math + image write 0.55, barrier 0.35, LDS read + 16 MFMAs + publish 0.70, dgx store +
+// barrier 0.24: HALF the step is the workgroup's own work, not the hand-off.  Built and dropped on that evidence: both
+// directions of a unit slice interleaved in one workgroup (the forward kernel's NG idea with the directions as the two chains;
+// half of each direction's weight operands in LDS to fit 244 registers; the next slot's gather requested ahead of the publish
+// stores as asm loads behind a hand-counted vmcnt) -- bit-identical results, 6.0-7.0 ms per launch against 3.5: a slot still
+// costs its 1.8 us of own work, so two chains in one workgroup take what two workgroups took side by side.  What would move it
+// is less work per step at B = 16 (one cell per thread instead of two half-dead ones, 16-column MFMAs, the gather's
+// rec-independent factors computed under the poll), then the interleave.
 #include "mt_common.h"
 #include <stdlib.h>
 
@@ -39,6 +48,13 @@ struct LstmBwdArgs {
     unsigned* status;     // abort word, zeroed before every launch
     int B, T, H;
 };
+
+#ifdef MT_BPTT_DIAG
+__device__ unsigned long long g_bptt_diag[1024][8];
+#define BD_STAMP(k) do { const long long n_ = __builtin_amdgcn_s_memrealtime(); dg[k] += (unsigned long long)(n_ - tl); tl = n_; } while (0)
+#else
+#define BD_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
 
@@ -111,6 +127,10 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         for (int e = 0; e < 2; ++e) ccur[e] = live ? cx_g[blk0 * 256 + (jl0 + e) * 32 + b] : 0.0f;
     }
     BPTT_FETCH(0);
+#ifdef MT_BPTT_DIAG
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tl = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int s = 0; s < T; ++s) {
         const int t = d ? s : (T - 1 - s);            // reverse of the forward processing order
         const int tn = d ? (t - 1) : (t + 1);         // the step processed just before this one
@@ -143,6 +163,9 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
                     rec[0] = sum[0]; rec[1] = sum[1];
                     break;
                 }
+#ifdef MT_BPTT_DIAG
+                dg[7] += 1;
+#endif
                 if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
                     break;
@@ -163,6 +186,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         // next step's operands: issued once the gather has succeeded (behind a retried gather they would sit, with their HBM
         // latency, in front of the retry in the wave's in-order memory queue); they have the cell math, the MFMA chain, the
         // publish and the next sleep to land
+        BD_STAMP(0);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < T) BPTT_FETCH(s + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -188,7 +212,9 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             *(unsigned*)(&img[2 * p + (wv >> 2)][((wv >> 1) & 1) * 32 + b][jl0]) = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16);
+        BD_STAMP(1);
         __syncthreads();                                // images complete (and every wave is past the previous step's reads of img)
+        BD_STAMP(2);
         if (abort_s) return;                            // a payload spin gave up (status word says where)
         // ---- reduce-scatter, producer side: partial[k][b] = sum over OWN gate rows of W_hh[rho][k] dgates[rho][b] for the
         //      consumer tiles of this wave, stored as bf16 slices [consumer][producer][unit/4][batch][4]
@@ -212,187 +238,22 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
                 }
             }
         }
+        BD_STAMP(3);
         // ---- dgates for the weight- and input-gradient GEMMs (consumed after the kernel: plain stores)
         {
             uint4* dst = (uint4*)(dgx_g + ((((size_t)t * 2 + d) * NW + w) * 8) * 1024);
             dst[tid] = *(const uint4*)(&img[tid >> 6][tid & 63][0]);
         }
         __syncthreads();                                // every wave is done reading img before the next step rewrites it
+        BD_STAMP(4);
     }
+#ifdef MT_BPTT_DIAG
+    if (tid == 0) {
+        const int wg = (blockIdx.z * 2 + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (int i = 0; i < 8; ++i) g_bptt_diag[wg][i] = dg[i];
+    }
+#endif
 #undef BPTT_FETCH
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// BOTH directions of a (batch group, 32-unit slice) in ONE workgroup, their steps interleaved (round 3).  A step of the kernel
-// above is one hand-off round trip (publish -> visible to 16 consumers -> their poll succeeds: ~1.2 us) plus ~1 us of own work
-// (gather sum, cell math, LDS image, 16 MFMAs, 9 stores), and at the reference's batch of 16 per GPU there is only ONE batch
-// group: nothing independent to run while the partial products travel -- except the other direction, whose recurrence shares
-// nothing with this one.  Here a workgroup holds the W_hh slices of both directions (2 x 64 registers of MFMA A-operands) and
-// alternates slot (fwd, s), slot (rev, s): the partials a slot gathers were published a whole slot earlier (no sleep, the first
-// poll succeeds), and the launch needs NW x NG workgroups instead of 2 NW x NG.  The lesson of the forward kernel's NG
-// interleaving (lstm.hip), with the directions as the two independent chains.  One workgroup barrier per slot: img[D] is
-// rewritten two slots later, behind the other direction's barrier.
-template <int TPW>
-__global__ __launch_bounds__(512) void lstm_bptt2_kernel(LstmBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16_t img[2][8][64][8];   // per direction: this workgroup's dgates of the slot, as 8 MFMA B-operand images
-    __shared__ int abort_s;
-    typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int H = a.H, T = a.T, nkb = H >> 3, NW = (H + 31) >> 5;
-    const int w = blockIdx.x, g = blockIdx.z;
-    const int b = lane & 31, hh = lane >> 5;
-    const int Bg = min(32, a.B - g * 32);
-    const int r = lane & 31;
-    bf16x8 wt[2][TPW][8];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int wc = wv * TPW + i, k = 32 * wc + r;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int rho = ks * 16 + 8 * hh + e, p = rho >> 5, u = rho & 31, jo = 32 * w + u;
-                    float v = 0.0f;
-                    if (wc < NW && k < H && jo < H) v = a.w_hh[((size_t)d * 4 * H + (size_t)p * H + jo) * H + k];
-                    wt[d][i][ks][e] = (short)f32_to_bf16(v);
-                }
-        }
-    const int kb = 4 * w + (wv >> 1), jl0 = 4 * (wv & 1) + 2 * hh;
-    const bool live = (kb < nkb) && (b < Bg);
-    const size_t g_blocks = (size_t)T * 2 * nkb;
-    const float* gates_g = a.gates + g * g_blocks * 1024;
-    const float* cx_g = a.cx + g * g_blocks * 256;
-    const float* dh_g = a.dh + g * g_blocks * 256;
-    char* dgx_g = (char*)a.dgx + g * ((size_t)T * 2 * NW * 8 * 1024);
-    const size_t part_bytes = (size_t)T * 2 * NW * NW * 2048;
-    char* part_g = (char*)a.part + g * part_bytes;
-    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(part_g, 0, (int)part_bytes, 0x00020000);
-    if (tid == 0) abort_s = 0;
-    __syncthreads();
-
-    float carry[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, ccur[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
-    float gt[2][4][2], cprev[2][2], dhin[2][2];
-#define BPTT2_FETCH(D, S_)                                                                                          \
-    do {                                                                                                            \
-        const int t_ = (D) ? (S_) : (T - 1 - (S_));                                                                 \
-        const int tp_ = (D) ? (t_ + 1) : (t_ - 1);                                                                  \
-        const size_t blk_ = ((size_t)t_ * 2 + (D)) * nkb + kb, blkp_ = ((size_t)tp_ * 2 + (D)) * nkb + kb;         \
-        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                             \
-            const int off_ = (jl0 + e) * 32 + b;                                                                    \
-            _Pragma("unroll") for (int p = 0; p < 4; ++p) gt[D][p][e] = live ? gates_g[blk_ * 1024 + p * 256 + off_] : 0.0f; \
-            dhin[D][e] = live ? dh_g[blk_ * 256 + off_] : 0.0f;                                                     \
-            cprev[D][e] = (live && tp_ >= 0 && tp_ < T) ? cx_g[blkp_ * 256 + off_] : 0.0f;                          \
-        }                                                                                                           \
-    } while (0)
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        const size_t blk0 = ((size_t)(d ? 0 : T - 1) * 2 + d) * nkb + kb;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) ccur[d][e] = live ? cx_g[blk0 * 256 + (jl0 + e) * 32 + b] : 0.0f;
-    }
-    BPTT2_FETCH(0, 0);
-    BPTT2_FETCH(1, 0);
-    for (int s = 0; s < T; ++s) {
-#pragma unroll
-        for (int D = 0; D < 2; ++D) {
-            const int t = D ? s : (T - 1 - s);            // reverse of the forward processing order
-            const int tn = D ? (t - 1) : (t + 1);         // the step of this direction processed just before this one
-            float g_i[2], g_f[2], g_g[2], g_o[2], c_prev[2], dh_in[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { g_i[e] = gt[D][0][e]; g_f[e] = gt[D][1][e]; g_g[e] = gt[D][2][e]; g_o[e] = gt[D][3][e]; c_prev[e] = cprev[D][e]; dh_in[e] = dhin[D][e]; }
-            float rec[2] = {0.0f, 0.0f};
-            if (s > 0) {
-                // reduce-scatter, consumer side (as lstm_bptt_kernel): the producers published these slices one slot ago
-                const int gbase = (((tn * 2 + D) * NW + w) * NW) * 2048 + (wv * 32 + b) * 8 + hh * 4;
-                long long t1 = 0;
-                for (unsigned it = 0;; ++it) {
-                    unsigned raw[TPW * 8];
-#pragma unroll
-                    for (int i = 0; i < TPW * 8; ++i)
-                        raw[i] = (i < NW) ? __builtin_amdgcn_raw_buffer_load_b32(prsrc, gbase + i * 2048, 0, 16 /*sc1*/) : 0u;
-                    unsigned worst = 0;
-                    float sum[2] = {0.0f, 0.0f};
-#pragma unroll
-                    for (int i = 0; i < TPW * 8; ++i) {
-                        worst = max(worst, raw[i]);
-                        sum[0] += __uint_as_float(raw[i] << 16);
-                        sum[1] += __uint_as_float(raw[i] & 0xFFFF0000u);
-                    }
-                    if (!__any(worst == DG_POISON)) {
-                        rec[0] = sum[0]; rec[1] = sum[1];
-                        break;
-                    }
-                    if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        if (lane == 0) abort_s = 1;
-                        break;
-                    }
-                    if ((it & 255u) == 255u) {
-                        const long long now = __builtin_amdgcn_s_memrealtime();
-                        if (t1 == 0) t1 = now;
-                        else if (now - t1 > BPTT_SPIN_LIMIT_TICKS) {
-                            if (lane == 0) {
-                                __hip_atomic_store(a.status, 0x40000000u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                abort_s = 1;
-                            }
-                            break;
-                        }
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < T) BPTT2_FETCH(D, s + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- cell backward (lane-local)
-            bf16_t o4[4][2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float dhv = dh_in[e] + rec[e];
-                const float ig = g_i[e], fg = g_f[e], gg = g_g[e], og = g_o[e];
-                const float tc = tanh_fast(ccur[D][e]);
-                const float dc = fmaf(dhv * og, 1.0f - tc * tc, carry[D][e]);
-                float di = dc * gg * ig * (1.0f - ig);
-                float df = dc * c_prev[e] * fg * (1.0f - fg);
-                float dgg = dc * ig * (1.0f - gg * gg);
-                float dov = dhv * tc * og * (1.0f - og);
-                carry[D][e] = dc * fg;
-                ccur[D][e] = c_prev[e];
-                if (!live) { di = df = dgg = dov = 0.0f; carry[D][e] = 0.0f; }
-                o4[0][e] = f32_to_bf16(di); o4[1][e] = f32_to_bf16(df); o4[2][e] = f32_to_bf16(dgg); o4[3][e] = f32_to_bf16(dov);
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                *(unsigned*)(&img[D][2 * p + (wv >> 2)][((wv >> 1) & 1) * 32 + b][jl0]) = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16);
-            __syncthreads();                                // this slot's images complete (and: every wave is past its reads of img[D ^ 1])
-            if (abort_s) return;
-            bf16x8 bfr[8];
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) bfr[ks] = *(const bf16x8*)(&img[D][ks][lane][0]);
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int wc = wv * TPW + i;
-                if (wc < NW) {
-                    f32x16 acc;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[D][i][ks], bfr[ks], acc, 0, 0, 0);
-                    const int obase = (((t * 2 + D) * NW + wc) * NW + w) * 2048 + (hh * 32 + b) * 8;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const u32x2 v = {pack_bf16x2(acc[4 * q], acc[4 * q + 1]), pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3])};
-                        __builtin_amdgcn_raw_buffer_store_b64(v, prsrc, obase + q * 512, 0, 16 /*sc1: write-through*/);
-                    }
-                }
-            }
-            {
-                uint4* dst = (uint4*)(dgx_g + ((((size_t)t * 2 + D) * NW + w) * 8) * 1024);
-                dst[tid] = *(const uint4*)(&img[D][tid >> 6][tid & 63][0]);
-            }
-        }
-    }
-#undef BPTT2_FETCH
 }
 
 // dgx images -> dG [(t*B+b)*ldg + d*4H + p*H + j] bf16 (GEMM A rows) and dGT [(d*4H + p*H + j)*ldt + t*B + b] bf16
@@ -506,6 +367,9 @@ int persistent_mark(hipStream_t st);
 }
 using namespace mt;
 
+#ifdef MT_BPTT_DIAG
+extern "C" int mt_lstm_bwd_diag_read(void* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mt::g_bptt_diag), sizeof(mt::g_bptt_diag)); }
+#endif
 extern "C" size_t mt_lstm_dgx_bytes(int B, int T, int H) {
     return (size_t)((B + 31) / 32) * T * 2 * ((H + 31) / 32) * 8 * 1024;
 }
@@ -540,18 +404,6 @@ extern "C" int mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const f
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, 256, st));
     if (!(flags & 1)) MT_CHECK_HIP(hipMemsetAsync(part_ws, 0xFF, mt_lstm_bwd_part_bytes(B, T, H), st));     // poison: see the hand-off note
     LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, part_ws, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
-    // both directions interleaved in one workgroup (lstm_bptt2_kernel) unless told otherwise (flags bit 1, or MT_BPTT_MODE=1)
-    static const int mode_env = getenv("MT_BPTT_MODE") ? atoi(getenv("MT_BPTT_MODE")) : 2;
-    if (!(flags & 2) && mode_env == 2) {
-        MT_REQUIRE(NW * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * NG);
-        const void* kern2 = NW <= 8 ? (const void*)lstm_bptt2_kernel<1> : (const void*)lstm_bptt2_kernel<2>;
-        int rc2 = persistent_admit(kern2, 512, 0, NW * NG, st, "mt_lstm_bidir_bwd");
-        if (rc2 != MT_OK) return rc2;
-        if (NW <= 8) hipLaunchKernelGGL(lstm_bptt2_kernel<1>, dim3(NW, 1, NG), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL(lstm_bptt2_kernel<2>, dim3(NW, 1, NG), dim3(512), 0, st, a);
-        MT_CHECK_LAUNCH();
-        return persistent_mark(st);
-    }
     dim3 grid(NW, 2, NG);
     MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);
     // every workgroup of this persistent launch must be resident: admission check (residency.hip), completion event behind it
