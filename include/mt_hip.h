@@ -568,6 +568,11 @@ int    mt_axpby_rows_f32(const float* a, int lda, const float* b, int ldb, float
  * src: interleaved [n_in][channels], fmt 0 = int16, 1 = int32 (left-aligned), 2 = float32.  soxr-exactness: unpinned. */
 int    mt_resample_poly(const void* src, long long n_in, int channels, int fmt, const float* h, int h_len, int up, int down,
                         long long n_pre_remove, float* out, long long n_out, mt_stream_t stream);
+/* The same sum with the filter in polyphase-major order hp[phase][k] = h[phase + k*up], taps_per_phase = ceil(h_len / up) taps per
+ * phase (zero-padded): what the host path uses for its designed filter (pass band 0.913 of the lower Nyquist frequency, stop
+ * band from that Nyquist frequency, >= 120 dB: ~500 taps per output at 44.1 -> 16 kHz; music-transcription_amd/transcribe.py). */
+int    mt_resample_polyphase(const void* src, long long n_in, int channels, int fmt, const float* hp, int taps_per_phase, int up, int down,
+                             long long n_pre_remove, float* out, long long n_out, mt_stream_t stream);
 
 #ifdef __cplusplus
 }

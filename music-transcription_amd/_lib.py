@@ -179,6 +179,7 @@ _SIGS = {
     "mt_dropout_f32": (i32, [vp, ll, C.c_float, C.c_uint, C.c_uint, vp]),
     "mt_axpby_rows_f32": (i32, [vp, i32, vp, i32, vp, i32, ll, i32, C.c_float, C.c_float, vp]),
     "mt_resample_poly": (i32, [vp, ll, i32, i32, vp, i32, i32, i32, ll, vp, ll, vp]),
+    "mt_resample_polyphase": (i32, [vp, ll, i32, i32, vp, i32, i32, i32, ll, vp, ll, vp]),
     "mt_cnnrnn_workspace_bytes": (sz, [C.POINTER(CnnRnnWeights), i32, i32]),
     "mt_cnnrnn_status_offset": (sz, [C.POINTER(CnnRnnWeights), i32, i32, i32]),
     "mt_cnnrnn_forward": (i32, [C.POINTER(CnnRnnWeights), vp, vp, i32, i32, vp, vp, sz, vp]),

@@ -53,9 +53,44 @@ __global__ __launch_bounds__(256) void resample_poly_kernel(const void* __restri
     }
 }
 
+// The same sum with the filter in polyphase-major order hp[phase][k] = h[phase + k*up] (L taps per phase, zero-padded): output j
+// needs phase (j + n_pre_remove)*down % up and inputs i_hi, i_hi - 1, ...: its L taps are contiguous (the designed filter is
+// ~500 taps per output at 44.1 -> 16 kHz, 316 KB in all: too long for LDS, and in h's natural order a wave's reads of one tap
+// would touch 64 lines `up` floats apart; here consecutive taps of a lane share lines).
+template <int FMT>
+__global__ __launch_bounds__(256) void resample_polyphase_kernel(const void* __restrict__ src, long long n_in, int channels,
+                                                                 const float* __restrict__ hp, int L, int up, int down,
+                                                                 long long n_pre_remove, float* __restrict__ out, long long n_out) {
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n_out; j += (long long)gridDim.x * 256) {
+        const long long c = (j + n_pre_remove) * down;                 // position on the upsampled grid
+        const long long i_hi = c / up;                                 // tap k multiplies x[i_hi - k]
+        const float* row = hp + (size_t)(c - i_hi * up) * L;
+        int k_lo = (int)max(0ll, i_hi - (n_in - 1));
+        int k_hi = (int)min((long long)L - 1, i_hi);
+        float acc = 0.0f;
+        for (int k = k_lo; k <= k_hi; ++k) acc = fmaf(load_mono<FMT>(src, i_hi - k, channels), row[k], acc);
+        out[j] = acc;
+    }
+}
+
 }  // namespace mt
 
 using namespace mt;
+
+extern "C" int mt_resample_polyphase(const void* src, long long n_in, int channels, int fmt, const float* hp, int taps_per_phase, int up, int down,
+                                     long long n_pre_remove, float* out, long long n_out, mt_stream_t stream) {
+    MT_REQUIRE(src && hp && out && n_in > 0 && n_out > 0 && channels > 0 && channels <= 8 && taps_per_phase > 0 && up > 0 && down > 0 && n_pre_remove >= 0,
+               MT_EINVAL, "mt_resample_polyphase: bad arguments");
+    MT_REQUIRE(fmt >= 0 && fmt <= 2, MT_EINVAL, "mt_resample_polyphase: fmt must be 0 (int16), 1 (int32) or 2 (float32)");
+    long long g = (n_out + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipStream_t st = (hipStream_t)stream;
+    if (fmt == 0) hipLaunchKernelGGL(resample_polyphase_kernel<0>, dim3((unsigned)g), dim3(256), 0, st, src, n_in, channels, hp, taps_per_phase, up, down, n_pre_remove, out, n_out);
+    else if (fmt == 1) hipLaunchKernelGGL(resample_polyphase_kernel<1>, dim3((unsigned)g), dim3(256), 0, st, src, n_in, channels, hp, taps_per_phase, up, down, n_pre_remove, out, n_out);
+    else hipLaunchKernelGGL(resample_polyphase_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, src, n_in, channels, hp, taps_per_phase, up, down, n_pre_remove, out, n_out);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
 
 // up == down == 1 degenerates to the channel mean + PCM scaling.
 extern "C" int mt_resample_poly(const void* src, long long n_in, int channels, int fmt, const float* h, int h_len, int up, int down,

@@ -16,7 +16,7 @@ from __future__ import annotations
 import os
 import struct
 from pathlib import Path
-from typing import List, Tuple
+from typing import Optional, List, Tuple
 
 import numpy as np
 import torch
@@ -30,20 +30,45 @@ MODEL_TYPE, N_MELS, HIDDEN_SIZE, NUM_LAYERS, DROPOUT = "cnn_rnn_large", 320, 512
 SR, HOP_LENGTH, CHUNK_LENGTH, THRESHOLD = 16000, 512, 30.0, 0.5                                # main.py:21-24
 
 
-def resample_plan(rate_in: int, rate_out: int, n_in: int):
-    """Polyphase plan with scipy.signal.resample_poly's conventions (Kaiser(5.0) windowed sinc of 2*10*max(up,down)+1
-    taps, scaled by `up`, pre-padded so that output sample j sits at input time j*down/up): returns
-    (up, down, h float32, n_pre_remove, n_out).  up == down == 1 -> a one-tap identity plan."""
+# Anti-alias / anti-image filter of the GPU resampler.  librosa.load(sr=16000) resamples with soxr_hq (main.py:76,
+# data/dataset.py:124-130); soxr is not available here, so the filter is DESIGNED to soxr's published HQ figures instead of
+# copied from it: pass band up to 0.913 of the lower Nyquist frequency, stop band from that Nyquist frequency on (no aliasing
+# into the band at all), >= 120 dB of rejection (HQ is specified as 20-bit precision).  A Kaiser-windowed sinc on the
+# up-sampled grid meets that by construction (scipy.signal.kaiserord); tests/test_host_cpu.py checks the realised frequency
+# response.  mel's fmax = 8000 Hz = the Nyquist frequency of the 16 kHz signal, so the roll-off between 7.3 and 8 kHz does land
+# in the top mel bins -- as soxr's does; tests/test_gpu_parity.py bounds what a 4x longer filter would change there.
+RESAMPLE_PASSBAND = 0.913        # of the lower of the two Nyquist frequencies
+RESAMPLE_STOPBAND = 1.0
+RESAMPLE_REJECTION_DB = 120.0
+
+
+def resample_fir(up: int, down: int, passband: float = RESAMPLE_PASSBAND, stopband: float = RESAMPLE_STOPBAND,
+                 rejection_db: float = RESAMPLE_REJECTION_DB) -> np.ndarray:
+    """Prototype low-pass on the up-sampled grid (rate_in * up), odd length, unit DC gain (scipy.signal.resample_poly scales it
+    by `up`): edges relative to the grid's Nyquist frequency are passband / max(up, down) and stopband / max(up, down)."""
+    from scipy.signal import firwin, kaiserord
+    m = float(max(up, down))
+    width = (stopband - passband) / m
+    n, beta = kaiserord(rejection_db, width)
+    n |= 1
+    return firwin(n, 0.5 * (passband + stopband) / m, window=("kaiser", beta))
+
+
+def resample_plan(rate_in: int, rate_out: int, n_in: int, fir: Optional[np.ndarray] = None):
+    """Polyphase plan with scipy.signal.resample_poly's conventions for a given prototype filter (default: resample_fir): the
+    filter scaled by `up` and pre-padded so that output sample j sits at input time j*down/up.  Returns
+    (up, down, h float32, n_pre_remove, n_out); y[j] = sum_i x[i] h[(j + n_pre_remove) * down - i * up], which is
+    scipy.signal.resample_poly(x, up, down, window=fir) -- the structural oracle of the tests.  up == down == 1 -> a one-tap
+    identity plan."""
     from math import gcd
     g = gcd(int(rate_in), int(rate_out))
     up, down = int(rate_out) // g, int(rate_in) // g
     if up == down == 1:
         return 1, 1, np.ones(1, np.float32), 0, n_in
-    from scipy.signal import firwin
     n_out = (n_in * up + down - 1) // down
-    max_rate = max(up, down)
-    half_len = 10 * max_rate
-    h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)) * up
+    proto = resample_fir(up, down) if fir is None else np.asarray(fir, dtype=np.float64)
+    half_len = (len(proto) - 1) // 2
+    h = proto * up
     n_pre_pad = down - half_len % down
     n_pre_remove = (half_len + n_pre_pad) // down
 
@@ -55,6 +80,14 @@ def resample_plan(rate_in: int, rate_out: int, n_in: int):
         n_post_pad += 1
     h = np.concatenate([np.zeros(n_pre_pad), h, np.zeros(n_post_pad)]).astype(np.float32)
     return up, down, h, n_pre_remove, n_out
+
+
+def polyphase_table(h: np.ndarray, up: int) -> np.ndarray:
+    """h[(phase) + k*up] -> table[phase][k] (zero-padded): the taps one output sample needs are then contiguous."""
+    L = (len(h) + up - 1) // up
+    t = np.zeros(L * up, dtype=np.float32)
+    t[:len(h)] = h
+    return np.ascontiguousarray(t.reshape(L, up).T)
 
 
 _PLAN_FILTERS = {}
@@ -139,13 +172,13 @@ def load_audio_device(path: str, sr: int = SR, device="cuda") -> torch.Tensor:
     dev = torch.device(device)
     key = (up, down, len(h), str(dev))
     if key not in _PLAN_FILTERS:
-        _PLAN_FILTERS[key] = torch.from_numpy(h).to(dev)
-    hd = _PLAN_FILTERS[key]
+        _PLAN_FILTERS[key] = torch.from_numpy(polyphase_table(h, up)).to(dev)
+    hd = _PLAN_FILTERS[key]                              # [up][taps per phase]
     src = torch.from_numpy(np.ascontiguousarray(data)).to(dev, non_blocking=True)
     out = torch.empty(n_out, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib.mt_resample_poly(_lib.ptr(src), n_in, ch, fmt, _lib.ptr(hd), len(h), up, down, n_pre_remove, _lib.ptr(out), n_out,
-                                             _lib.stream_ptr()), "mt_resample_poly")
+        _lib.check(_lib.lib.mt_resample_polyphase(_lib.ptr(src), n_in, ch, fmt, _lib.ptr(hd), hd.shape[1], up, down, n_pre_remove, _lib.ptr(out), n_out,
+                                                  _lib.stream_ptr()), "mt_resample_polyphase")
     return out
 
 

@@ -96,3 +96,97 @@ def test_f1_parity_cnnrnn_canonical_trained_scale(mta, dtype):
 def test_f1_parity_cnnrnn_large_canonical_trained_scale(mta, dtype):
     out = _run(mta, "cnn_rnn_large", seed=202, dtype=dtype)
     assert out["rel"] < REL_TOL[dtype], out
+
+
+# ------------------------------------------------------------------ hardened evidence (round 3)
+# The licence for f16 operands must not rest on one seed, one label-noise level, one recurrence gain and unpadded T = 938:
+#   * 2 seeds x 8 chunks, W_hh gain in {3, 4} (gain 4 makes the LSTM's own dynamics amplify input perturbations: DESIGN.md 2);
+#   * labels y = [fp32 logit + N(0, sigma) > 0] with sigma in {1.0, 0.3}: with sigma = 0.3 the F1 is decided by the cells near the
+#     threshold, exactly the ones a rounding difference can flip;
+#   * a cached-format batch (T = 937) of RAGGED chunks right-padded with 0.0 dB as collate_fn does
+#     (train/train_transcriber.py:23-39): the padding leaks into valid frames through the bi-LSTM and the attention
+#      and the metric is per-sample F1 over the VALID frames only (scripts/evaluate.py:361-378).
+# Every row asserts |dF1| <= 0.002 at threshold 0.5 and at the fp32-tuned threshold, and the table is printed.
+N_HARD = 8
+
+
+def _hip_logits(mta, model_type, sd, mel_dev, cmax=None):
+    model = mta.TranscriptionModel(model_type, n_mels=320, hidden_size=512, num_layers=3, device="cuda")
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    with torch.no_grad():
+        out = model.model(mel_dev, check_status=True) if cmax is None else model.model(mel_dev, chunk_max_power=cmax, check_status=True)
+    return out.float().cpu()
+
+
+def _f1_valid(logits, rolls, lengths, thr):
+    preds = (torch.sigmoid(logits) > thr).float().numpy()
+    return R.mean_f1(preds, rolls, list(lengths))
+
+
+@pytest.mark.parametrize("model_type", ["cnn_rnn", "cnn_rnn_large"])
+def test_f1_parity_matrix_seeds_noise_gain(mta, model_type):
+    rows, worst = [], 0.0
+    fe = mta.MelFrontend(16000, 320, 512, "cuda")
+    for seed in (303, 404):
+        wave = FR.synth_audio(N_HARD, 480000, seed=seed)
+        mel_ref = torch.from_numpy(FR.audio_to_mel_batch(wave))
+        with torch.no_grad():
+            mel_dev, _ = fe(torch.from_numpy(wave).cuda(), clamp=True)
+        sd0 = R.make_state_dict(model_type, 320, 512, 3, seed=seed + 1)
+        for gain in (3.0, 4.0):
+            sd, _ = R.trained_scale_state_dict(sd0, model_type, mel_ref[:1], w_hh_gain=gain)
+            with torch.no_grad():
+                ref = R.forward(sd, mel_ref, model_type, o=R.Opts(fast_lstm=True))
+            got = _hip_logits(mta, model_type, sd, mel_dev)
+            rel = float((got - ref).abs().max() / ref.abs().max())
+            for sigma in (1.0, 0.3):
+                g = torch.Generator().manual_seed(seed + int(10 * sigma) + int(gain))
+                rolls = ((ref + sigma * torch.randn(ref.shape, generator=g)) > 0).float().numpy()
+                thr = _tune(ref, rolls)
+                for name, t in (("0.5", 0.5), ("tuned", thr)):
+                    fr, fh = _f1_at(ref, rolls, t), _f1_at(got, rolls, t)
+                    rows.append((seed, gain, sigma, name, t, fr, fh, fh - fr, rel))
+                    worst = max(worst, abs(fh - fr))
+    print(f"\n[{model_type} f16] seed gain sigma thr  F1 fp32 -> HIP (delta)  max|dlogit|/max|logit|")
+    for r_ in rows:
+        print(f"  {r_[0]} {r_[1]:.0f} {r_[2]:.1f} {r_[3]:>5s}={r_[4]:.2f}  {r_[5]:.5f} -> {r_[6]:.5f} ({r_[7]:+.5f})  {r_[8]:.4f}")
+    assert worst <= F1_TOL, (worst, rows)
+    assert max(r_[8] for r_ in rows) < 2.5e-2          # (gain 4: the recurrence amplifies the operand rounding; F1 is what is licensed)
+
+
+@pytest.mark.parametrize("model_type", ["cnn_rnn", "cnn_rnn_large"])
+def test_f1_parity_ragged_batch_padded_with_zero_db(mta, model_type):
+    """Cached-format chunks (mel dB already clamped, T = 937), ragged lengths >= 50 % (data/dataset.py:82), right-padded with 0.0
+    exactly as collate_fn pads: the same padded tensor goes through the HIP model and the fp32 oracle; per-sample F1 over the
+    valid frames."""
+    from music_transcription_amd import collate_fn
+    seed, T = 505, 937
+    wave = FR.synth_audio(N_HARD, 480000, seed=seed)
+    mel_full = FR.audio_to_mel_batch(wave)[:, 0, :, :T]                      # (B, 320, 937): what the cache stores per chunk
+    lengths = [937, 470, 800, 937, 600, 512, 700, 900]
+    g = torch.Generator().manual_seed(seed)
+    batch = [(torch.from_numpy(mel_full[i][None, :, :lengths[i]].copy()), torch.zeros(88, lengths[i])) for i in range(N_HARD)]
+    mel_pad, _, lens = collate_fn(batch)                                     # (B, 1, 320, 937), pad value 0.0
+    assert mel_pad.shape == (N_HARD, 1, 320, T) and float(mel_pad[1, 0, :, 500:].abs().max()) == 0.0
+    sd0 = R.make_state_dict(model_type, 320, 512, 3, seed=seed + 1)
+    sd, _ = R.trained_scale_state_dict(sd0, model_type, mel_pad[:1])
+    with torch.no_grad():
+        ref = R.forward(sd, mel_pad, model_type, o=R.Opts(fast_lstm=True))
+    got = _hip_logits(mta, model_type, sd, mel_pad.cuda())
+    assert got.shape == ref.shape == (N_HARD, 88, T)
+    lens = [int(v) for v in lens]
+    worst = 0.0
+    for sigma in (1.0, 0.3):
+        rolls = ((ref + sigma * torch.randn(ref.shape, generator=g)) > 0).float().numpy()
+        for i, L in enumerate(lens):
+            rolls[i, :, L:] = 0.0
+        for t in (0.5, 0.3):
+            fr, fh = _f1_valid(ref, rolls, lens, t), _f1_valid(got, rolls, lens, t)
+            print(f"\n[{model_type} ragged 0-dB-padded T=937] sigma={sigma} thr={t}: F1 fp32 {fr:.5f} -> HIP {fh:.5f} ({fh - fr:+.5f})")
+            worst = max(worst, abs(fh - fr))
+    valid = torch.zeros(ref.shape, dtype=torch.bool)
+    for i, L in enumerate(lens):
+        valid[i, :, :L] = True
+    print(f"max|dlogit| on valid frames {float((got - ref).abs()[valid].max()):.4f} of max|logit| {float(ref.abs()[valid].max()):.2f}")
+    assert worst <= F1_TOL, worst

@@ -214,13 +214,14 @@ def test_chunking_notes_and_midi_writer(mta, tmp_path):
     raw = p.read_bytes()
     assert raw[:4] == b"MThd" and raw[8:14] == bytes([0, 1, 0, 2, 0, 220]) and raw.count(b"MTrk") == 2
     assert raw.count(bytes([0x90, 60, 100])) == 2 and raw.endswith(b"\xFF\x2F\x00")
-    # the resampling plan handed to the GPU kernel reproduces scipy.signal.resample_poly (evaluated here in numpy)
+    # the resampling plan handed to the GPU kernel reproduces scipy.signal.resample_poly with the SAME prototype filter
+    # (evaluated here in numpy, natural and polyphase-major tap order)
     from scipy.signal import resample_poly
     rng = np.random.default_rng(0)
     for rate, n_in in ((44100, 5000), (48000, 3001), (22050, 777), (8000, 500)):
         x = rng.standard_normal(n_in)
         up, down, h, npr, n_out = tr.resample_plan(rate, 16000, n_in)
-        ref = resample_poly(x, up, down)
+        ref = resample_poly(x, up, down, window=tr.resample_fir(up, down))
         assert n_out == len(ref)
         j = np.arange(n_out)[:, None]
         i = np.arange(n_in)[None, :]
@@ -228,6 +229,8 @@ def test_chunking_notes_and_midi_writer(mta, tmp_path):
         ok = (idx >= 0) & (idx < len(h))
         y = (np.where(ok, h.astype(np.float64)[np.clip(idx, 0, len(h) - 1)], 0.0) * x[None, :]).sum(1)
         assert np.abs(y - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+        tab = tr.polyphase_table(h, up)
+        assert tab.shape[0] == up and all(tab[ph, k] == h[ph + k * up] for ph in (0, up - 1) for k in (0, 1, tab.shape[1] // 2) if ph + k * up < len(h))
     assert tr.resample_plan(16000, 16000, 123)[:2] == (1, 1)
 
 
@@ -291,3 +294,26 @@ def test_compressed_audio_goes_through_a_host_decoder(mta, tmp_path, monkeypatch
     rate, data = tr.decode_compressed_host(str(mp3))
     assert rate == 44100 and data.shape == (44100, 2) and data.dtype == np.float32
     assert abs(pp.wav_duration(str(tmp_path / "rec.wav")) - 1.0) < 1e-9          # through the .wav -> .mp3 fallback
+
+
+def test_resampling_filter_meets_its_stated_spec():
+    """The designed anti-alias filter (transcribe.resample_fir; librosa's soxr_hq is not available: SURVEY 8 f3): realised
+    frequency response for the rates MAESTRO ships (44.1 and 48 kHz) and for an up-sampling case -- pass band flat to 0.01 dB
+    up to 0.913 of the lower Nyquist frequency, >= 110 dB down from that Nyquist frequency on (design: 120 dB), unit DC gain."""
+    from math import gcd
+    from music_transcription_amd import transcribe as tr
+    for rate_in, rate_out in ((44100, 16000), (48000, 16000), (8000, 16000)):
+        g = gcd(rate_in, rate_out)
+        up, down = rate_out // g, rate_in // g
+        h = tr.resample_fir(up, down)
+        assert len(h) % 2 == 1 and abs(h.sum() - 1.0) < 1e-9 and np.allclose(h, h[::-1])
+        nfft = 1 << 22
+        H = np.abs(np.fft.rfft(h, nfft))
+        f = np.arange(len(H)) / nfft * rate_in * up                     # Hz on the up-sampled grid
+        nyq = min(rate_in, rate_out) / 2.0
+        pb = H[f <= tr.RESAMPLE_PASSBAND * nyq]
+        sb = H[f >= tr.RESAMPLE_STOPBAND * nyq]
+        assert np.abs(20 * np.log10(pb)).max() < 0.01, (rate_in, np.abs(20 * np.log10(pb)).max())
+        assert 20 * np.log10(sb.max()) < -110.0, (rate_in, 20 * np.log10(sb.max()))
+        taps_per_output = len(h) / up
+        assert taps_per_output < 700                                    # cost bound: ~500 taps per output sample
