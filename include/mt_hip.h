@@ -275,6 +275,12 @@ int    mt_attn_softmax_clamped(const float* S, int lds, void* P, int Tp, int T, 
                                float scale, float clip, mt_stream_t stream);
 int    mt_attn_transpose_v(const void* qkv, int ld3, int voff, void* VT, int B, int T, int Tp,
                            int heads, int dp, mt_stream_t stream);
+/* Fused attention core (eval mode): ao[(t*B+b)*ldo + head*dp + d] = sum_j softmax_j(clamp(Q K^T * scale, +-clip))[t][j] V[j][d] per
+ * (chunk, head), scores never written (cnn_rnn_model.py:118-139: scale, clamp BEFORE softmax -- so exp() needs no running
+ * maximum).  qkv [(t*B+b)][ld3]: Q at column head*dp, K at Ca + head*dp (16-bit, dt); VT as mt_attn_transpose_v writes it for
+ * Tp = roundup(T, 64).  dp in {64, 128, 192} (else MT_EUNSUPPORTED), clip <= 10.  csrc/attn_fused.hip.                       */
+int    mt_attn_fused_clamped(const void* qkv, int ld3, int Ca, const void* VT, int Tp, int B, int T, int heads, int dp,
+                             float scale, float clip, void* ao, int ldo, int dt, mt_stream_t stream);
 int    mt_layernorm_residual(const float* resid, int ldr, const float* proj, int ldp, const float* gamma,
                              const float* beta, void* y, int ldy, long long rows, int n, float eps,
                              mt_stream_t stream);

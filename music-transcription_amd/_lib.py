@@ -118,6 +118,7 @@ _SIGS = {
     "mt_lstm_relayout_ex": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "mt_attn_softmax_clamped": (i32, [vp, i32, vp, i32, i32, ll, C.c_float, C.c_float, vp]),
     "mt_attn_transpose_v": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "mt_attn_fused_clamped": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, C.c_float, C.c_float, vp, i32, i32, vp]),
     "mt_layernorm_residual": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, ll, i32, C.c_float, vp]),
     "mt_cnnrnn_large_workspace_bytes": (sz, [C.POINTER(CnnRnnLargeWeights), i32, i32]),
     "mt_cnnrnn_large_status_offset": (sz, [C.POINTER(CnnRnnLargeWeights), i32, i32, i32]),

@@ -23,6 +23,7 @@ int mt_gemm_lstm_gx_from_hx_sched(const float*, const void*, int, const float*, 
 int mt_lstm_bidir_fwd_xproj(const float*, const float*, const float*, const float*, float*, void*, size_t, int, int, int, mt_stream_t);
 int mt_attn_softmax_clamped_dt(const float*, int, void*, int, int, long long, float, float, int, mt_stream_t);
 int mt_attn_transpose_v(const void*, int, int, void*, int, int, int, int, int, mt_stream_t);
+int mt_attn_fused_clamped(const void*, int, int, const void*, int, int, int, int, int, float, float, void*, int, int, mt_stream_t);
 int mt_layernorm_residual_dt(const float*, int, const float*, int, const float*, const float*, void*, int, long long, int, float, int, mt_stream_t);
 size_t mt_lstm_gx_bytes(int, int, int);
 size_t mt_lstm_hx_bytes(int, int, int);
@@ -67,8 +68,10 @@ static LargePlan lplan(const mt_cnnrnn_large_weights* w, int B, int T) {
     p.rb = take((size_t)p.Mpad * p.Cp * 2);
     p.r32 = take((size_t)p.M * p.comb * 4);
     p.qkv = take((size_t)p.Tr * B * p.ld3 * 2);
-    p.S = take((size_t)B * w->heads * T * p.Tp * 4);
-    p.P = take((size_t)B * w->heads * p.Tr * p.Tp * 2);
+    // fused attention core (csrc/attn_fused.hip; head sizes 64 / 128 / 192): the scores are never written -- no S, no P
+    const bool fused_attn = p.dp == 64 || p.dp == 128 || p.dp == 192;
+    p.S = take(fused_attn ? 0 : (size_t)B * w->heads * T * p.Tp * 4);
+    p.P = take(fused_attn ? 0 : (size_t)B * w->heads * p.Tr * p.Tp * 2);
     p.VT = take((size_t)B * w->heads * align_up((size_t)p.dp, 128) * p.Tp * 2);
     p.ao = take((size_t)p.Mpad * p.Ca * 2);
     p.proj = take((size_t)p.M * p.comb * 4);
@@ -194,16 +197,21 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
         // qkv projection (rows up to Tr*B are readable as padding of the per-head GEMMs below)
         RUN(mt_gemm_batched_h16out_dt(ws + p.rb, p.Cp, 0, 0, w->qkv_w, p.Cp, 0, 0, w->qkv_b, ws + p.qkv, p.ld3, 0, 0, p.M, p.ld3, p.Cp, 1, 1, 0, dt, stream));
         const bf16_t* qkv = (const bf16_t*)(ws + p.qkv);
-        // S[b][head] = Q K^T : A rows t -> qkv row t*B+b (lda = B*ld3), batch z = b*heads + head
-        RUN(mt_gemm_batched_f32_dt(qkv, B * p.ld3, p.ld3, dp, qkv + p.Ca, B * p.ld3, p.ld3, dp, nullptr, (float*)(ws + p.S), p.Tp,
-                                (long long)heads * T * p.Tp, (long long)T * p.Tp, T, T, dp, B * heads, heads, dt, stream));
-        RUN(mt_attn_softmax_clamped_dt((const float*)(ws + p.S), p.Tp, ws + p.P, p.Tp, T, (long long)B * heads * T, w->attn_scale, 10.0f, dt, stream));
-        // P is [B*heads][T][Tp]; the PV GEMM may read A rows up to roundup(T,128) of a head, i.e. into the next head's
-        // rows (or the buffer's tail, sized for it): those rows only feed masked outputs.
         RUN(mt_attn_transpose_v(qkv, p.ld3, 2 * p.Ca, ws + p.VT, B, T, p.Tp, heads, dp, stream));
-        RUN(mt_gemm_batched_h16out_dt(ws + p.P, p.Tp, (long long)heads * T * p.Tp, (long long)T * p.Tp, ws + p.VT, p.Tp,
-                                    (long long)heads * align_up((size_t)dp, 128) * p.Tp, (long long)align_up((size_t)dp, 128) * p.Tp, nullptr,
-                                    ws + p.ao, B * p.Ca, p.Ca, dp, T, dp, p.Tp, B * heads, heads, 0, dt, stream));
+        if (dp == 64 || dp == 128 || dp == 192) {
+            // QK^T -> scale -> clamp +-10 -> exp -> P V in ONE kernel per (chunk, head, 256 queries); S and P never reach memory
+            RUN(mt_attn_fused_clamped(qkv, p.ld3, p.Ca, ws + p.VT, p.Tp, B, T, heads, dp, w->attn_scale, 10.0f, ws + p.ao, p.Ca, dt, stream));
+        } else {
+            // S[b][head] = Q K^T : A rows t -> qkv row t*B+b (lda = B*ld3), batch z = b*heads + head
+            RUN(mt_gemm_batched_f32_dt(qkv, B * p.ld3, p.ld3, dp, qkv + p.Ca, B * p.ld3, p.ld3, dp, nullptr, (float*)(ws + p.S), p.Tp,
+                                    (long long)heads * T * p.Tp, (long long)T * p.Tp, T, T, dp, B * heads, heads, dt, stream));
+            RUN(mt_attn_softmax_clamped_dt((const float*)(ws + p.S), p.Tp, ws + p.P, p.Tp, T, (long long)B * heads * T, w->attn_scale, 10.0f, dt, stream));
+            // P is [B*heads][T][Tp]; the PV GEMM may read A rows up to roundup(T,128) of a head, i.e. into the next head's
+            // rows (or the buffer's tail, sized for it): those rows only feed masked outputs.
+            RUN(mt_gemm_batched_h16out_dt(ws + p.P, p.Tp, (long long)heads * T * p.Tp, (long long)T * p.Tp, ws + p.VT, p.Tp,
+                                        (long long)heads * align_up((size_t)dp, 128) * p.Tp, (long long)align_up((size_t)dp, 128) * p.Tp, nullptr,
+                                        ws + p.ao, B * p.Ca, p.Ca, dp, T, dp, p.Tp, B * heads, heads, 0, dt, stream));
+        }
         RUN(mt_gemm_batched_f32_dt(ws + p.ao, p.Ca, 0, 0, w->proj_w, p.Ca, 0, 0, w->proj_b, (float*)(ws + p.proj), p.comb, 0, 0, p.M, p.comb, p.Ca, 1, 1, dt, stream));
         if (p.Cp != p.comb) MT_CHECK_HIP(hipMemsetAsync(ws + p.ln, 0, (size_t)p.Mpad * p.Cp * 2, st));
         RUN(mt_layernorm_residual_dt((const float*)(ws + p.r32), p.comb, (const float*)(ws + p.proj), p.comb, w->ln_g, w->ln_b, ws + p.ln, p.Cp,

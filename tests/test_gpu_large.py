@@ -86,6 +86,38 @@ def test_attention_pieces(mta):
     assert (y[:, :n].float().cpu() - ref).abs().max().item() < 3e-2 and float(y[:, n:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,T,heads,dp,dt", [(2, 938, 8, 192, "f16"), (3, 100, 2, 64, "bf16"), (1, 65, 1, 128, "f16"), (2, 937, 3, 192, "f16")])
+def test_attention_fused_matches_torch(mta, B, T, heads, dp, dt):
+    """csrc/attn_fused.hip against the module's own arithmetic (cnn_rnn_model.py:118-139) in fp32 on the same 16-bit q, k, v:
+    scale, clamp +-10 BEFORE the softmax (a third of the scores here are at the clamp), softmax over all T keys (no mask), P V.
+    Rows whose query index is past T are not written; every other output column of the row is."""
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr, DT_F16, DT_BF16
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    Ca, ld3, ldo = heads * dp, 3 * heads * dp, heads * dp
+    scale = float(dp) ** -0.5
+    qkv = (torch.randn(T * B, ld3, generator=g) * 1.5).to(tdt)
+    qkv[:, :Ca] *= 3.0                                                    # |q k| * scale reaches +-10 and beyond (14 % of the scores)
+    Tp = (T + 63) // 64 * 64
+    dpr = (dp + 127) // 128 * 128
+    qd = qkv.cuda()
+    VT = torch.zeros(B * heads * dpr * Tp, dtype=tdt, device="cuda")
+    ao = torch.full((T * B, ldo), 7.0, dtype=tdt, device="cuda")
+    st = stream_ptr()
+    code = DT_F16 if dt == "f16" else DT_BF16
+    check(lib.mt_attn_transpose_v(ptr(qd), ld3, 2 * Ca, ptr(VT), B, T, Tp, heads, dp, st))
+    check(lib.mt_attn_fused_clamped(ptr(qd), ld3, Ca, ptr(VT), Tp, B, T, heads, dp, scale, 10.0, ptr(ao), ldo, code, st))
+    torch.cuda.synchronize()
+    x = qkv.float().view(T, B, 3, heads, dp)
+    q, k, v = (x[:, :, i].permute(1, 2, 0, 3) for i in range(3))          # (B, heads, T, dp)
+    sc = torch.clamp(q @ k.transpose(-1, -2) * scale, -10.0, 10.0)
+    assert float((sc.abs() >= 10.0).float().mean()) > 0.05
+    ref = (torch.softmax(sc, -1) @ v).permute(2, 0, 1, 3).reshape(T * B, ldo)
+    got = ao.float().cpu()
+    tol = (4e-3 if dt == "f16" else 3e-2) * float(ref.abs().max())
+    assert float((got - ref).abs().max()) < tol, (float((got - ref).abs().max()), tol)
+
+
 @pytest.mark.parametrize("tag", ["large_a", "large_b"])
 def test_large_small_configs_vs_reference_golden(mta, golden_dir, tag):
     z = np.load(os.path.join(golden_dir, "small_models.npz"))
