@@ -182,11 +182,21 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #undef CG_READ
 #undef CG_MFMA
 
-    // ---- epilogue: + bias, (pool), (ReLU), bf16 store
+    // ---- epilogue: + bias, (pool), (ReLU), 16-bit store
     const int Fo = POOL ? a.F / 2 : a.F;
+    // Straight from the accumulators a lane stores single 16-bit values (lanes = channels: 64 contiguous bytes per position and
+    // half-wave), 32-64 store instructions per wave -- at ~70 cycles of store path per wave-instruction that was 2-4 thousand
+    // cycles per tile against 1 150 cycles of MFMAs for a residual block's first convolution (K = 288): the residual blocks ran
+    // at 18 % of the matrix peak because of their epilogue.  The tile's rows are contiguous in memory (channels-last: BN_ x 2
+    // bytes per position, 16 consecutive frames per frequency row), so they go through LDS (the input / weight buffers are free
+    // after the main loop's last barrier) and leave as 16-byte stores, 1 KB per wave-instruction.  (accum / tie: training
+    // paths, kept on the direct form.)
+    constexpr int NP = POOL ? (CG_TF / 2) * CG_TT : CG_TF * CG_TT;     // output positions of the tile
+    const bool staged = !a.accum && !a.tie && (OUT == CG_OUT_CL || (a.ldx & 7) == 0);
+    bf16_t* stg = (bf16_t*)smem;                                        // [NP][BN_]
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int co = n0 + wn * (BN_ / 2) + j * 32 + r;
+        const int col = wn * (BN_ / 2) + j * 32 + r, co = n0 + col;
         const float bv = a.bias[co];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
             for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    const int t = t0 + p + 8 * qq + 4 * h;
+                    const int tl = p + 8 * qq + 4 * h, t = t0 + tl;
                     if (!POOL && a.tie) {                  // (uniform branch: every lane takes part in the ballots)
                         const float z0 = acc[i][j][4 * qq + p], z1 = acc[i][j][4 * (qq + 2) + p];
                         const unsigned long long gt = __ballot(z0 > z1), lt = __ballot(z0 < z1);
@@ -205,8 +215,21 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
                             a.tie[w_ + 1] = (unsigned)(h ? lt >> 32 : lt);
                         }
                     }
-                    if (t >= a.T) continue;
                     const float v0 = acc[i][j][4 * qq + p] + bv, v1 = acc[i][j][4 * (qq + 2) + p] + bv;
+                    if (staged) {
+                        if (POOL) {
+                            float v = fmaxf(v0, v1);
+                            if (a.relu) v = fmaxf(v, 0.0f);
+                            stg[((2 * wm + i) * CG_TT + tl) * BN_ + col] = f32_to_h16<DT>(v);
+                        } else {
+                            float u0 = v0, u1 = v1;
+                            if (a.relu) { u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
+                            stg[((4 * wm + 2 * i) * CG_TT + tl) * BN_ + col] = f32_to_h16<DT>(u0);
+                            stg[((4 * wm + 2 * i + 1) * CG_TT + tl) * BN_ + col] = f32_to_h16<DT>(u1);
+                        }
+                        continue;
+                    }
+                    if (t >= a.T) continue;
                     if (POOL) {
                         const int fo = (f0 >> 1) + 2 * wm + i;
                         if (fo >= Fo) continue;
@@ -229,6 +252,20 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
                 }
         }
     }
+    if (staged) {
+        __syncthreads();
+        constexpr int UPP = BN_ / 8;                                    // 16-byte units per position
+        const int fbase = POOL ? (f0 >> 1) : f0;
+#pragma unroll 2
+        for (int u = tid; u < NP * UPP; u += 512) {
+            const int pos = u / UPP, c = u - pos * UPP, f = fbase + (pos >> 4), t = t0 + (pos & 15);
+            if (f < Fo && t < a.T) {
+                bf16_t* o = OUT == CG_OUT_CL ? a.out + (((size_t)b * Fo + f) * a.T + t) * a.Cout + n0 + c * 8
+                                             : a.out + ((size_t)t * a.B + b) * a.ldx + (size_t)f * a.Cout + n0 + c * 8;
+                *(uint4*)o = *(const uint4*)(stg + (size_t)pos * BN_ + c * 8);
+            }
+        }
+    }
 #undef CG_WLOAD
 #undef CG_WSTORE
 #undef CG_WSWZ
@@ -238,7 +275,9 @@ template <int KC, int BN_, bool POOL, int OUT, int DT>
 static int cg_launch(const ConvGArgs& a, hipStream_t st) {
     const int nc1 = a.C1 / 8, pr1 = 16 / nc1 > 0 ? 16 / nc1 : 1;
     const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
-    const size_t lds = (size_t)(CG_TF + a.KH - 1) * pitch1 * a.C1 * 2 + (a.C2 ? (size_t)CG_TF * CG_TT * a.C2 * 2 : 0) + 2 * BN_ * KC * 2;
+    size_t lds = (size_t)(CG_TF + a.KH - 1) * pitch1 * a.C1 * 2 + (a.C2 ? (size_t)CG_TF * CG_TT * a.C2 * 2 : 0) + 2 * BN_ * KC * 2;
+    const size_t stage = (size_t)(POOL ? CG_TF / 2 : CG_TF) * CG_TT * BN_ * 2;       // the epilogue's output rows reuse the buffers
+    if (lds < stage) lds = stage;
     MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "conv: tile needs %zu B of LDS", lds);
     static bool attr_set = false;
     if (!attr_set) {
