@@ -973,10 +973,12 @@ static int launch_persist(const bf16_t* a, int lda, const bf16_t* w, int ldw, in
 
 template <int EPI, int DT>
 static int launch256(const bf16_t* a, int lda, const bf16_t* w, int ldw, int M, int N, int K, const GemmEpi& ep, hipStream_t st, int batch) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};                          // per device: the attribute belongs to the device's code object
+    int dev_ = 0;
+    MT_CHECK_HIP(hipGetDevice(&dev_));
+    if (dev_ >= 0 && dev_ < 16 && !attr_set[dev_]) {
         MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256x_kernel<EPI, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
-        attr_set = true;
+        attr_set[dev_] = true;
     }
     dim3 grid(cdiv(N, BN2) * cdiv(M, BM2), 1, batch);
     hipLaunchKernelGGL((gemm256x_kernel<EPI, DT>), grid, dim3(512), G256_LDS, st, a, lda, w, ldw, M, N, K, ep);
@@ -1013,10 +1015,12 @@ static int launch_hx(int epi, const void* hx, const void* W, int ldw, int M, int
     const bf16_t* a = (const bf16_t*)hx; const bf16_t* w = (const bf16_t*)W;
     if (epi == EPI_LSTM_GX && persist_ok(ep, M, N, K, sched)) return launch_persist<MT_DT_F16, true>(a, K, w, ldw, M, N, K, ep, sched, st);
     if (epi == EPI_LSTM_GX && M >= 1024 && N >= 512 && N % 128 == 0 && (long long)cdiv(M, BM2) * cdiv(N, BN2) >= 128) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[16] = {};
+        int dev_ = 0;
+        MT_CHECK_HIP(hipGetDevice(&dev_));
+        if (dev_ >= 0 && dev_ < 16 && !attr_set[dev_]) {
             MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256x_kernel<EPI_LSTM_GX, MT_DT_F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
-            attr_set = true;
+            attr_set[dev_] = true;
         }
         hipLaunchKernelGGL((gemm256x_kernel<EPI_LSTM_GX, MT_DT_F16, true>), dim3(cdiv(N, BN2) * cdiv(M, BM2)), dim3(512), G256_LDS, st, a, K, w, ldw, M, N, K, ep);
     } else if (epi == EPI_LSTM_GX) {

@@ -332,7 +332,12 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
                     }
                 }
                 if (NG > 1) {
-                    // requested in the previous slot: nothing younger is in this wave's queue but, in wave 0, that slot's publish store
+                    // requested in the previous slot: nothing younger is in this wave's queue but, in wave 0, that slot's publish store.
+                    // THE COUNT IS BY HAND: exactly one vector-memory operation (that store) may be issued by wave 0 between the asm
+                    // gather request and this wait.  The TRAIN gate / cx stores and the XP xr loads would be further ones -- those
+                    // variants are never built with NG > 1 (static_assert below); a new VMEM instruction on this path must either
+                    // raise the count or move the request behind it.
+                    static_assert(NG == 1 || (!TRAIN && !XP), "NG > 1 is the plain inference kernel: the hand-counted vmcnt does not cover TRAIN / XP stores and loads");
                     if (pf && it == 0 && wv == 0) vm_wait<1>();
                     else vm_wait<0>();
 #pragma unroll
@@ -647,6 +652,17 @@ __global__ void lstm_unpack_kernel(const f16_t* __restrict__ hx, float* __restri
 
 int persistent_admit(const void* kernel, int block, size_t smem, int nwg, hipStream_t st, const char* who);   // residency.hip
 int persistent_mark(hipStream_t st);
+int persistent_cancel(hipStream_t st);
+// (a launch that fails after its admission gives the reserved CUs back)
+#define MT_CHECK_LAUNCH_OR_CANCEL()                                                                 \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) {                                                                     \
+            mt::persistent_cancel(st);                                                              \
+            mt::set_error("%s:%d: persistent launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return MT_EHIP;                                                                         \
+        }                                                                                           \
+    } while (0)
 
 // every workgroup of a persistent launch must be resident: admission check first (fails fast), completion event behind it
 #define MT_PERSISTENT_LAUNCH_N(kernel, grid, nthreads, who)                                                       \
@@ -655,7 +671,7 @@ int persistent_mark(hipStream_t st);
         int rc_ = persistent_admit((const void*)(kernel), (nthreads), 0, (int)(g_.x * g_.y * g_.z), st, who);     \
         if (rc_ != MT_OK) return rc_;                                                                             \
         hipLaunchKernelGGL((kernel), g_, dim3(nthreads), 0, st, a);                                               \
-        MT_CHECK_LAUNCH();                                                                                        \
+        MT_CHECK_LAUNCH_OR_CANCEL();                                                                              \
         if ((rc_ = persistent_mark(st)) != MT_OK) return rc_;                                                     \
     } while (0)
 #define MT_PERSISTENT_LAUNCH(kernel, grid, who) MT_PERSISTENT_LAUNCH_N(kernel, grid, 256, who)
@@ -667,7 +683,7 @@ static int launch_rec16(const LstmArgs& a, hipStream_t st) {
     int rc = persistent_admit((const void*)lstm_rec16_kernel<NKSW>, 256, 0, stay, st, "mt_lstm_bidir_fwd (XCD-local)");
     if (rc != MT_OK) return rc;
     hipLaunchKernelGGL((lstm_rec16_kernel<NKSW>), dim3(8 * (a.H >> 4)), dim3(256), 0, st, a);
-    MT_CHECK_LAUNCH();
+    MT_CHECK_LAUNCH_OR_CANCEL();
     return persistent_mark(st);
 }
 

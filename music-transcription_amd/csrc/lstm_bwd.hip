@@ -376,6 +376,17 @@ __global__ void dlogits_pack_kernel(const float* __restrict__ dl, bf16_t* __rest
 namespace mt {
 int persistent_admit(const void* kernel, int block, size_t smem, int nwg, hipStream_t st, const char* who);   // residency.hip
 int persistent_mark(hipStream_t st);
+int persistent_cancel(hipStream_t st);
+// (a launch that fails after its admission gives the reserved CUs back)
+#define MT_CHECK_LAUNCH_OR_CANCEL()                                                                 \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) {                                                                     \
+            mt::persistent_cancel(st);                                                              \
+            mt::set_error("%s:%d: persistent launch -> %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return MT_EHIP;                                                                         \
+        }                                                                                           \
+    } while (0)
 }
 using namespace mt;
 
@@ -424,7 +435,7 @@ extern "C" int mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const f
     if (rc != MT_OK) return rc;
     if (NW <= 8) hipLaunchKernelGGL(lstm_bptt_kernel<1>, grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(512), 0, st, a);
-    MT_CHECK_LAUNCH();
+    MT_CHECK_LAUNCH_OR_CANCEL();
     return persistent_mark(st);
 }
 

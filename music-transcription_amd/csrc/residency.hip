@@ -16,7 +16,9 @@ struct PersistentEntry {
     hipStream_t st;
     hipEvent_t ev;
     double need;      // CUs
-    bool pending;
+    bool pending;     // a launch is queued on the stream, `ev` is recorded behind it
+    int reserved;     // launches admitted but not yet committed by persistent_mark (or given up by persistent_cancel)
+    double rneed;     // CUs of the reservation(s)
 };
 static std::mutex g_mu;
 static std::vector<PersistentEntry> g_tab[16];
@@ -35,10 +37,14 @@ int persistent_admit(const void* kernel, int block, size_t smem, int nwg, hipStr
     MT_REQUIRE(need <= cap, MT_EUNSUPPORTED, "%s: %d workgroups at %d per CU cannot be resident on %d CUs", who, nwg, per_cu, g_ncu[dev]);
     double others = 0.0;
     PersistentEntry* mine = nullptr;
+    // Admission is check-AND-RESERVE under one lock: the CUs of an admitted launch count against other host threads' admissions
+    // from here on, whether or not its event has been recorded yet (persistent_mark commits the reservation, persistent_cancel
+    // gives it up when the launch failed).  Entries of streams whose work has drained hold no CUs and are reused when the
+    // runtime hands the same stream handle out again; nothing else outlives a launch.
     for (auto& e : g_tab[dev]) {
         if (e.pending && hipEventQuery(e.ev) == hipSuccess) { e.pending = false; e.need = 0.0; }
         if (e.st == st) mine = &e;
-        else if (e.pending) others += e.need;
+        else others += (e.pending ? e.need : 0.0) > e.rneed ? (e.pending ? e.need : 0.0) : e.rneed;
     }
     (void)hipGetLastError();          // hipEventQuery reports "not ready" as an error code: clear it
     if (others + need > cap + 1e-9) {
@@ -48,12 +54,30 @@ int persistent_admit(const void* kernel, int block, size_t smem, int nwg, hipStr
         return MT_EUNSUPPORTED;
     }
     if (!mine) {
-        PersistentEntry e{st, nullptr, 0.0, false};
+        PersistentEntry e{st, nullptr, 0.0, false, 0, 0.0};
         MT_CHECK_HIP(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
         g_tab[dev].push_back(e);
         mine = &g_tab[dev].back();
     }
-    mine->need = mine->pending ? (mine->need > need ? mine->need : need) : need;
+    mine->reserved += 1;
+    mine->rneed = mine->rneed > need ? mine->rneed : need;      // launches on one stream run one after the other: the largest counts
+    return MT_OK;
+}
+
+static PersistentEntry* find_entry(int dev, hipStream_t st) {
+    for (auto& e : g_tab[dev])
+        if (e.st == st) return &e;
+    return nullptr;
+}
+
+// the admitted launch failed: give the reservation back
+int persistent_cancel(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return MT_EHIP;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (PersistentEntry* e = find_entry(dev, st)) {
+        if (e->reserved > 0 && --e->reserved == 0) e->rneed = 0.0;
+    }
     return MT_OK;
 }
 
@@ -62,12 +86,13 @@ int persistent_mark(hipStream_t st) {
     int dev = 0;
     MT_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_mu);
-    for (auto& e : g_tab[dev])
-        if (e.st == st) {
-            MT_CHECK_HIP(hipEventRecord(e.ev, st));
-            e.pending = true;
-            return MT_OK;
-        }
+    if (PersistentEntry* e = find_entry(dev, st)) {
+        const double was = e->pending ? e->need : 0.0;
+        MT_CHECK_HIP(hipEventRecord(e->ev, st));
+        e->need = was > e->rneed ? was : e->rneed;
+        e->pending = true;
+        if (e->reserved > 0 && --e->reserved == 0) e->rneed = 0.0;
+    }
     return MT_OK;
 }
 
@@ -81,7 +106,7 @@ extern "C" int mt_persistent_cus_in_flight(mt_stream_t stream) {
     double others = 0.0;
     for (auto& e : mt::g_tab[dev]) {
         if (e.pending && hipEventQuery(e.ev) == hipSuccess) { e.pending = false; e.need = 0.0; }
-        if (e.st != (hipStream_t)stream && e.pending) others += e.need;
+        if (e.st != (hipStream_t)stream) others += (e.pending ? e.need : 0.0) > e.rneed ? (e.pending ? e.need : 0.0) : e.rneed;
     }
     (void)hipGetLastError();
     return (int)(others + 0.5);

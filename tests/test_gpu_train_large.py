@@ -369,6 +369,34 @@ def test_large_train_step_matches_reference_golden(mta, golden_dir):
             assert int(sdm[k[len("bn0::"):]]) == int(g[k])
 
 
+def test_large_gradients_at_a_realistic_position_count(mta):
+    """The wide per-tensor bounds of GRAD_REL_BY_KEY belong to the goldens' TOY shapes (a few hundred positions per BatchNorm
+    channel: the conv weight gradients are cancelling sums of a few hundred terms and one flipped ReLU / pool decision moves
+    them by percents).  At n_mels = 320, B = 2, T = 200 -- 64 000 positions per channel in the first block, 32 000 in the 7x3
+    conv -- every tensor, the conv weight gradients included, is within GRAD_REL = 6 % of the oracle with the same bf16
+    rounding points, cosine > 0.999."""
+    nm, H, L, B, T = 320, 64, 2, 2, 200
+    m, sd = _hip_large(mta, nm, H, L, 21)
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    mel = _mel_in(B, nm, T, 31)
+    roll = (torch.rand(B, 88, T, generator=g) < 0.1).float()
+    lengths = torch.tensor([T, T - 37], dtype=torch.int64)
+    mel[1, :, :, T - 37:] = 0.0
+    roll[1, :, T - 37:] = 0.0
+    logits = m(mel.cuda())
+    loss = m.compute_loss(logits, roll.cuda(), lengths)
+    loss.backward()
+    m.model.raise_on_train_handoff_timeout()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    lo_emu, ref_emu = _oracle_grads(sd, mel, roll, lengths, True)
+    assert float((logits.detach().cpu() - lo_emu.detach()).abs().max()) < 2.5 * LOGIT_TOL_TRAIN_EMU
+    worst, cos = _compare_grads(grads, ref_emu)
+    _report("large 320/64/2, B = 2, T = 200 vs bf16-emulating oracle", worst, cos)
+    bad = {k: v for k, v in worst.items() if v > GRAD_REL}
+    assert not bad and cos > 0.999, (bad, cos)
+
+
 def test_large_training_loop_matches_reference_losses(mta, golden_dir):
     """train_one_epoch of this package over the golden's 3 batches, CNNRNNModelLarge (what example.sh:22 trains)."""
     g = np.load(os.path.join(golden_dir, "train_step_large.npz"))

@@ -317,3 +317,20 @@ def test_resampling_filter_meets_its_stated_spec():
         assert 20 * np.log10(sb.max()) < -110.0, (rate_in, 20 * np.log10(sb.max()))
         taps_per_output = len(h) / up
         assert taps_per_output < 700                                    # cost bound: ~500 taps per output sample
+
+
+def test_lpt_balances_a_maestro_sized_corpus_over_eight_ranks():
+    """SURVEY 8e / BASELINE configs[4]: 177 recordings with gamma-distributed lengths (20 h in all) LPT-sharded over 8 ranks --
+    every rank's load within 2 % of the mean for 20 different corpora, every recording on exactly one rank, the assignment
+    identical whoever computes it (ties broken by index)."""
+    from music_transcription_amd.parallel import lpt_assign
+    from music_transcription_amd.corpus import synthetic_corpus
+    for seed in range(20):
+        dur = synthetic_corpus(177, 20.0, seed=seed)
+        shards = lpt_assign(dur, 8)
+        assert sorted(i for s_ in shards for i in s_) == list(range(177))
+        loads = np.array([sum(dur[i] for i in s_) for s_ in shards])
+        assert loads.max() <= 1.02 * loads.mean() and loads.min() >= 0.98 * loads.mean(), (seed, loads / loads.mean())
+        assert shards == lpt_assign(list(dur), 8)
+    # degenerate shapes: fewer recordings than ranks, one rank
+    assert [len(s_) for s_ in lpt_assign([3.0, 1.0], 4)] == [1, 1, 0, 0] and lpt_assign([1.0, 2.0, 3.0], 1) == [[2, 1, 0]]
