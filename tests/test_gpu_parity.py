@@ -725,6 +725,12 @@ def test_oversubscribed_persistent_launches_fail_fast(mta):
         assert _lib.lib.mt_persistent_cus_in_flight(None) == 0
         # the host-side bound of the model refuses a third stream outright ...
         streams = [torch.cuda.Stream() for _ in range(4)]
+        nbytes = _lib.lib.mt_cnnrnn_workspace_bytes(net._ensure_packed(mel.device)["struct"], 32, 938)
+        for s_ in streams:                                  # a cached block per stream: the workspace of a new stream is then handed out
+            with torch.cuda.stream(s_):                     # without a hipMalloc (milliseconds: the forwards before it would have drained)
+                warm = [torch.empty(nbytes, dtype=torch.uint8, device="cuda"), torch.empty(32, 88, 938, device="cuda")]
+                del warm
+        torch.cuda.synchronize()
         outs = []
         with pytest.raises(_lib.MtError, match="caller streams"):
             for s_ in streams:
