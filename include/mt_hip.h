@@ -528,6 +528,11 @@ int    mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_x, int l
  * positions: tap kh is the pointer offset (kh - ph)*Tp into the activation plane, Tp % 8 == 0.                       */
 int    mt_cl_to_planar(const void* src, int pitch, int C, void* dst, long long ld, int B, int F, int T, int ph, int Tp,
                        int toff, mt_stream_t stream);
+/* The same for up to 3 column shifts at once: plane k (the source shifted by toffs[k] <= 8 columns; HOST array) goes to rows
+ * [k*plane_rows, k*plane_rows + C) of dst -- one read of the source, 16-byte stores (Tp % 8 == 0, ld % 8 == 0, pitch % 8 == 0,
+ * 16-byte aligned buffers).  Destination columns [0, Tp) of the rows it touches are written (zeros outside the sequence). */
+int    mt_cl_to_planar_multi(const void* src, int pitch, int C, void* dst, long long ld, int plane_rows, int B, int F, int T, int ph,
+                             int Tp, int ntoff, const int* toffs, mt_stream_t stream);
 /* General form of mt_conv_cl_dt: A / S are channel slices (pitchA / pitchS elements between positions) and accum != 0
  * adds the result to `out` -- the input gradient of freq_aware_conv (256 output channels) is two calls.              */
 int    mt_conv_cl_ex(const void* A, int pitchA, const void* S, int pitchS, const void* W, const float* bias, void* out,

@@ -192,34 +192,40 @@ class _Planes:
         self.dev = dev
 
     def make(self, src, pitch, C, toffs):
-        """-> tensor [len(toffs)][roundup(C, 128)][ld]; plane k holds the source shifted by toffs[k] columns."""
-        rows = _ru(C, 128)
-        out = torch.zeros(len(toffs), rows, self.ld, device=self.dev, dtype=torch.bfloat16)
-        for k, toff in enumerate(toffs):
-            base = out[k].reshape(-1)[self.front:]
-            check(lib.mt_cl_to_planar(ptr(src), pitch, C, ptr(base), self.ld, self.B, self.F, self.T, self.ph, self.Tp2, toff, _st()),
-                  "mt_cl_to_planar")
+        """-> tensor [rows][ld] with plane k (the source shifted by toffs[k] columns) at rows [k*C, (k+1)*C): the planes of the
+        three kernel columns are ADJACENT row blocks, so one weight-gradient GEMM takes them as N = 3 C columns (one launch
+        instead of three, and a 32-channel input fills 96 of a 128-wide tile instead of 32).  rows leaves room for the GEMM's
+        contract (W readable up to roundup(N, 128) rows from any plane's first row)."""
+        rows = _ru(len(toffs) * C, 128) + 128
+        out = torch.zeros(rows, self.ld, device=self.dev, dtype=torch.bfloat16)
+        import ctypes as C_
+        base = out.reshape(-1)[self.front:]
+        arr = (C_.c_int * len(toffs))(*toffs)
+        check(lib.mt_cl_to_planar_multi(ptr(src), pitch, C, ptr(base), self.ld, C, self.B, self.F, self.T, self.ph, self.Tp2, len(toffs), arr, _st()),
+              "mt_cl_to_planar_multi")
         return out
 
 
 def _conv_wgrad(pl: _Planes, dzPs, xP, Cout, Cin, KH, kws, out):
     """out (f32, reference layout [Cout][Cin][KH][len(kws)]) = sum over positions of dz[pos][co] * x[pos + tap][ci].
-    dzPs: list of planes tensors [1][.][ld] (toff 1) whose sum is dz (the bf16 value and, optionally, its rounding remainder:
-    BatchNorm makes the sum cancel heavily); xP: planes [3][.][ld] for kernel columns 0, 1, 2 (toffs 2, 1, 0);
-    kws: the kernel columns wanted ((0, 1, 2) for a KH x 3 conv, (1,) with KH = 1 for the 1x1 skip).  Tap kh is the pointer
-    offset (kh - KH // 2) * Tp2 into the activation plane."""
+    dzPs: list of planes tensors (one plane, toff 1) whose sum is dz (the bf16 value and, optionally, its rounding remainder:
+    BatchNorm makes the sum cancel heavily); xP: planes for kernel columns 0, 1, 2 (toffs 2, 1, 0) in adjacent row blocks of
+    Cin rows; kws: the kernel columns wanted ((0, 1, 2) for a KH x 3 conv, (1,) with KH = 1 for the 1x1 skip).  Tap kh is the
+    pointer offset (kh - KH // 2) * Tp2 into the activation plane; the kernel columns are N = len(kws) * Cin columns of ONE
+    batched NT GEMM per piece of dz (batch = K split x kernel rows)."""
     dev = pl.dev
     nkw, npc = len(kws), len(dzPs)
-    part = torch.empty(nkw, npc, pl.S, KH, Cout, Cin, device=dev, dtype=torch.float32)
-    red = torch.empty(nkw, KH, Cout, Cin, device=dev, dtype=torch.float32)
-    for i, kw in enumerate(kws):
-        w = xP[kw].reshape(-1)[pl.front - (KH // 2) * pl.Tp2:]
-        for j, dzP in enumerate(dzPs):
-            a = dzP[0].reshape(-1)[pl.front:]
-            check(lib.mt_gemm_batched_f32(ptr(a), pl.ld, pl.Ks, 0, ptr(w), pl.ld, pl.Ks, pl.Tp2, None, ptr(part[i, j]), Cin,
-                                          KH * Cout * Cin, Cout * Cin, Cout, Cin, pl.Ks, pl.S * KH, KH, _st()), "mt_gemm_batched_f32 (conv wgrad)")
-        check(lib.mt_sum_slices_f32(ptr(part[i]), KH * Cout * Cin, Cin, npc * pl.S, ptr(red[i]), Cin, KH * Cout, Cin, _st()), "mt_sum_slices_f32")
-    _gather4(red, 0, out, (Cout, Cin, KH, nkw), (Cin, 1, Cout * Cin, KH * Cout * Cin))
+    N = nkw * Cin
+    part = torch.empty(npc, pl.S, KH, Cout, N, device=dev, dtype=torch.float32)
+    red = torch.empty(KH, Cout, N, device=dev, dtype=torch.float32)
+    w = xP[kws[0] * Cin:].reshape(-1)[pl.front - (KH // 2) * pl.Tp2:]
+    for j, dzP in enumerate(dzPs):
+        a = dzP.reshape(-1)[pl.front:]
+        check(lib.mt_gemm_batched_f32(ptr(a), pl.ld, pl.Ks, 0, ptr(w), pl.ld, pl.Ks, pl.Tp2, None, ptr(part[j]), N,
+                                      KH * Cout * N, Cout * N, Cout, N, pl.Ks, pl.S * KH, KH, _st()), "mt_gemm_batched_f32 (conv wgrad)")
+    check(lib.mt_sum_slices_f32(ptr(part), KH * Cout * N, N, npc * pl.S, ptr(red), N, KH * Cout, N, _st()), "mt_sum_slices_f32")
+    # out[co][ci][kh][kw] = red[kh][co][kw * Cin + ci]
+    _gather4(red, 0, out, (Cout, Cin, KH, nkw), (N, 1, Cout * N, Cin))
     return out
 
 
