@@ -20,6 +20,8 @@ Every dense contraction of the backward pass is an NT GEMM or a channels-last co
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List
 
 import torch
@@ -176,6 +178,18 @@ def _bn_act_bwd(dcl, ldd_cl, dx, ldd_x, za, sa, zb, sb, mask, dza, dzb, grads, B
     return sums
 
 
+_SIDE2 = {}
+
+
+def _side_streams(dev):
+    """Two side streams per device: (weight-gradient work of the LSTM stack, the local LSTM's own chain).  The backward
+    recurrences are latency-bound on 16-32 CUs: everything that does not gate the next recurrence runs beside them."""
+    key = str(dev)
+    if key not in _SIDE2:
+        _SIDE2[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+    return _SIDE2[key]
+
+
 class _Planes:
     """Zero-padded position-major planes of a channels-last tensor [B][F][T][C] (see mt_cl_to_planar): the operands of the
     convolution weight-gradient GEMMs.  geometry: Fp = F + 2 ph rows per chunk, Tp2 = roundup(T + 2, 8) columns per row."""
@@ -257,7 +271,7 @@ def _lstm_forward(X0, K0, w_ih, b_g, w_hh, L, Hp, Hv, K1, B, T, dropout, seed, l
 
 
 def _lstm_backward(sv, dh, w_hh, w_ihT, L, Hp, Hv, K0, K1, B, T, dropout, seed, layer_id0, dev, sync_slots, dG0, ldg0, col0, names, g, rnn_prefix,
-                   k0_gather):
+                   k0_gather, wg_stream=None):
     """BPTT through the stack.  dh: gradient of the top layer's output in the backward recurrence's layout.  Layer 0's gate
     gradients go to dG0[:, col0 : col0 + 8 Hp] (row pitch ldg0): the caller turns them into the input gradient.  Parameter
     gradients land in g under rnn_prefix; k0_gather(gwi, di) produces layer 0's W_ih gradient in the reference layout."""
@@ -265,6 +279,7 @@ def _lstm_backward(sv, dh, w_hh, w_ihT, L, Hp, Hv, K0, K1, B, T, dropout, seed, 
     bf = dict(device=dev, dtype=torch.bfloat16)
     f32 = dict(device=dev, dtype=torch.float32)
     Hr = _ru(Hp, 128)
+    keep = []
     for l in range(L - 1, -1, -1):
         K = K0 if l == 0 else K1
         part = torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
@@ -285,28 +300,43 @@ def _lstm_backward(sv, dh, w_hh, w_ihT, L, Hp, Hv, K0, K1, B, T, dropout, seed, 
             dh = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
             check(lib.mt_gemm_lstm_dh(ptr(dGv), 8 * Hp, ptr(w_ihT[l]), 8 * Hp, ptr(dh), B, T, Hp, Hv, 8 * Hp, float(dropout), seed,
                                       layer_id0 + l - 1, _st()), "mt_gemm_lstm_dh")
-        # ---- weight gradients: dW_ih = dG^T X_l, dW_hh = dG^T H_prev, db = sum dG
+        # ---- weight gradients: dW_ih = dG^T X_l, dW_hh = dG^T H_prev, db = sum dG.  They gate nothing below: on `wg_stream`
+        #      (when given) they run beside the next layer's backward recurrence.  All buffers are allocated here, on the calling
+        #      stream, and stay referenced in `keep` until the caller has joined the streams.
         XT = torch.empty(_ru(K, 128) * Mpad, **bf)
-        check(lib.mt_transpose_bf16(ptr(sv["Xs"][l]), K, M, K, ptr(XT), Mpad, K, _st()), "mt_transpose_bf16")
         HT = torch.zeros(2 * Hr, Mpad, **bf)
-        check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HT), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
         gb, gwi, gwh = torch.empty(8 * Hp, **f32), torch.empty(8 * Hp, K, **f32), torch.empty(2, 4 * Hp, Hp, **f32)
-        check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
-        _gemm(dGT, Mpad, XT, Mpad, gwi, K, 8 * Hp, K, Mpad)
+        outs = []
         for di in range(2):
-            _gemm(dGT[di * 4 * Hp:], Mpad, HT[di * Hr:], Mpad, gwh[di], Hp, 4 * Hp, Hp, Mpad)
-        for di, suf in enumerate(("", "_reverse")):
-            if l == 0:
-                wi = k0_gather(gwi, di)
-            else:
-                wi = torch.empty(4 * Hv, 2 * Hv, **f32)
-                _gather4(gwi, di * 4 * Hp * K, wi, (4, Hv, 1, 2 * Hv), (Hp * K, K, 0, 1))
-            wh, bb, bb2 = torch.empty(4 * Hv, Hv, **f32), torch.empty(4 * Hv, **f32), torch.empty(4 * Hv, **f32)
-            _gather4(gwh, di * 4 * Hp * Hp, wh, (4, Hv, 1, Hv), (Hp * Hp, Hp, 0, 1))
-            _gather4(gb, di * 4 * Hp, bb, (1, 1, 4, Hv), (0, 0, Hp, 1))
-            _gather4(gb, di * 4 * Hp, bb2, (1, 1, 4, Hv), (0, 0, Hp, 1))
-            g[f"{rnn_prefix}.weight_ih_l{l}{suf}"], g[f"{rnn_prefix}.weight_hh_l{l}{suf}"] = wi, wh
-            g[f"{rnn_prefix}.bias_ih_l{l}{suf}"], g[f"{rnn_prefix}.bias_hh_l{l}{suf}"] = bb, bb2
+            wi = torch.empty(4 * Hv, 256 * (K0 // 256), **f32) if l == 0 else torch.empty(4 * Hv, 2 * Hv, **f32)
+            outs.append((wi, torch.empty(4 * Hv, Hv, **f32), torch.empty(4 * Hv, **f32), torch.empty(4 * Hv, **f32)))
+        keep += [XT, HT, gb, gwi, gwh, dGT, dGv, outs]
+        cur = torch.cuda.current_stream(dev)
+        ws = wg_stream if wg_stream is not None else cur
+        if wg_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+        with torch.cuda.stream(ws):
+            if wg_stream is not None:
+                ws.wait_event(ev)
+            check(lib.mt_transpose_bf16(ptr(sv["Xs"][l]), K, M, K, ptr(XT), Mpad, K, _st()), "mt_transpose_bf16")
+            check(lib.mt_lstm_hprev_t(ptr(sv["hxs"][l]), ptr(HT), Mpad, Hr, B, T, Hp, _st()), "mt_lstm_hprev_t")
+            check(lib.mt_rowsum_bf16(ptr(dGT), Mpad, M, ptr(gb), 8 * Hp, _st()), "mt_rowsum_bf16")
+            _gemm(dGT, Mpad, XT, Mpad, gwi, K, 8 * Hp, K, Mpad)
+            for di in range(2):
+                _gemm(dGT[di * 4 * Hp:], Mpad, HT[di * Hr:], Mpad, gwh[di], Hp, 4 * Hp, Hp, Mpad)
+            for di, suf in enumerate(("", "_reverse")):
+                wi, wh, bb, bb2 = outs[di]
+                if l == 0:
+                    k0_gather(gwi, di, wi)
+                else:
+                    _gather4(gwi, di * 4 * Hp * K, wi, (4, Hv, 1, 2 * Hv), (Hp * K, K, 0, 1))
+                _gather4(gwh, di * 4 * Hp * Hp, wh, (4, Hv, 1, Hv), (Hp * Hp, Hp, 0, 1))
+                _gather4(gb, di * 4 * Hp, bb, (1, 1, 4, Hv), (0, 0, Hp, 1))
+                _gather4(gb, di * 4 * Hp, bb2, (1, 1, 4, Hv), (0, 0, Hp, 1))
+                g[f"{rnn_prefix}.weight_ih_l{l}{suf}"], g[f"{rnn_prefix}.weight_hh_l{l}{suf}"] = wi, wh
+                g[f"{rnn_prefix}.bias_ih_l{l}{suf}"], g[f"{rnn_prefix}.bias_hh_l{l}{suf}"] = bb, bb2
+    return keep
 
 
 # ---------------------------------------------------------------------------------------------------------------- forward
@@ -388,8 +418,27 @@ def forward_train_large(model, x: torch.Tensor, p_drop: float, seed: int, p2d=DR
         sv.update(r2=r2, zf=zf, sf=sf)
         # ---- LSTMs
         pm = p_drop if L > 1 else 0.0
+        # the local layer (an independent recurrence on the same input) runs on a side stream beside the main stack
+        use_side = os.environ.get("MT_TRAIN_LARGE_STREAMS", "1") != "0"
+        slots_local = [slots.pop()]
+        if use_side:
+            main_st, side_b = torch.cuda.current_stream(dev), _side_streams(dev)[1]
+            ev_x0 = torch.cuda.Event()
+            ev_x0.record(main_st)
+            with torch.cuda.stream(side_b):
+                side_b.wait_event(ev_x0)
+                sv["local"] = _lstm_forward(X0, K0, pk["l_wih"], pk["l_b"], pk["l_whh"], 1, Hlp, Hl, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
+                                            slots_local)
+                ev_loc = torch.cuda.Event()
+                ev_loc.record(side_b)
+            for t_ in sv["local"]["gates"] + sv["local"]["cxs"] + sv["local"]["hxs"]:
+                t_.record_stream(main_st)              # allocated under the side stream, read by the backward pass on the calling one
         sv["main"] = _lstm_forward(X0, K0, pk["m_wih"], pk["m_b"], pk["m_whh"], L, Hp, H, K1, B, T, pm, seed, 0, dev, slots)
-        sv["local"] = _lstm_forward(X0, K0, pk["l_wih"], pk["l_b"], pk["l_whh"], 1, Hlp, Hl, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev, slots)
+        if use_side:
+            main_st.wait_event(ev_loc)
+        else:
+            sv["local"] = _lstm_forward(X0, K0, pk["l_wih"], pk["l_b"], pk["l_whh"], 1, Hlp, Hl, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
+                                        slots_local)
         rb = torch.zeros(Mpad, Cp, **bf)
         r32 = torch.empty(M, comb, **f32)
         check(lib.mt_lstm_relayout_ex(ptr(sv["main"]["hxs"][-1]), ptr(rb), Cp, ptr(r32), comb, 0, B, T, Hp, H, _st()), "mt_lstm_relayout_ex")
@@ -589,16 +638,38 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         check(lib.mt_lstm_dh_relayout(ptr(drf[2 * H:]), comb, ptr(dh_l), B, T, Hlp, Hl, 0.0, seed, 0, _st()), "mt_lstm_dh_relayout")
 
         def k0_gather(Hx, Hxp):
-            def f(gwi, di):
-                wi = torch.empty(4 * Hx, 256 * F3, **f32)
+            def f(gwi, di, wi):
                 _gather4(gwi, di * 4 * Hxp * K0, wi, (4, Hx, 256, F3), (Hxp * K0, K0, 1, 256))
-                return wi
             return f
         pm = p_drop if L > 1 else 0.0
-        _lstm_backward(sv["main"], dh_m, pk["m_whh"], pk["m_wihT"], L, Hp, H, K0, K1, B, T, pm, seed, 0, dev, slots, dG0, ldg, 0, None, g,
-                       "rnn_main", k0_gather(H, Hp))
-        _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev, slots, dG0, ldg,
-                       8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp))
+        # Stream plan: the main stack's recurrences on the calling stream, its weight-gradient GEMMs on side stream A beside the
+        # next layer's recurrence, the local layer's whole chain (an independent recurrence writing its own columns of dG0)
+        # on side stream B beside the main stack.  MT_TRAIN_LARGE_STREAMS=0: everything on the calling stream.
+        use_side = os.environ.get("MT_TRAIN_LARGE_STREAMS", "1") != "0"
+        main_st = torch.cuda.current_stream(dev)
+        side_a, side_b = _side_streams(dev) if use_side else (None, None)
+        ev_in = torch.cuda.Event()
+        ev_in.record(main_st)
+        slots_local = [slots.pop()]                    # (the local layer's status slot: taken now, the streams pop independently)
+        keep_all = []
+        if use_side:
+            with torch.cuda.stream(side_b):
+                side_b.wait_event(ev_in)
+                keep_all += _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
+                                           slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp))
+        keep_all += _lstm_backward(sv["main"], dh_m, pk["m_whh"], pk["m_wihT"], L, Hp, H, K0, K1, B, T, pm, seed, 0, dev, slots, dG0, ldg, 0, None, g,
+                                   "rnn_main", k0_gather(H, Hp), wg_stream=side_a)
+        if not use_side:
+            keep_all += _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
+                                       slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp))
+        else:
+            for st_ in (side_a, side_b):                # join: dG0 is complete, every LSTM gradient is final
+                evj = torch.cuda.Event()
+                evj.record(st_)
+                main_st.wait_event(evj)
+            for t_ in [v for k_, v in g.items() if k_.startswith("rnn_local.")]:
+                t_.record_stream(main_st)              # allocated under side stream B, consumed by autograd on the calling stream
+        sv["_keep_lstm_bwd"] = keep_all                # (referenced until the backward pass returns)
         dX0 = torch.empty(M, K0, **f32)
         _gemm(dG0, ldg, pk["ml_wihT"], ldg, dX0, K0, M, K0, ldg)
         # ---- freq_aware_conv
