@@ -652,7 +652,19 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         ev_in.record(main_st)
         slots_local = [slots.pop()]                    # (the local layer's status slot: taken now, the streams pop independently)
         keep_all = []
+        pre = {}                                       # activation planes of the conv weight gradients (they depend on saved tensors only)
         if use_side:
+            with torch.cuda.stream(side_a):            # ... made beside the backward recurrences, ahead of the LSTM weight gradients
+                side_a.wait_event(ev_in)
+                plf = _Planes(B, F2, T, 3, dev)
+                pre["fa"] = (plf, plf.make(sv["r2"], 128, 128, (2, 1, 0)))
+                for name_ in ("rb2", "rb1"):
+                    st_ = sv[name_]
+                    pl_ = _Planes(B, st_["Fin"], T, 1, dev)
+                    pre[name_] = (pl_, pl_.make(st_["xin"], st_["cin"], st_["cin"], (2, 1, 0)), pl_.make(st_["y1"], st_["cout"], st_["cout"], (2, 1, 0)))
+                for v_ in pre.values():
+                    for t_ in v_[1:]:
+                        t_.record_stream(main_st)
             with torch.cuda.stream(side_b):
                 side_b.wait_event(ev_in)
                 keep_all += _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
@@ -682,9 +694,12 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         dr2 = torch.empty(B * F2 * T, 128, **bf)
         _conv(dzf, None, pk["fa_wdA"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256)
         _conv(dzf.reshape(-1)[128:], None, pk["fa_wdB"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256, accum=1)
-        pl = _Planes(B, F2, T, 3, dev)
+        pl, r2P = pre["fa"] if "fa" in pre else (None, None)
+        if pl is None:
+            pl = _Planes(B, F2, T, 3, dev)
+            r2P = pl.make(sv["r2"], 128, 128, (2, 1, 0))
         g["freq_aware_conv.0.weight"] = torch.empty(256, 128, 7, 3, **f32)
-        _conv_wgrad(pl, [pl.make(dzf, 256, 256, (1,)), pl.make(dzf_lo, 256, 256, (1,))], pl.make(sv["r2"], 128, 128, (2, 1, 0)), 256, 128, 7, (0, 1, 2),
+        _conv_wgrad(pl, [pl.make(dzf, 256, 256, (1,)), pl.make(dzf_lo, 256, 256, (1,))], r2P, 256, 128, 7, (0, 1, 2),
                     g["freq_aware_conv.0.weight"])
         g["freq_aware_conv.0.bias"] = torch.zeros(256, **f32)          # a conv bias in front of a BatchNorm: analytically zero
         # ---- residual blocks, top down
@@ -707,9 +722,12 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             dxin = torch.empty(N, cin_p, **bf)
             _conv(dz1, dzs, pk[name + "c1s_wd"], z256, dxin, B, Fin, T, cout, cout, cin_p, 3)
             # weight gradients
-            pl = _Planes(B, Fin, T, 1, dev)
-            xP = pl.make(xin, cin, cin, (2, 1, 0))
-            yP = pl.make(st["y1"], cout, cout, (2, 1, 0))
+            if name in pre:
+                pl, xP, yP = pre[name]
+            else:
+                pl = _Planes(B, Fin, T, 1, dev)
+                xP = pl.make(xin, cin, cin, (2, 1, 0))
+                yP = pl.make(st["y1"], cout, cout, (2, 1, 0))
             pfx = "res_block1" if name == "rb1" else "res_block2"
             two = lambda hi, lo: [pl.make(hi, cout, cout, (1,)), pl.make(lo, cout, cout, (1,))]
             g[pfx + ".conv1.weight"] = _conv_wgrad(pl, two(dz1, dz1_lo), xP, cout, cin, 3, (0, 1, 2), torch.empty(cout, cin, 3, 3, **f32))
