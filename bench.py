@@ -564,6 +564,62 @@ def section_train(mta, dev, cores, do_cpu):
     return sec
 
 
+def section_train_large(mta, dev, cores, do_cpu):
+    """CNNRNNModelLarge training step (what the reference's example.sh:22 trains), batch 16 cached-format chunks, 1 GPU: train-mode
+    forward (batch-statistic BatchNorm, Dropout2d, dual LSTM, clamped attention with probability dropout, heads) + masked BCE +
+    backward + fused clip/Adam, with the step's stream plan (LSTM weight gradients beside the next backward recurrence, the local
+    layer's chain beside the main stack).  The roofline object is the WHOLE step against the bf16 matrix peak (3 x forward FLOPs)."""
+    import torch
+    B, K, W, T = 16, 4, 2, 937
+    g = torch.Generator().manual_seed(1234)
+    model = seeded_model(mta, "cnn_rnn_large", str(dev), dropout=0.2)
+    opt = mta.make_optimizer(model, lr=1e-4)
+    lengths = torch.randint(469, T + 1, (B,), generator=g)
+    lengths[0] = T
+    mel = torch.rand(B, 1, N_MELS, T, generator=g) * 60.0 - 70.0
+    roll = (torch.rand(B, 88, T, generator=g) < 0.04).float()
+    for b in range(B):
+        mel[b, :, :, lengths[b]:] = 0.0
+        roll[b, :, lengths[b]:] = 0.0
+    meld, rolld = mel.to(dev), roll.to(dev)
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        loss = model.compute_loss(model(meld), rolld, lengths)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    model.model.raise_on_train_handoff_timeout()
+    tf = 3.0 * 326.47e9 * B * T / 938.0 * K / el / 1e12
+    sec = {"workload": "CNNRNNModelLarge training step (example.sh:22's model), batch=16 cached-format chunks, 1 GPU",
+           "value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_step": round(1e3 * el / K, 3), "steps": K,
+           "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "model_tflops_per_s": round(tf, 1),
+           "roofline": {"kernel": "whole training step (3 x forward FLOPs)", "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                        "per_kernel": "profiles/r03_train_large_b16_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --mode train --model cnn_rnn_large`)"},
+           "final_loss": round(float(loss.item()), 5)}
+    if do_cpu:
+        from oracle import model_ref
+        torch.set_num_threads(cores)
+        sd = {k: (v.detach().float() if v.dtype.is_floating_point else v.detach()).cpu().clone() for k, v in model.state_dict().items()}
+        batch = [(mel[:1].clone(), roll[:1].clone(), lengths[:1].clone())]
+        t1 = time.perf_counter()
+        model_ref.train_steps(sd, batch, o=model_ref.Opts(fast_lstm=True), model_type="cnn_rnn_large")
+        dt = time.perf_counter() - t1
+        sec["cpu_baseline"] = {"value": round(1 / dt, 3), "unit": "chunks/s", "cores": cores, "kind": "port",
+                               "sample": f"1 step on 1 chunk: fp32 torch-CPU train-mode forward + autograd backward + clip + Adam (oracle.train_steps), {cores} threads"}
+    return sec
+
+
 def section_corpus(mta, dev, cores, do_cpu):
     """BASELINE.json configs[4] on one GPU: the whole synthetic "MAESTRO test split" (177 recordings, 20 h, gamma-distributed
     lengths) through music_transcription_amd.corpus.transcribe_shard -- the code path of scripts/transcribe_corpus.py --
@@ -880,7 +936,8 @@ def main():
             # (the training section first: the HIP runtime deals a process's streams onto its hardware queues in creation order,
             #  and after the streams of the Large section the training step's side stream ends up sharing a queue with the
             #  stream it is meant to overlap -- 630 instead of 700 chunks/s)
-            for name, fn in (("configs3_train_b16", section_train), ("configs2_large_b16", section_large), ("configs4_corpus", section_corpus)):
+            for name, fn in (("configs3_train_b16", section_train), ("train_large_b16", section_train_large), ("configs2_large_b16", section_large),
+                             ("configs4_corpus", section_corpus)):
                 t1 = time.perf_counter()
                 try:
                     sections[name] = fn(mta, dev, cores, not args.no_cpu_baseline)

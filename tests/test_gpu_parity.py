@@ -781,8 +781,14 @@ def test_bench_line_contract(tmp_path):
     assert c["batch_per_gpu"] == 32 and c["coscheduled_batches_per_forward"] == 4 and c["streams_per_gpu"] == 4 and "workload" in c
     rf = d["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0
-    assert {"configs1_other_schedules", "configs2_large_b16", "configs3_train_b16"} <= set(d)
-    assert "error" not in d["configs2_large_b16"] and "error" not in d["configs3_train_b16"]
+    assert {"configs1_other_schedules", "configs2_large_b16", "configs3_train_b16", "train_large_b16", "configs4_corpus"} <= set(d)
+    for sec in ("configs2_large_b16", "configs3_train_b16", "train_large_b16", "configs4_corpus"):
+        assert "error" not in d[sec], (sec, d[sec])
+    assert sum(c["forwards_in_timed_region"].values()) >= 3 and c["distinct_chunks_per_forward"] is True
+    # every kernel's roofline fraction in one compact object, for the three workloads
+    assert {"all", "all_large", "all_train"} <= set(rf) and len(rf["all"]) >= 10 and all(0.0 < v < 1.0 for v in rf["all"].values())
+    cz = d["configs4_corpus"]
+    assert cz["chunks"] > 2000 and cz["finite"] and cz["notes"] > 1000 and cz["value"] > 500
 
 
 def test_bench_two_ranks_rehearsal(tmp_path):
