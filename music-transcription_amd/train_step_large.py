@@ -682,6 +682,19 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             for t_ in [v for k_, v in g.items() if k_.startswith("rnn_local.")]:
                 t_.record_stream(main_st)              # allocated under side stream B, consumed by autograd on the calling stream
         sv["_keep_lstm_bwd"] = keep_all                # (referenced until the backward pass returns)
+        # data parallel: every parameter ABOVE the convolution stack -- both LSTMs, attention, LayerNorm, shared_fc, the heads:
+        # 99 % of the 89 M parameters and one contiguous tail of the flat gradient buffer -- is final here, while the whole
+        # convolution backward (about half of the step) is still to run: their all-reduce starts now, under it
+        # (optim.EarlyBucket; the onset / offset heads' zero gradients under a frame-only loss ride along so that the tail
+        # stays contiguous -- the optimizer still skips those parameters, see CnnRnnLargeTrainFn.backward).
+        model._early_taken = set()
+        if getattr(model, "_grad_sync", None) is not None:
+            conv_pfx = ("conv1.", "res_block1.", "res_block2.", "freq_aware_conv.")
+            early = {k_: v_ for k_, v_ in g.items() if v_ is not None and not k_.startswith(conv_pfx)}
+            for k_ in model._grad_sync.reduce_early(early, main_st):
+                keep_all.append(g[k_])
+                g[k_] = None
+                model._early_taken.add(k_)
         dX0 = torch.empty(M, K0, **f32)
         _gemm(dG0, ldg, pk["ml_wihT"], ldg, dX0, K0, M, K0, ldg)
         # ---- freq_aware_conv
@@ -770,8 +783,13 @@ class CnnRnnLargeTrainFn(torch.autograd.Function):
             for n in ctx.names:
                 if n.startswith(("onset_head.", "offset_head.")):
                     g[n] = None
-        # (FusedAdamClip reads this: p.grad is a view of its flat buffer there, never None)
-        ctx.model._params_without_grad = set(getattr(ctx.model, "_params_without_grad", ())) | {n for n in ctx.names if g[n] is None}
+        # (FusedAdamClip reads this: p.grad is a view of its flat buffer there, never None.  Parameters whose gradient the
+        #  early all-reduce took over are None here too, but they DO have a gradient -- only the frame-only heads do not.)
+        early = getattr(ctx.model, "_early_taken", set())
+        no_grad = {n for n in ctx.names if g[n] is None and n not in early}
+        if ctx.frame_only:
+            no_grad |= {n for n in ctx.names if n.startswith(("onset_head.", "offset_head."))}
+        ctx.model._params_without_grad = set(getattr(ctx.model, "_params_without_grad", ())) | no_grad
         return (None, None, None, None, None, None, None) + tuple(g[n] for n in ctx.names)
 
 

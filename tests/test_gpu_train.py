@@ -391,7 +391,8 @@ def test_preprocess_and_cache_end_to_end(mta, tmp_path):
     assert np.array_equal(roll1.numpy(), MD.chunk_roll(m, 30.0, 47.0)[:, :531])
 
 
-def test_data_parallel_training_two_ranks(mta):
+@pytest.mark.parametrize("mtype", ["cnn_rnn", "cnn_rnn_large"])
+def test_data_parallel_training_two_ranks(mta, mtype):
     """Two ranks (torch.distributed.run, gloo between processes that share this box's GPU), different data per rank:
     after three steps of all-reduce(mean) + fused clip/Adam every rank holds bit-identical parameters -- the same ones whether the
     gradients of the upper LSTM layers and the fc are reduced early, under the rest of the backward pass, or all at once."""
@@ -401,14 +402,16 @@ def test_data_parallel_training_two_ranks(mta):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for early in ("1", "0"):          # with the tail of the flat gradient all-reduced under the backward pass (optim.EarlyBucket), and without
-        env = dict(os.environ, MT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MT_DP_EARLY_BUCKET=early)
+        env = dict(os.environ, MT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MT_DP_EARLY_BUCKET=early, MT_DP_MODEL=mtype)
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                             "--master-port", "29533", os.path.join(root, "tests", "tools", "dp_check.py")], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-3000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         out = json.loads(line)
-        assert out["world"] == 2 and out["identical_parameters"], out
+        assert out["world"] == 2 and out["identical_parameters"] and out["model"] == mtype, out
         assert all(np.isfinite(out["losses_rank0"])) and len(out["losses_rank0"]) == 3
+        if mtype == "cnn_rnn_large":       # CNNRNNModelLarge: everything above the convolutions is reduced under the convolution backward,
+            assert out["onset_offset_heads_untouched"] is True, out       # and the heads without a gradient path stay as they were
         outs[early] = out
     assert outs["1"]["early_bucket_reduces"] == 3 and outs["0"]["early_bucket_reduces"] == 0
     # the same sums in a different order of collectives: identical parameters
