@@ -737,6 +737,8 @@ def main():
             w = w + 0.02 * torch.randn(w.shape, device=dev, generator=gen)
         parts.append(w.clamp_(-1.0, 1.0) if c else w)
     wave_f = torch.cat(parts)[:C * B].contiguous()
+    if os.environ.get("MT_BENCH_TILE_CHUNKS") == "1":       # rounds 1-2: four distinct chunks repeated through the forward (A/B of the data effect)
+        wave_f = torch.cat([base[:4]] * (C * B // 4))[:C * B].contiguous()
     wave = wave_f[:B]
     del parts
     model = seeded_model(mta, "cnn_rnn", str(dev))

@@ -5,7 +5,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, pmc, dst = os.path.join(ROOT, "gpurun_out", "refresh"), os.path.join(ROOT, "gpurun_out", "pmc"), os.path.join(ROOT, "profiles")
 names = {"default": "bench_default", "1stream": "bench_1stream", "1forward": "bench_1forward", "train": "train_b16", "train_large": "train_large_b16", "large": "large_b16"}
 for k, n in names.items():
@@ -18,7 +18,8 @@ for k, n in names.items():
         newest = max(os.path.getmtime(f) for f in stats)
         latest = [f for f in stats if newest - os.path.getmtime(f) < 300]
         shutil.copy(max(latest, key=os.path.getsize), os.path.join(dst, f"{R}_{n}_kernel_stats.csv"))
-for f in ("pmc_traffic.json", "pmc_mfma_util.json", "pmc_traffic_b32.json", "pmc_mfma_util_b32.json"):
+for f in ("pmc_traffic.json", "pmc_mfma_util.json", "pmc_traffic_b32.json", "pmc_mfma_util_b32.json", "pmc_traffic_large.json", "pmc_mfma_util_large.json",
+          "pmc_traffic_train.json", "pmc_mfma_util_train.json"):
     if os.path.exists(os.path.join(pmc, f)):
         shutil.copy(os.path.join(pmc, f), os.path.join(dst, f"{R}_{f}"))
 print("\n".join(sorted(os.listdir(dst))))

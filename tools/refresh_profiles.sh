@@ -1,4 +1,4 @@
-# Regenerates the round's evidence under gpurun_out/refresh (one gpurun call); copy the results to profiles/r02_*.
+# Regenerates the round's evidence under gpurun_out/refresh (one gpurun call); copy the results to profiles/r03_*.
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/refresh
