@@ -314,6 +314,11 @@ constexpr int G256_LDS = 2 * (BM2 + BN2) * BK * 2;
 // lagging wave still reads it.  (Two phases of 32 MFMAs per K-tile, re-measured in round 2 with the gx16 epilogue: 0 ... 4 % at K = 1024, nothing
 // at K = 5120: not kept.  The kernel's 128 KB of LDS leave no room for a second workgroup or a recurrence workgroup on its CU, so its
 // register count -- 200 with the epilogue's bias values held through the main loop -- is not a co-residency matter any more.)
+// Round 3, built and dropped: the same phases fed through FOUR 32-deep, 32 KB buffers with the DMA three sub-steps (six phases)
+// ahead behind a counted vmcnt(8) -- never a vmcnt(0) in the loop.  Bit-identical, slower: 4.20 against 3.86 ms at K = 5120,
+// 1.06 against 1.00 ms at K = 1024 (M = 120 064): the loop does not wait for DMA latency (a request is two to three phases old
+// when it is waited for, and that suffices); what it is short of is the CU's vector-memory path (tools/gemm_persist_bench.py,
+// the note at persist_ok), and 64-byte rows make each LDS-DMA instruction fetch 16 half-lines instead of 8 whole ones.
 // A wave's 128 x 64 outputs are 8 x 4 tiles of 16 x 16 (C: column = lane & 15,
 // rows 4 (lane >> 4) + j); fragment reads stay conflict-free under the same swizzle (lane = row & 15, 16-B chunk
 // 4 ks + (lane >> 4)).
