@@ -710,7 +710,6 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import music_transcription_amd as mta
-    from music_transcription_amd import model as mt_model
 
     B, K, W = args.batch, args.steps, args.warmup
     C = max(1, min(args.cosched, 4, K))               # batches per forward (the recurrence interleaves at most 4 batch groups of 32)
@@ -719,10 +718,6 @@ def main():
     # A STEP is one pass of the hot path over one batch of B = 32 chunks (BASELINE configs[1]).  The steps of the timed region are
     # issued C at a time as one forward over C x 32 chunks (K % C left-over steps as one smaller forward at the end), and --streams
     # such forwards are in flight: C x streams batches of 32 at once, against round 1's 3 (one per stream).
-    # One batch per forward (--cosched 1) with >= 3 streams: the XCD-local 16-unit recurrence (csrc/lstm.hip, mode 2) holds 64 CUs
-    # per launch instead of 128; it takes effect only if a census launch shows the dispatcher dealing workgroups evenly over the XCDs.
-    if "MT_LSTM_MODE" not in os.environ and C == 1 and max(1, args.streams) >= 3:
-        os.environ["MT_LSTM_MODE"] = "2"
     # seeded synthetic input: noise + decaying piano-range sinusoids; seed = 1234 + rank.
     # Four distinct chunks tiled to the batch keep host-side synthesis short; the kernels see B chunks.
     # Eight chunks are synthesised on the host (that is what takes time there); the other chunks of a forward are DISTINCT
@@ -829,7 +824,6 @@ def main():
     elapsed = time.perf_counter() - t0
     for nb_ in sorted({nb_ for _, nb_ in sched}):
         net.raise_on_handoff_timeout(nb_ * B, T)
-    hl_mode = int(mt_model._LSTM_MODE.get(dev_index, 0))        # what the timed region actually ran (census may have refused mode 2)
     log(f"timed region: {elapsed:.3f} s for {K} steps")
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -844,8 +838,6 @@ def main():
         K1 = 8
         fused_hl = bool(net.fuse_input_projection)
         net.fuse_input_projection = False
-        mode_hl = mt_model._LSTM_MODE.get(dev_index, 0)
-        mt_model._LSTM_MODE[dev_index] = 0               # one forward in flight: the agent-scope kernel
         try:
             for nb in sorted({C, 1}, reverse=True):
                 n = nb * B
@@ -872,7 +864,6 @@ def main():
             log(f"un-overlapped passes failed ({type(e).__name__}: {str(e)[:200]}): stages fall back to the timed region's")
             one_ms = {}
         net.fuse_input_projection = fused_hl
-        mt_model._LSTM_MODE[dev_index] = mode_hl
 
     if rank == 0:
         # ---- per-kernel times from the events recorded inside the timed region (several batches in flight: kernels of
@@ -905,8 +896,6 @@ def main():
         for fname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
-                # (the 1-stream pass runs the agent-scope recurrence, mt::lstm_rec_kernel; the XCD-local mt::lstm_rec16_kernel of a
-                #  multi-stream headline is a different kernel)
                 hit = [v for k, v in prof.items() if ("lstm_rec_kernel" in k if dom_key == "lstm_rec" else dom_key.split("_l")[0] in k.replace("::", "_"))]
                 if hit and B == 32 and json.load(open(os.path.join(ROOT, "profiles", fname))).get("batches_per_forward", 1) == C:
                     traffic = round(sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in hit) / sum(v["launches"] for v in hit))
@@ -926,7 +915,6 @@ def main():
                 cpu = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
         sections = {}
         if world == 1 and not args.no_sections:
-            mt_model._LSTM_MODE[dev_index] = 0           # the sections below run the agent-scope recurrence
             del mel, cmax
             net._ws.clear()
             torch.cuda.empty_cache()
@@ -971,7 +959,7 @@ def main():
                                         f"their batch groups in one persistent launch), dealt round-robin over {NS} streams: "
                                         f"{NS} forwards in flight; the batches beyond whole rounds of {NS} x {C} run as a last round of smaller forwards side by side.  One batch of {B} per forward, the literal configs[1] schedule: configs1_other_schedules.b32_streams_3",
                           "distinct_chunks_per_forward": True,
-                          "fused_input_projection": bool(net.fuse_input_projection), "lstm_mode": hl_mode},
+                          "fused_input_projection": bool(net.fuse_input_projection)},
                "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
                "roofline_one_batch": roofline_one_batch, "stages_one_batch": stages_one_batch,
                "roofline_overlapped": roofline_overlapped, "stages_overlapped": stages_overlapped, **sections}

@@ -46,7 +46,7 @@ extern "C" {
  * exponent range for gradients; BASELINE configs[3] names bf16).  The un-suffixed entry points are the bf16 forms. */
 #define MT_DT_BF16 0
 #define MT_DT_F16  1
-/* Flag OR-ed into `dt` of mt_gemm_lstm_gx_dt and into `mode` of mt_lstm_bidir_fwd_ex (mode 0 only): the gate pre-activations
+/* Flag OR-ed into `dt` of mt_gemm_lstm_gx_dt and into `flags` of mt_lstm_bidir_fwd_ex: the gate pre-activations
  * travel between the two as f16 -- same [group][t][dir][unit/8][gate][unit%8][chunk%32] layout, half the bytes of the largest
  * intermediate of the forward (492 -> 246 MB per layer at B = 32); round-to-nearest-even of W_ih x + b, added in f32 by the
  * cell update.  Inference only (the training step keeps its gates in f32).                                                  */
@@ -174,16 +174,11 @@ int    mt_lstm_bidir_fwd(const float* gx, const float* w_hh, float* hx, void* sy
  * units), bias [2][4H] = b_ih + b_hh.  H <= 512.                                                                       */
 int    mt_lstm_bidir_fwd_xproj(const float* hx_prev, const float* w_ihx, const float* bias, const float* w_hh, float* hx,
                                void* sync_ws, size_t sync_bytes, int B, int T, int H, mt_stream_t stream);
-/* mode 0: as above (agent-scope hand-off, correct under any workgroup placement).  mode 2: XCD-local hand-off with
- * 16 hidden units per workgroup: the H/16 workgroups of a (direction, batch group) read their hardware XCC id, gather
- * on ONE XCD and exchange h through that XCD's L2 (plain stores, L1-bypassing loads: an L2 round trip per step instead
- * of a trip through the fabric).  It needs the dispatcher to deal the launch's workgroups evenly over the 8 XCDs
- * (liveness only; bounded spins report otherwise in the status word): check once with mt_xcd_census (host array of 8
- * counts; scratch32 = 32 device bytes; synchronises the stream).  (Mode 1, the same with 8 units per workgroup, lost to
- * both and is gone.)                                                                                                    */
+/* As mt_lstm_bidir_fwd, with flags: 0, or MT_GX_F16 (gx holds f16 gate pre-activations).  (The XCD-local hand-off variants
+ * that this entry point used to select -- "mode 1" with 8 and "mode 2" with 16 units per workgroup -- lost to the agent-scope
+ * kernel with interleaved batch groups at every schedule and are gone, and mt_xcd_census with them.)                       */
 int    mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
-                            int B, int T, int H, int mode, mt_stream_t stream);
-int    mt_xcd_census(int* counts_host, void* scratch32, int nwg, mt_stream_t stream);
+                            int B, int T, int H, int flags, mt_stream_t stream);
 /* CUs held by persistent launches still pending on streams other than `stream` on the current device (see above). */
 int    mt_persistent_cus_in_flight(mt_stream_t stream);
 /* hx -> X[(t*B+b)*ldx + dir*H + j] bf16 (next GEMM's A) / y[b][t][dir*H + j] f32 (torch layout). */
@@ -199,7 +194,6 @@ typedef struct {
     int n_mels;                              /* input mel bins                                    */
     int hidden;                              /* LSTM hidden size (1..1024); laid out padded to 16 */
     int layers;                              /* LSTM layers (<= MT_MAX_LSTM_LAYERS)               */
-    int lstm_mode;                           /* 0 agent-scope hand-off, 2 XCD-local (mt_lstm_bidir_fwd_ex) */
     int operand_dtype;                       /* MT_DT_BF16 / MT_DT_F16: type of every 16-bit weight below and of the */
                                              /*   activations between the kernels (model.py packs f16 for inference) */
     const float* conv1_w;                    /* [32][9]  BN-folded                                */
@@ -295,7 +289,6 @@ typedef struct {
     int n_mels, hidden, layers, hidden_local;     /* real sizes (hidden_local = hidden / 2)            */
     int use_attention, use_heads, heads, head_dim_pad;  /* head_dim padded to a multiple of 64         */
     float attn_scale;                             /* (real head_dim)^-1/2                              */
-    int lstm_mode;                                /* 0 agent-scope hand-off, 2 XCD-local               */
     int operand_dtype;                            /* MT_DT_BF16 / MT_DT_F16 (as mt_cnnrnn_weights)     */
     const float* conv1_w; const float* conv1_b;   /* [32][9], [32]                                     */
     const void*  rb1c1_w; const float* rb1c1_b;   /* bf16 [64][9*32]                                   */

@@ -51,7 +51,7 @@ class MelDesc(C.Structure):
 
 class CnnRnnWeights(C.Structure):
     """mt_cnnrnn_weights (include/mt_hip.h)."""
-    _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("lstm_mode", i32), ("operand_dtype", i32),
+    _fields_ = [("n_mels", i32), ("hidden", i32), ("layers", i32), ("operand_dtype", i32),
                 ("conv1_w", vp), ("conv1_b", vp), ("conv2_w", vp), ("conv2_b", vp),
                 ("w_ih", vp * MAX_LSTM_LAYERS), ("b_gates", vp * MAX_LSTM_LAYERS), ("w_hh", vp * MAX_LSTM_LAYERS),
                 ("fc_w", vp), ("fc_b", vp), ("w_ihx", vp * MAX_LSTM_LAYERS)]
@@ -60,7 +60,7 @@ class CnnRnnWeights(C.Structure):
 class CnnRnnLargeWeights(C.Structure):
     """mt_cnnrnn_large_weights (include/mt_hip.h)."""
     _fields_ = ([(n, i32) for n in ("n_mels", "hidden", "layers", "hidden_local", "use_attention", "use_heads", "heads", "head_dim_pad")]
-                + [("attn_scale", C.c_float), ("lstm_mode", i32), ("operand_dtype", i32)]
+                + [("attn_scale", C.c_float), ("operand_dtype", i32)]
                 + [(n, vp) for n in ("conv1_w", "conv1_b", "rb1c1_w", "rb1c1_b", "rb1c2_w", "rb1c2_b", "rb2c1_w", "rb2c1_b",
                                      "rb2c2_w", "rb2c2_b", "fa_w", "fa_b")]
                 + [("main_w_ih", vp * MAX_LSTM_LAYERS), ("main_b", vp * MAX_LSTM_LAYERS), ("main_w_hh", vp * MAX_LSTM_LAYERS)]
@@ -108,7 +108,6 @@ _SIGS = {
     "mt_lstm_bidir_fwd": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "mt_lstm_bidir_fwd_xproj": (i32, [vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "mt_lstm_bidir_fwd_ex": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]),
-    "mt_xcd_census": (i32, [vp, vp, i32, vp]),
     "mt_persistent_cus_in_flight": (i32, [vp]),
     "mt_lstm_relayout_bf16": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "mt_lstm_unpack_f32": (i32, [vp, vp, i32, i32, i32, vp]),

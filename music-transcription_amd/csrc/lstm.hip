@@ -42,10 +42,12 @@
 //     lines (loads that bypass the caches serialise at their line's home channel): 3.3 us;
 //   * flag stored right behind the payload without draining it (poison makes the order irrelevant): 3.05 us;
 //   * f16 exchange instead of two bf16 pieces: 2.45 us;  * no flag at all (one round trip instead of two): 1.88 us.
-// The XCD-local variant (lstm_rec16_kernel below: plain stores into one XCD's L2) polls the payload the same way.  Every spin is
-// bounded: on timeout the workgroup raises the abort word, which every other workgroup's spin also watches, and all leave.
+// Every spin is bounded: on timeout the workgroup raises the abort word, which every other workgroup's spin also watches, and
+// all leave.  (An XCD-local variant -- 16 units per workgroup, one (direction, batch group) per XCD, plain stores into that XCD's
+// L2 -- shipped as "mode 2" through round 2.  With the interleaved batch groups below the agent-scope kernel beats it at every
+// schedule bench.py reports (7.45k against 6.75k chunks/s at its own best case, one batch per forward on three streams), so it
+// was removed in round 3 together with its placement census.)
 #include "mt_common.h"
-#include <atomic>
 #include <stdlib.h>
 
 namespace mt {
@@ -56,14 +58,10 @@ struct LstmArgs {
     const float* gx;      // [NG][T][2][NKB][4][8][32]
     const float* w_hh;    // [2][4H][H]
     float* hx;            // [NG][T][2][NKB/2][64][8] f16 (typed float* in the C ABI)
-    unsigned* flags;      // unused (the hand-off has no flags any more); kept so that the sync workspace layout stays put
     unsigned* status;     // [0] = abort/timeout word, zeroed before every launch
     int B, T, H;
     int g0;               // first batch group of this launch
     int ngl;              // batch groups of this launch
-    // XCD-local mode (lstm_rec16_kernel): lanes = (direction, batch group) pairs of this launch,
-    unsigned* tickets;    // [8] per-XCD arrival counters, zeroed before every launch
-    int nlanes, xcd_off;  // lane l runs on the XCD with hardware id (l + xcd_off) & 7
     // train mode (lstm_rec_kernel<.., TRAIN = true>): what the backward pass needs (lstm_bwd.hip)
     float* gates_out;     // = gx: the ACTIVATED gates i, f, g, o overwrite the pre-activations in place
     float* cx;            // [NG][T][2][NKB][8][32] cell states
@@ -87,10 +85,6 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 __device__ __forceinline__ float tanhf_(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
 constexpr int OOB_OFF = 0x7FFFFF00;           // a buffer offset beyond every resource here: such loads return 0, such stores are dropped
 constexpr unsigned H_POISON = 0xFFFFFFFFu;   // never the bit pattern of a hidden state (|h| < 1)
-#ifndef MT_FLAG_REPL
-#define MT_FLAG_REPL 8
-#endif
-constexpr int FLAG_REPL = MT_FLAG_REPL;      // replicas of every step flag (XCD-local variants)
 constexpr int PAYLOAD_POLL_SLEEP = 10;       // s_sleep units (64 clocks) before a step's first payload poll: 8..14 measured equal, 24+ slower
 
 // Diagnostic build only (-DMT_LSTM_DIAG): per-phase wall-clock shares of a step, accumulated by wave 0
@@ -458,151 +452,6 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
 #endif
 }
 
-// XCD-local variant with FATTER workgroups (mode 2): 16 hidden units (64 gate rows = two MFMA M-tiles) per workgroup, so
-// a (direction, batch group) lane is H/16 workgroups that all sit on ONE XCD (hardware XCC id + arrival ticket, as above)
-// and that XCD's L2 is the coherence point of the whole exchange:
-//   * h_t is published with PLAIN stores (they stay in this XCD's L2) and gathered with sc1 loads (L1 bypass, L2 hit):
-//     a hand-off is an L2 round trip (~0.2 us) instead of a trip through the fabric to the memory side and back (~1 us);
-//   * no flags: as in the agent-scope kernel the payload loads are the poll (poison pattern = not yet published);
-//   * half the workgroups per lane means half the all-gather copies through that one L2 (32 x 32 KB per step at H = 512;
-//     the 8-unit XCD-local variant lost to the agent-scope kernel because 64 copies per step saturated it).
-// A workgroup's 16 units are exactly one 16-wide k-step of the published layout, so it writes one whole 1-KB block per step.
-// Which XCD a workgroup lands on is the dispatcher's choice (round-robin over the 8 XCDs); that is a liveness matter only,
-// checked once by mt_xcd_census, and every spin is bounded.
-constexpr int X16_POLL_SLEEP = 2;            // s_sleep units (64 clocks) before a step's first payload poll
-template <int NKSW>
-__global__ __launch_bounds__(256) void lstm_rec16_kernel(LstmArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4][64][36];       // [k-slice wave][lane][2 tiles x 16 regs + pad]: 144-B lane stride, conflict-free b128
-    __shared__ __attribute__((aligned(16))) f16_t hs[64][8];            // [(unit>>3)*32 + batch][unit & 7]
-    __shared__ int abort_s;
-    __shared__ int ident_s[2];
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int H = a.H, T = a.T, nkb = H >> 3, nks = H >> 4, nwg = H >> 4;
-    if (tid == 0) {
-        const int xcc = __builtin_amdgcn_s_getreg(20 /*HW_REG_XCC_ID*/ | (0 << 6) | ((4 - 1) << 11));
-        const int ln = (xcc - a.xcd_off) & 7;
-        ident_s[0] = ln;
-        ident_s[1] = ln < a.nlanes ? (int)__hip_atomic_fetch_add(a.tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
-        abort_s = 0;
-    }
-    __syncthreads();
-    const int ln = ident_s[0], wg = ident_s[1];
-    if (ln >= a.nlanes || wg >= nwg) return;
-    const int d = ln & 1, g = a.g0 + (ln >> 1);
-    const int b = lane & 31, hh = lane >> 5;
-    const int Bg = min(32, a.B - g * 32);
-
-    const int r = lane & 31, q = r >> 3, rh = (r >> 2) & 1, p = r & 3;
-    f16x8 w16[2][NKSW];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int wrow = p * H + wg * 16 + m * 8 + 2 * q + rh;
-        const float* wsrc = a.w_hh + ((size_t)d * 4 * H + wrow) * H;
-#pragma unroll
-        for (int i = 0; i < NKSW; ++i) {
-            const int ks = wv * NKSW + i;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w16[m][i][j] = (ks < nks) ? (f16_t)wsrc[ks * 16 + 8 * hh + j] : (f16_t)0.0f;
-        }
-    }
-    const int jl = 2 * wv + hh;                         // unit inside an 8-unit half (M-tile m): unit = 8m + jl
-    float c[2] = {0.0f, 0.0f};
-    const size_t gd_blocks = (size_t)T * 2 * nkb;
-    const float* gx_g = a.gx + (size_t)g * gd_blocks * 1024;
-    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
-    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
-
-    for (int s = 0; s < T; ++s) {
-        const int t = d ? (T - 1 - s) : s;
-        const int tprev = d ? (t + 1) : (t - 1);
-        float gxv[2][4];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const float* gxp = gx_g + (((size_t)t * 2 + d) * nkb + 2 * wg + m) * 1024 + jl * 32 + b;
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) gxv[m][pp] = (b < Bg) ? gxp[pp * 256] : 0.0f;
-        }
-        f32x16 acc[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
-        if (s > 0) {
-            sleep64(a.sleep_first);
-            // gather h_{t-1} from this XCD's L2 and run the f16 MFMA chain; a word that still holds the poison pattern has not
-            // been published: redo (bounded)
-            const int hbase = ((tprev * 2 + d) * nkb) * 512 + lane * 16;
-            long long t1 = 0;
-            for (unsigned it = 0;; ++it) {
-                typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-                u32x4 rhv[NKSW];
-#pragma unroll
-                for (int i = 0; i < NKSW; ++i) {
-                    const int ks = wv * NKSW + i;
-                    rhv[i] = (ks < nks) ? __builtin_amdgcn_raw_buffer_load_b128(hrsrc, hbase + ks * 1024, 0, 16 /*sc1: bypass L1, served by this XCD's L2*/)
-                                        : u32x4{0, 0, 0, 0};
-                }
-                unsigned worst = 0;
-#pragma unroll
-                for (int i = 0; i < NKSW; ++i) {
-                    worst = max(max(worst, max(rhv[i][0], rhv[i][1])), max(rhv[i][2], rhv[i][3]));
-                    const f16x8 hv = __builtin_bit_cast(f16x8, rhv[i]);
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w16[m][i], hv, acc[m], 0, 0, 0);
-                }
-                if (!__any(worst == H_POISON)) break;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[m][e] = 0.0f;
-                sleep64(a.sleep_retry);
-                if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                    if (lane == 0) abort_s = 1;          // another workgroup gave up: leave with it
-                    break;
-                }
-                if ((it & 255u) == 255u) {
-                    const long long now = __builtin_amdgcn_s_memrealtime();
-                    if (t1 == 0) t1 = now;
-                    else if (now - t1 > LSTM_SPIN_LIMIT_TICKS) {
-                        if (lane == 0) {
-                            __hip_atomic_store(a.status, 0x40000000u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            abort_s = 1;
-                        }
-                        break;
-                    }
-                }
-            }
-        }
-        // ---- sum the four K-slices through LDS (b128 both ways); wave wv finishes gate rows 8wv + 4h + p of both tiles
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4)
-                *(f32x4*)(&red[wv][lane][m * 16 + 4 * e4]) = f32x4{acc[m][4 * e4], acc[m][4 * e4 + 1], acc[m][4 * e4 + 2], acc[m][4 * e4 + 3]};
-        __syncthreads();
-        if (abort_s) return;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const f32x4 r0 = *(const f32x4*)(&red[0][lane][m * 16 + 4 * wv]), r1 = *(const f32x4*)(&red[1][lane][m * 16 + 4 * wv]);
-            const f32x4 r2 = *(const f32x4*)(&red[2][lane][m * 16 + 4 * wv]), r3 = *(const f32x4*)(&red[3][lane][m * 16 + 4 * wv]);
-            float pre[4];
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + gxv[m][pp];
-            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
-            c[m] = fmaf(fg, c[m], ig * gg);
-            const float hval = og * tanhf_(c[m]);
-            hs[m * 32 + b][jl] = (f16_t)hval;            // block lane = (k half = m)*32 + batch, element = unit & 7
-        }
-        __syncthreads();                                 // block assembled; every wave is done with `red`
-        if (wv == 0) {
-            typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-            const u32x4 ph = *(const u32x4*)(&hs[lane][0]);
-            const int hoff = ((t * 2 + d) * nkb) * 512 + wg * 1024 + lane * 16;
-            __builtin_amdgcn_raw_buffer_store_b128(ph, hrsrc, hoff, 0, 0 /*plain: stays in this XCD's L2*/);
-        }
-    }
-}
-
 // Layer output for (g, t, d): nks blocks of 1 KB: [lane = (k half)*32 + batch][8 f16], k = 16 ks + 8 half + j.
 // hx -> X[(t*B + b)][d*H + k] bf16 (next layer's GEMM A matrix), round-to-nearest.
 // H = layout hidden size (multiple of 16), Hv <= H = real hidden size (units >= Hv are zero padding and are
@@ -677,17 +526,6 @@ int persistent_cancel(hipStream_t st);
 #define MT_PERSISTENT_LAUNCH(kernel, grid, who) MT_PERSISTENT_LAUNCH_N(kernel, grid, 256, who)
 
 template <int NKSW>
-static int launch_rec16(const LstmArgs& a, hipStream_t st) {
-    // (6 of the 8 XCDs' workgroups leave at once when the launch has one batch group: only the lanes' 2 x H/16 stay)
-    const int stay = a.nlanes * (a.H >> 4);
-    int rc = persistent_admit((const void*)lstm_rec16_kernel<NKSW>, 256, 0, stay, st, "mt_lstm_bidir_fwd (XCD-local)");
-    if (rc != MT_OK) return rc;
-    hipLaunchKernelGGL((lstm_rec16_kernel<NKSW>), dim3(8 * (a.H >> 4)), dim3(256), 0, st, a);
-    MT_CHECK_LAUNCH_OR_CANCEL();
-    return persistent_mark(st);
-}
-
-template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, bool g16, hipStream_t st) {
     if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
     else if (a.cx) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, true, false>), dim3(a.H >> 3, 2, ngroups), 320, "mt_lstm_bidir_fwd_train");
@@ -710,74 +548,45 @@ using namespace mt;
 
 extern "C" size_t mt_lstm_gx_bytes(int B, int T, int H) { return (size_t)cdiv(B, 32) * T * 2 * (H >> 3) * 4096; }
 extern "C" size_t mt_lstm_hx_bytes(int B, int T, int H) { return (size_t)cdiv(B, 32) * T * 2 * (H >> 3) * 512; }
-extern "C" size_t mt_lstm_sync_bytes(int B, int H) { return align_up(256 + (size_t)cdiv(B, 32) * 2 * FLAG_REPL * (H >> 3) * 4, 256); }
+// (the hand-off has no flags: the sync workspace is the status word's own cache line, plus one spare line)
+extern "C" size_t mt_lstm_sync_bytes(int B, int H) { (void)B; (void)H; return 512; }
 
 // One bidirectional LSTM layer's recurrence.  gx from mt_gemm_lstm_gx, w_hh = [fwd; reverse] (2 x 4H x H f32),
 // hx receives every step's hidden state (layer output, MFMA-operand layout).  sync_ws: mt_lstm_sync_bytes().
 // After the stream has drained, word 0 of sync_ws is 0 on success, 1 + step on a hand-off timeout.
-// Workgroups of a `nwg`-workgroup launch per hardware XCC id (host array of 8 ints).  Synchronises the stream.
-__global__ void xcd_census_kernel(unsigned* counts) {
-    if (threadIdx.x == 0) {
-        const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));
-        atomicAdd(counts + (xcc & 7), 1u);
-    }
-}
-extern "C" int mt_xcd_census(int* counts_host, void* scratch32, int nwg, mt_stream_t stream) {
-    MT_REQUIRE(counts_host && scratch32 && nwg > 0, MT_EINVAL, "mt_xcd_census: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    MT_CHECK_HIP(hipMemsetAsync(scratch32, 0, 32, st));
-    hipLaunchKernelGGL(xcd_census_kernel, dim3(nwg), dim3(256), 0, st, (unsigned*)scratch32);
-    MT_CHECK_LAUNCH();
-    MT_CHECK_HIP(hipMemcpyAsync(counts_host, scratch32, 32, hipMemcpyDeviceToHost, st));
-    MT_CHECK_HIP(hipStreamSynchronize(st));
-    return MT_OK;
-}
-
 static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
-                         int B, int T, int H, int xcd_local, mt_stream_t stream, float* cx = nullptr,
+                         int B, int T, int H, int flags, mt_stream_t stream, float* cx = nullptr,
                          const float* w_ihx = nullptr, const float* bias = nullptr, const float* hx_prev = nullptr) {
     MT_REQUIRE((gx || w_ihx) && w_hh && hx && sync_ws, MT_EINVAL, "mt_lstm_bidir_fwd: null pointer");
     MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 1024, MT_EUNSUPPORTED,
                "mt_lstm_bidir_fwd: hidden size %d unsupported (multiple of 16, <= 1024)", H);
     MT_REQUIRE(sync_bytes >= mt_lstm_sync_bytes(B, H), MT_EWORKSPACE, "mt_lstm_bidir_fwd: sync workspace too small");
     const int nkb = H >> 3, ng = cdiv(B, 32);
-    const bool g16 = (xcd_local & MT_GX_F16) != 0;
-    xcd_local &= ~MT_GX_F16;
-    MT_REQUIRE(!g16 || (xcd_local == 0 && !cx && !w_ihx), MT_EINVAL, "mt_lstm_bidir_fwd_ex: MT_GX_F16 goes with mode 0 only");
+    const bool g16 = (flags & MT_GX_F16) != 0;
+    MT_REQUIRE(!g16 || (!cx && !w_ihx), MT_EINVAL, "mt_lstm_bidir_fwd_ex: MT_GX_F16 is for plain inference launches only");
     MT_REQUIRE((size_t)T * 2 * nkb * 512 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_bidir_fwd: T*H too large for one buffer descriptor");
     MT_REQUIRE((((size_t)w_hh | (size_t)w_ihx) & 15) == 0, MT_EINVAL, "mt_lstm_bidir_fwd: weight matrices must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
     MT_CHECK_HIP(hipMemsetAsync(hx, 0xFF, mt_lstm_hx_bytes(B, T, H), st));   // poison: see the hand-off note above
-    // sync_ws: [0] status word, [32..64) XCD tickets, [256..) flags (own cache lines, away from the polled status word)
+    // sync_ws: [0] status word (its own cache line)
     static const int env_first = getenv("MT_LSTM_POLL_FIRST") ? atoi(getenv("MT_LSTM_POLL_FIRST")) : -1;
     static const int env_retry = getenv("MT_LSTM_POLL_RETRY") ? atoi(getenv("MT_LSTM_POLL_RETRY")) : -1;
-    LstmArgs a{gx, w_hh, hx, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, 0, 0, (unsigned*)((char*)sync_ws + 32), 0, 0,
+    LstmArgs a{gx, w_hh, hx, (unsigned*)sync_ws, B, T, H, 0, 0,
                cx ? const_cast<float*>(gx) : nullptr, cx, w_ihx, bias, hx_prev,
-               env_first >= 0 ? env_first : (xcd_local ? X16_POLL_SLEEP : PAYLOAD_POLL_SLEEP), env_retry >= 0 ? env_retry : 0};
-    // every workgroup of a launch must be resident (they wait on each other).  Agent-scope variant: at most 256
-    // workgroups (one per CU) per launch -- for plain inference each set of 2 H/8 workgroups carries up to 4 batch groups
-    // interleaved (lstm_rec_kernel, NG), the training / fused-projection variants one; XCD-local variant: at most 8 lanes =
-    // 4 batch groups per launch, each lane's H/16 workgroups share one XCD.  Further groups run as further launches.
-    static std::atomic<unsigned> rotate{0};
+               env_first >= 0 ? env_first : PAYLOAD_POLL_SLEEP, env_retry >= 0 ? env_retry : 0};
+    // every workgroup of a launch must be resident (they wait on each other): at most 256 workgroups (one per CU) per launch --
+    // for plain inference each set of 2 H/8 workgroups carries up to 4 batch groups interleaved (lstm_rec_kernel, NG), the
+    // training / fused-projection variants one.  Further groups run as further launches.
     const int zmax = (256 / (2 * nkb)) > 0 ? (256 / (2 * nkb)) : 1;
     const int nksw = cdiv(nkb / 2, 4);
-    const int per_launch = xcd_local ? 4 : ((cx || w_ihx || nksw > 8) ? zmax : 4 * zmax);
+    const int per_launch = (cx || w_ihx || nksw > 8) ? zmax : 4 * zmax;
     for (int g0 = 0; g0 < ng; g0 += per_launch) {
         a.g0 = g0;
         const int n = (ng - g0) < per_launch ? (ng - g0) : per_launch;
         a.ngl = n;
-        a.nlanes = 2 * n;
-        a.xcd_off = xcd_local ? (int)(rotate.fetch_add(2 * n) & 7) : 0;
-        if (xcd_local && g0 > 0) MT_CHECK_HIP(hipMemsetAsync((char*)sync_ws + 32, 0, 32, st));   // fresh tickets per launch
         int rc;
-        if (xcd_local == 2) {                  // XCD-local, 16 units per workgroup
-            if (nksw <= 1) rc = launch_rec16<1>(a, st);
-            else if (nksw <= 2) rc = launch_rec16<2>(a, st);
-            else if (nksw <= 4) rc = launch_rec16<4>(a, st);
-            else if (nksw <= 8) rc = launch_rec16<8>(a, st);
-            else rc = launch_rec16<16>(a, st);
-        } else if (nksw <= 1) rc = launch_rec<1>(a, n, g16, st);
+        if (nksw <= 1) rc = launch_rec<1>(a, n, g16, st);
         else if (nksw <= 2) rc = launch_rec<2>(a, n, g16, st);
         else if (nksw <= 4) rc = launch_rec<4>(a, n, g16, st);
         else if (nksw <= 8) rc = launch_rec<8>(a, n, g16, st);
@@ -810,12 +619,11 @@ extern "C" int mt_lstm_bidir_fwd_train(float* gx_inout, const float* w_hh, float
     return lstm_fwd_impl(gx_inout, w_hh, hx, sync_ws, sync_bytes, B, T, H, 0, stream, cx);
 }
 
-// mode 0: agent-scope hand-off (placement-independent); mode 2: XCD-local, 16 units per workgroup (lstm_rec16_kernel).
+// flags: 0, or MT_GX_F16 (gx holds f16 gate pre-activations, as mt_gemm_lstm_gx_dt(.. | MT_GX_F16) stores them).
 extern "C" int mt_lstm_bidir_fwd_ex(const float* gx, const float* w_hh, float* hx, void* sync_ws, size_t sync_bytes,
-                                    int B, int T, int H, int mode, mt_stream_t stream) {
-    MT_REQUIRE(mode == 0 || mode == 2 || mode == MT_GX_F16, MT_EINVAL,
-               "mt_lstm_bidir_fwd_ex: mode must be 0 (agent-scope hand-off; | MT_GX_F16: gx is f16) or 2 (XCD-local, 16 units per workgroup)");
-    return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, mode, stream);
+                                    int B, int T, int H, int flags, mt_stream_t stream) {
+    MT_REQUIRE(flags == 0 || flags == MT_GX_F16, MT_EINVAL, "mt_lstm_bidir_fwd_ex: flags must be 0 or MT_GX_F16 (gx is f16)");
+    return lstm_fwd_impl(gx, w_hh, hx, sync_ws, sync_bytes, B, T, H, flags, stream);
 }
 
 extern "C" int mt_lstm_relayout_dt(const float* hx, void* X, int ldx, float* Y, int ldy, int col_off, int B, int T, int H, int Hv,

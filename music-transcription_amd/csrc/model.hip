@@ -112,11 +112,11 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
     // l & 1, so the layer above reads its predecessor's while writing its own.
     const bool from_hx = dt == MT_DT_F16 && H == Hv && H % 64 == 0;
     // f16 operands + agent-scope recurrence: the gate pre-activations travel GEMM -> recurrence as f16 (MT_GX_F16, include/mt_hip.h)
-    const int gx16 = (dt == MT_DT_F16 && w->lstm_mode == 0) ? MT_GX_F16 : 0;
+    const int gx16 = (dt == MT_DT_F16) ? MT_GX_F16 : 0;
     for (int l = 0; l < w->layers; ++l) {
         const bool last = l + 1 == w->layers;
         // layers > 0 with packed W_ihx: input projection fused into the recurrence (reads the previous layer's hx directly)
-        const bool fused = l > 0 && w->w_ihx[l] && w->lstm_mode == 0 && H <= 512;
+        const bool fused = l > 0 && w->w_ihx[l] && H <= 512;
         if (fused) {
             if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;              // (no projection GEMM: empty stage)
             if ((rc = mt_lstm_bidir_fwd_xproj((const float*)hcur, w->w_ihx[l], w->b_gates[l], w->w_hh[l], (float*)hnext,
@@ -135,11 +135,11 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
             }
             if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
             if ((rc = mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * l,
-                                           p.sync_stride, B, T, H, w->lstm_mode | gx16, stream)) != MT_OK) return rc;
+                                           p.sync_stride, B, T, H, gx16, stream)) != MT_OK) return rc;
         }
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
         // the next consumer of feature ROWS: a GEMM-projected layer, or the final fc (none when they read hx directly)
-        const bool next_fused = !last && w->w_ihx[l + 1] && w->lstm_mode == 0 && H <= 512;
+        const bool next_fused = !last && w->w_ihx[l + 1] && H <= 512;
         if (!next_fused && !from_hx)
             if ((rc = mt_lstm_relayout_dt((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, H, Hv, dt, stream)) != MT_OK) return rc;
         if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;

@@ -148,10 +148,10 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
         MT_CHECK_HIP(hipStreamWaitEvent((hipStream_t)side_stream, (hipEvent_t)ev_fork, 0));
     }
     // f16 operands + agent-scope recurrence: the gate pre-activations travel GEMM -> recurrence as f16 (MT_GX_F16, include/mt_hip.h)
-    const int gx16 = (dt == MT_DT_F16 && w->lstm_mode == 0) ? MT_GX_F16 : 0;
+    const int gx16 = (dt == MT_DT_F16) ? MT_GX_F16 : 0;
     RUN(mt_gemm_lstm_gx_sched(ws + p.x0, p.K0, w->local_w_ih, p.K0, w->local_b, (float*)(ws + p.gx2), B, T, p.Hlp, p.K0, dt | gx16, ws + p.sched, ls));
     REC();
-    RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, w->lstm_mode | gx16, ls));
+    RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx2), w->local_w_hh, (float*)(ws + p.hx2), ws + p.sync, p.sync_stride, B, T, p.Hlp, gx16, ls));
     REC();
     RUN(mt_lstm_relayout_dt((const float*)(ws + p.hx2), ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 2 * Hv, B, T, p.Hlp, Hl, dt, ls));
     REC();
@@ -163,7 +163,7 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
     const bool from_hx = dt == MT_DT_F16 && p.Hp == Hv && Hv % 64 == 0;
     for (int l = 0; l < w->layers; ++l) {
         const bool last = l + 1 == w->layers;
-        const bool fused = l > 0 && w->main_w_ihx[l] && w->lstm_mode == 0 && p.Hp <= 512;
+        const bool fused = l > 0 && w->main_w_ihx[l] && p.Hp <= 512;
         if (fused) {
             REC();                                               // (no projection GEMM: empty stage)
             RUN(mt_lstm_bidir_fwd_xproj((const float*)hcur, w->main_w_ihx[l], w->main_b[l], w->main_w_hh[l], (float*)hnext,
@@ -182,10 +182,10 @@ static int large_forward_impl(const mt_cnnrnn_large_weights* w, const float* mel
             }
             REC();
             RUN(mt_lstm_bidir_fwd_ex((const float*)(ws + p.gx), w->main_w_hh[l], (float*)hcur, ws + p.sync + p.sync_stride * (l + 1),
-                                  p.sync_stride, B, T, p.Hp, w->lstm_mode | gx16, stream));
+                                  p.sync_stride, B, T, p.Hp, gx16, stream));
         }
         REC();
-        const bool next_fused = !last && w->main_w_ihx[l + 1] && w->lstm_mode == 0 && p.Hp <= 512;
+        const bool next_fused = !last && w->main_w_ihx[l + 1] && p.Hp <= 512;
         if (last) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.rb, p.Cp, (float*)(ws + p.r32), p.comb, 0, B, T, p.Hp, Hv, dt, stream));
         else if (!next_fused && !from_hx) RUN(mt_lstm_relayout_dt((const float*)hcur, ws + p.x1, p.K1, nullptr, 0, 0, B, T, p.Hp, Hv, dt, stream));
         REC();

@@ -25,33 +25,6 @@ from ._lib import lib, check, ptr, CnnRnnWeights, CnnRnnLargeWeights
 BN_EPS = 1e-5
 
 
-_LSTM_MODE: Dict[int, int] = {}
-
-
-def lstm_mode(device) -> int:
-    """Hand-off protocol of the recurrence kernel on this device: 0 = agent-scope (default; correct under any
-    workgroup placement), 2 = XCD-local with 16 units per workgroup (csrc/lstm.hip).  MT_LSTM_MODE=2 opts in, and only
-    takes effect if a census launch shows the dispatcher dealing workgroups evenly over the 8 XCDs."""
-    import os
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx not in _LSTM_MODE:
-        env = os.environ.get("MT_LSTM_MODE", "0")
-        if env != "2":
-            _LSTM_MODE[idx] = 0
-        else:
-            import ctypes
-            counts = (ctypes.c_int * 8)()
-            scratch = torch.empty(32, dtype=torch.uint8, device=dev)
-            ok = True
-            with torch.cuda.device(dev):
-                for nwg in (512, 256, 128):
-                    check(lib.mt_xcd_census(counts, ptr(scratch), nwg, _lib.stream_ptr()), "mt_xcd_census")
-                    ok = ok and all(c == nwg // 8 for c in counts)
-            _LSTM_MODE[idx] = int(env) if ok else 0
-    return _LSTM_MODE[idx]
-
-
 def _round_up(v: int, a: int) -> int:
     return (v + a - 1) // a * a
 
@@ -300,7 +273,6 @@ class CNNRNNModel(nn.Module, _HipForward):
             import ctypes
             n_ev = len(events)
             ev_arr = (ctypes.c_void_p * n_ev)(*[e.cuda_event for e in events])
-        w.lstm_mode = lstm_mode(x.device)
         # Layers > 0 can take their input projection inside the recurrence (no GEMM, no gx buffer, no re-layout between LSTM
         # layers; csrc/lstm.hip, XP).  It lengthens the latency-bound recurrence and removes GEMM work: a loss with one batch in
         # flight, a gain with several (the GEMMs are the shared resource then) -- so the caller decides.  MT_LSTM_XPROJ=0/1 forces it.
@@ -488,7 +460,6 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
                 self._ws.pop(k, None)
             self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         ws = self._ws[key]
-        w.lstm_mode = lstm_mode(x.device)
         # a side stream + fork/join events per caller stream: the local LSTM branch runs beside the main LSTM stack
         if not hasattr(self, "_side"):
             self._side = {}

@@ -97,10 +97,9 @@ def test_gemm_bf16(mta, M, N, K):
 
 
 # ------------------------------------------------------------------ LSTM layer (input projection + recurrence)
-@pytest.mark.parametrize("mode", [0, 2])
 @pytest.mark.parametrize("B,T,H,K", [(2, 20, 16, 64), (5, 33, 32, 128), (32, 40, 512, 1024), (33, 12, 256, 192), (1, 50, 64, 64),
                                      (150, 9, 64, 64), (70, 11, 32, 64), (32, 300, 512, 128)])    # 5 / 3 batch groups: interleaved in one launch; the last: input projection on the 256 x 256 tile
-def test_lstm_layer_matches_oracle(mta, B, T, H, K, mode):
+def test_lstm_layer_matches_oracle(mta, B, T, H, K):
     from music_transcription_amd._lib import lib, check, ptr, stream_ptr
     g = torch.Generator().manual_seed(B * 1000 + T * 10 + H)
     bound = 1.0 / np.sqrt(H)
@@ -125,7 +124,7 @@ def test_lstm_layer_matches_oracle(mta, B, T, H, K, mode):
     y = torch.empty(B, T, 2 * H, device="cuda")
     s = stream_ptr()
     check(lib.mt_gemm_lstm_gx(ptr(X), K, ptr(Wp), K, ptr(bg), ptr(gx), B, T, H, K, s))
-    check(lib.mt_lstm_bidir_fwd_ex(ptr(gx), ptr(whh), ptr(hx), ptr(sync), sync.numel(), B, T, H, mode, s))
+    check(lib.mt_lstm_bidir_fwd(ptr(gx), ptr(whh), ptr(hx), ptr(sync), sync.numel(), B, T, H, s))
     check(lib.mt_lstm_unpack_f32(ptr(hx), ptr(y), B, T, H, s))
     torch.cuda.synchronize()
     assert int(sync[:4].view(torch.int32).item()) == 0, "hand-off timeout"

@@ -13,7 +13,7 @@ B, T, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (32, 938, 5
 vp = C.c_void_p
 lib.mt_lstm_gx_bytes.restype = lib.mt_lstm_hx_bytes.restype = lib.mt_lstm_sync_bytes.restype = C.c_size_t
 lib.mt_lstm_bidir_fwd_ex.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, vp]
-MODE = int(os.environ.get("MT_LSTM_MODE", "0"))
+MODE = 0
 lib.mt_lstm_diag_read.argtypes = [vp]
 gx = torch.randn(lib.mt_lstm_gx_bytes(B, T, H) // 4, device="cuda") * 0.5
 whh = ((torch.rand(2, 4 * H, H, device="cuda") * 2 - 1) / np.sqrt(H)).contiguous()
