@@ -515,17 +515,16 @@ int    mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_x, int l
                      const float* mask2d, double* sums, void* dza, int pitch_a, void* dza_lo, void* dzb, int pitch_b, void* dzb_lo,
                      float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b,
                      int B, int F, int T, int C, int relu, int pool, mt_stream_t stream);
-/* Channels-last -> zero-padded position-major planes: dst[c*ld + (b*(F+2ph) + f+ph)*Tp + t + toff] = src[((b*F+f)*T+t)*pitch + c]
- * (dst pre-zeroed by the caller).  With the gradient plane (toff = 1) and three activation planes (toff = 2, 1, 0 for
- * kernel columns kw = 0, 1, 2) the weight gradient of a KH x 3 convolution is, per kw, one batched NT GEMM over the
- * positions: tap kh is the pointer offset (kh - ph)*Tp into the activation plane, Tp % 8 == 0.                       */
-int    mt_cl_to_planar(const void* src, int pitch, int C, void* dst, long long ld, int B, int F, int T, int ph, int Tp,
-                       int toff, mt_stream_t stream);
-/* The same for up to 3 column shifts at once: plane k (the source shifted by toffs[k] <= 8 columns; HOST array) goes to rows
- * [k*plane_rows, k*plane_rows + C) of dst -- one read of the source, 16-byte stores (Tp % 8 == 0, ld % 8 == 0, pitch % 8 == 0,
- * 16-byte aligned buffers).  Destination columns [0, Tp) of the rows it touches are written (zeros outside the sequence). */
-int    mt_cl_to_planar_multi(const void* src, int pitch, int C, void* dst, long long ld, int plane_rows, int B, int F, int T, int ph,
-                             int Tp, int ntoff, const int* toffs, mt_stream_t stream);
+/* (r3) Weight gradient of a channels-last convolution (csrc/conv_wgrad.hip; replaces round 2's position planes + batched GEMM): what autograd computes for the
+ * convolutions of ResidualBlock and freq_aware_conv (cnn_rnn_model.py:76-124,:186-196) under train_transcriber.py:130.
+ *   out[co][ci][kh][kw] (f32, the reference's weight layout) = sum over (b, f, t) of
+ *       (dz_hi + dz_lo)[b][f][t][co] * x[b][f + kh - KH/2][t + kw - KW/2][ci]            (zero outside the image)
+ * dz_hi / dz_lo: bf16 [B][F][T][dz_pitch] (the gradient and its rounding remainder; dz_lo may be NULL), x: bf16
+ * [B][F][T][x_pitch].  Cout % 64 == 0, Cin % 32 == 0, KH odd, KW = 3 or 1, pitches % 8 == 0, 16-byte aligned tensors,
+ * F*T*pitch*2 < 2 GB.  ws: mt_conv_wgrad_ws_bytes() of scratch (partial sums per K split, added in a fixed order).      */
+size_t mt_conv_wgrad_ws_bytes(int B, int F, int T, int Cout, int Cin, int KH, int KW);
+int    mt_conv_wgrad(const void* dz_hi, const void* dz_lo, int dz_pitch, const void* x, int x_pitch, int B, int F, int T,
+                     int Cout, int Cin, int KH, int KW, void* ws, size_t ws_bytes, float* out, mt_stream_t stream);
 /* General form of mt_conv_cl_dt: A / S are channel slices (pitchA / pitchS elements between positions) and accum != 0
  * adds the result to `out` -- the input gradient of freq_aware_conv (256 output channels) is two calls.              */
 int    mt_conv_cl_ex(const void* A, int pitchA, const void* S, int pitchS, const void* W, const float* bias, void* out,

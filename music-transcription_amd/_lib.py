@@ -164,8 +164,8 @@ _SIGS = {
     "mt_dropout2d_mask": (i32, [vp, i32, i32, C.c_float, C.c_uint, C.c_uint, vp]),
     "mt_bn_act_fwd": (i32, [vp] * 12 + [i32] * 8 + [vp]),
     "mt_bn_act_bwd": (i32, [vp, i32, vp, i32] + [vp] * 13 + [i32, vp, vp, i32, vp] + [vp] * 4 + [i32] * 6 + [vp]),
-    "mt_cl_to_planar": (i32, [vp, i32, i32, vp, ll, i32, i32, i32, i32, i32, i32, vp]),
-    "mt_cl_to_planar_multi": (i32, [vp, i32, i32, vp, ll, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "mt_conv_wgrad_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
+    "mt_conv_wgrad": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
     "mt_conv_cl_ex": (i32, [vp, i32, vp, i32, vp, vp, vp] + [i32] * 13 + [vp]),
     "mt_transpose_bf16_batched": (i32, [vp, ll, ll, i32, i32, vp, ll, ll, i32, i32, vp]),
     "mt_attn_softmax_train": (i32, [vp, i32, vp, i32, i32, ll, C.c_float, C.c_float, C.c_float, C.c_uint, C.c_uint, vp]),

@@ -4,9 +4,7 @@
 //   ResidualBlock / freq_aware_conv (cnn_rnn_model.py:76-99,:186-202) with BatchNorm BATCH statistics:
 //     bn_act_fwd      out = Dropout2d( MaxPool( ReLU( BN_a(za) [+ BN_b(zb)] ) ) )   (pool, ReLU, second branch, dropout optional)
 //     bn_act_bwd      the backward of the same, two passes (per-channel sums of dy, dy*xhat_a, dy*xhat_b; then dz_a, dz_b)
-//     cl_to_planar    channels-last activations / gradients -> zero-padded position-major planes [C][positions]: with them a
-//                     conv weight gradient is ONE batched NT GEMM per kernel column (taps along f are pointer offsets,
-//                     the contraction runs over positions, split over workgroups) -- no im2col
+//     (the convolutions' weight gradients: conv_wgrad.hip)
 //   MultiHeadAttention (cnn_rnn_model.py:118-139): softmax with the +-10 clamp and probability dropout, and its backward
 //     (clamp => zero gradient outside [-clip, clip]), around batched GEMMs
 //   LayerNorm(x + attn) (cnn_rnn_model.py:243,:322): forward with saved statistics, backward (dx, dgamma, dbeta)
@@ -257,67 +255,6 @@ __global__ void bn_act_param_grads_kernel(const double* __restrict__ sums, float
     if (dgamma_a) dgamma_a[c] = (float)sums[C + c];
     if (dbeta_b) dbeta_b[c] = (float)sums[c];
     if (dgamma_b) dgamma_b[c] = (float)sums[2 * C + c];
-}
-
-// ------------------------------------------------------------------------------------------------ channels-last -> padded planes
-// src [B][F][T][pitch] bf16 (channels c0..c0+C at +c) -> dst[c*ld + (b*Fp + f + ph)*Tp + t + toff], Fp = F + 2 ph.
-// The destination is zero-filled by the caller; a block moves 64 frames x 64 channels through LDS.
-__global__ __launch_bounds__(256) void cl_to_planar_kernel(const bf16_t* __restrict__ src, int pitch, int C, bf16_t* __restrict__ dst,
-                                                           long long ld, int B, int F, int T, int ph, int Tp, int toff) {
-    __shared__ bf16_t tile[64][66];
-    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int bf = blockIdx.z, b = bf / F, f = bf - b * F;
-    const bf16_t* s = src + ((size_t)bf * T) * pitch;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int tl = i >> 6, cl = i & 63;
-        tile[tl][cl] = (t0 + tl < T && c0 + cl < C) ? s[(size_t)(t0 + tl) * pitch + c0 + cl] : (bf16_t)0;
-    }
-    __syncthreads();
-    const size_t rowbase = ((size_t)b * (F + 2 * ph) + f + ph) * Tp + toff;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int cl = i >> 6, tl = i & 63;
-        if (c0 + cl < C && t0 + tl < T) dst[(size_t)(c0 + cl) * ld + rowbase + t0 + tl] = tile[tl][cl];
-    }
-}
-
-// Several column-shifted planes from ONE read of the source: plane k (rows k*plane_rows + c) holds the source shifted by toffs[k]
-// columns -- the three kernel columns of a KH x 3 convolution's weight-gradient GEMM.  A block moves 64 destination columns x
-// 64 channels: the source frames [t0 - 8, t0 + 64) come in as 16-byte channel vectors, go through LDS transposed, and every
-// plane leaves as 16-byte stores of 8 consecutive columns (the shift is taken on the LDS read).  Destination columns outside
-// the shifted sequence are written as zeros, rows and columns outside [0, Tp) are the caller's zero fill.
-__global__ __launch_bounds__(256) void cl_to_planar_multi_kernel(const bf16_t* __restrict__ src, int pitch, int C, bf16_t* __restrict__ dst,
-                                                                 long long ld, int plane_rows, int B, int F, int T, int ph, int Tp,
-                                                                 int ntoff, int toff0, int toff1, int toff2) {
-    __shared__ bf16_t tile[64][72 + 2];
-    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int bf = blockIdx.z, b = bf / F, f = bf - b * F;
-    const bf16_t* s = src + ((size_t)bf * T) * pitch;
-    for (int i = threadIdx.x; i < 72 * 8; i += 256) {
-        const int tl = i >> 3, cg = i & 7, t = t0 - 8 + tl, c = c0 + cg * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t >= 0 && t < T && c + 8 <= C) v = *(const uint4*)(s + (size_t)t * pitch + c);
-        else if (t >= 0 && t < T) {
-            bf16_t tmp[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) tmp[e] = c + e < C ? s[(size_t)t * pitch + c + e] : (bf16_t)0;
-            v = *(const uint4*)tmp;
-        }
-        const bf16_t* pv = (const bf16_t*)&v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tile[cg * 8 + e][tl] = pv[e];
-    }
-    __syncthreads();
-    const size_t rowbase = ((size_t)b * (F + 2 * ph) + f + ph) * Tp;
-    const int ncol = min(64, Tp - t0);                       // destination columns of this block (a multiple of 8)
-    for (int i = threadIdx.x; i < ntoff * 64 * 8; i += 256) {
-        const int k = i / 512, r = i - k * 512, cl = r >> 3, q = r & 7;
-        if (c0 + cl >= C || q * 8 >= ncol) continue;
-        const int toff = k == 0 ? toff0 : (k == 1 ? toff1 : toff2);
-        bf16_t o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = tile[cl][8 + q * 8 + e - toff];      // source frame t0 + 8q + e - toff (zero outside [0, T))
-        *(uint4*)(dst + ((size_t)k * plane_rows + c0 + cl) * ld + rowbase + t0 + q * 8) = *(const uint4*)o;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------ batched bf16 transpose
@@ -629,30 +566,6 @@ extern "C" int mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_
     hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3((unsigned)g), dim3(256), 0, ST(stream), a);
     MT_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_act_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST(stream), sums, dbeta_a, dgamma_a, dbeta_b, dgamma_b, C);
-    MT_CHECK_LAUNCH();
-    return MT_OK;
-}
-
-extern "C" int mt_cl_to_planar(const void* src, int pitch, int C, void* dst, long long ld, int B, int F, int T, int ph, int Tp, int toff,
-                               mt_stream_t stream) {
-    MT_REQUIRE(src && dst && pitch >= C && C > 0 && B > 0 && F > 0 && T > 0 && ph >= 0 && toff >= 0 && Tp >= T + toff &&
-               ld >= (long long)B * (F + 2 * ph) * Tp, MT_EINVAL, "mt_cl_to_planar: bad arguments");
-    MT_REQUIRE((long long)B * F < 65536, MT_EUNSUPPORTED, "mt_cl_to_planar: B*F too large for one launch");
-    hipLaunchKernelGGL(cl_to_planar_kernel, dim3(cdiv(T, 64), cdiv(C, 64), B * F), dim3(256), 0, ST(stream), (const bf16_t*)src, pitch, C,
-                       (bf16_t*)dst, ld, B, F, T, ph, Tp, toff);
-    MT_CHECK_LAUNCH();
-    return MT_OK;
-}
-
-extern "C" int mt_cl_to_planar_multi(const void* src, int pitch, int C, void* dst, long long ld, int plane_rows, int B, int F, int T, int ph, int Tp,
-                                     int ntoff, const int* toffs, mt_stream_t stream) {
-    MT_REQUIRE(src && dst && toffs && pitch >= C && pitch % 8 == 0 && C > 0 && B > 0 && F > 0 && T > 0 && ph >= 0 && ntoff >= 1 && ntoff <= 3 &&
-               plane_rows >= C && Tp % 8 == 0 && ld % 8 == 0 && ld >= (long long)B * (F + 2 * ph) * Tp && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
-               MT_EINVAL, "mt_cl_to_planar_multi: bad arguments");
-    for (int k = 0; k < ntoff; ++k) MT_REQUIRE(toffs[k] >= 0 && toffs[k] <= 8 && Tp >= T + toffs[k], MT_EINVAL, "mt_cl_to_planar_multi: bad column shift %d", toffs[k]);
-    MT_REQUIRE((long long)B * F < 65536, MT_EUNSUPPORTED, "mt_cl_to_planar_multi: B*F too large for one launch");
-    hipLaunchKernelGGL(cl_to_planar_multi_kernel, dim3(cdiv(Tp, 64), cdiv(C, 64), B * F), dim3(256), 0, ST(stream), (const bf16_t*)src, pitch, C,
-                       (bf16_t*)dst, ld, plane_rows, B, F, T, ph, Tp, ntoff, toffs[0], ntoff > 1 ? toffs[1] : 0, ntoff > 2 ? toffs[2] : 0);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

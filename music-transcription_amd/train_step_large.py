@@ -13,8 +13,8 @@ f64-accumulated, dropout masks from a counter-based hash seeded from torch's CPU
 
 Every dense contraction of the backward pass is an NT GEMM or a channels-last conv:
   * conv input gradients  = mt_conv_cl_* with flipped / transposed weights (a residual block's 3x3 + 1x1-skip pair in one call);
-  * conv weight gradients = per kernel column one batched GEMM over zero-padded position-major planes (mt_cl_to_planar):
-    taps along frequency are pointer offsets, the contraction over positions is split over workgroups -- no im2col;
+  * conv weight gradients = mt_conv_wgrad straight from the channels-last tensors (csrc/conv_wgrad.hip: both MFMA operands through
+    transposed LDS reads, the contraction over positions split over workgroups, no planes, no im2col);
   * attention: dPd = dO V^T, dV = Pd^T dO, dQ = dS K, dK = dS^T Q as per-(chunk, head) batched GEMMs around
     mt_attn_clamped_bwd.
 """
@@ -190,56 +190,13 @@ def _side_streams(dev):
     return _SIDE2[key]
 
 
-class _Planes:
-    """Zero-padded position-major planes of a channels-last tensor [B][F][T][C] (see mt_cl_to_planar): the operands of the
-    convolution weight-gradient GEMMs.  geometry: Fp = F + 2 ph rows per chunk, Tp2 = roundup(T + 2, 8) columns per row."""
-
-    def __init__(self, B, F, T, ph, dev):
-        self.B, self.F, self.T, self.ph = B, F, T, ph
-        self.Tp2 = _ru(T + 2, 8)
-        self.npos = B * (F + 2 * ph) * self.Tp2
-        self.S = max(1, min(96, self.npos // 2048))                # K splits (workgroups along the contraction)
-        self.Ks = _ru(-(-self.npos // self.S), 64)
-        self.Kp = self.S * self.Ks
-        self.front = ph * self.Tp2
-        self.ld = _ru(self.front + self.Kp + ph * self.Tp2 + 64, 8)
-        self.dev = dev
-
-    def make(self, src, pitch, C, toffs):
-        """-> tensor [rows][ld] with plane k (the source shifted by toffs[k] columns) at rows [k*C, (k+1)*C): the planes of the
-        three kernel columns are ADJACENT row blocks, so one weight-gradient GEMM takes them as N = 3 C columns (one launch
-        instead of three, and a 32-channel input fills 96 of a 128-wide tile instead of 32).  rows leaves room for the GEMM's
-        contract (W readable up to roundup(N, 128) rows from any plane's first row)."""
-        rows = _ru(len(toffs) * C, 128) + 128
-        out = torch.zeros(rows, self.ld, device=self.dev, dtype=torch.bfloat16)
-        import ctypes as C_
-        base = out.reshape(-1)[self.front:]
-        arr = (C_.c_int * len(toffs))(*toffs)
-        check(lib.mt_cl_to_planar_multi(ptr(src), pitch, C, ptr(base), self.ld, C, self.B, self.F, self.T, self.ph, self.Tp2, len(toffs), arr, _st()),
-              "mt_cl_to_planar_multi")
-        return out
-
-
-def _conv_wgrad(pl: _Planes, dzPs, xP, Cout, Cin, KH, kws, out):
-    """out (f32, reference layout [Cout][Cin][KH][len(kws)]) = sum over positions of dz[pos][co] * x[pos + tap][ci].
-    dzPs: list of planes tensors (one plane, toff 1) whose sum is dz (the bf16 value and, optionally, its rounding remainder:
-    BatchNorm makes the sum cancel heavily); xP: planes for kernel columns 0, 1, 2 (toffs 2, 1, 0) in adjacent row blocks of
-    Cin rows; kws: the kernel columns wanted ((0, 1, 2) for a KH x 3 conv, (1,) with KH = 1 for the 1x1 skip).  Tap kh is the
-    pointer offset (kh - KH // 2) * Tp2 into the activation plane; the kernel columns are N = len(kws) * Cin columns of ONE
-    batched NT GEMM per piece of dz (batch = K split x kernel rows)."""
-    dev = pl.dev
-    nkw, npc = len(kws), len(dzPs)
-    N = nkw * Cin
-    part = torch.empty(npc, pl.S, KH, Cout, N, device=dev, dtype=torch.float32)
-    red = torch.empty(KH, Cout, N, device=dev, dtype=torch.float32)
-    w = xP[kws[0] * Cin:].reshape(-1)[pl.front - (KH // 2) * pl.Tp2:]
-    for j, dzP in enumerate(dzPs):
-        a = dzP.reshape(-1)[pl.front:]
-        check(lib.mt_gemm_batched_f32(ptr(a), pl.ld, pl.Ks, 0, ptr(w), pl.ld, pl.Ks, pl.Tp2, None, ptr(part[j]), N,
-                                      KH * Cout * N, Cout * N, Cout, N, pl.Ks, pl.S * KH, KH, _st()), "mt_gemm_batched_f32 (conv wgrad)")
-    check(lib.mt_sum_slices_f32(ptr(part), KH * Cout * N, N, npc * pl.S, ptr(red), N, KH * Cout, N, _st()), "mt_sum_slices_f32")
-    # out[co][ci][kh][kw] = red[kh][co][kw * Cin + ci]
-    _gather4(red, 0, out, (Cout, Cin, KH, nkw), (N, 1, Cout * N, Cin))
+def conv_wgrad_direct(dz_hi, dz_lo, dz_pitch, x, x_pitch, B, F, T, Cout, Cin, KH, KW, out):
+    """out[Cout][Cin][KH][KW] (f32) = the convolution's weight gradient straight from the channels-last tensors (csrc/conv_wgrad.hip:
+    no planes, both MFMA operands through transposed LDS reads, every kernel row of a K range on one XCD).  dz_hi + dz_lo = dz."""
+    nws = lib.mt_conv_wgrad_ws_bytes(B, F, T, Cout, Cin, KH, KW)
+    ws = torch.empty(max(nws, 16) // 4, device=out.device, dtype=torch.float32)
+    check(lib.mt_conv_wgrad(ptr(dz_hi), ptr(dz_lo) if dz_lo is not None else None, dz_pitch, ptr(x), x_pitch, B, F, T, Cout, Cin, KH, KW,
+                            ptr(ws), nws, ptr(out), _st()), "mt_conv_wgrad")
     return out
 
 
@@ -652,19 +609,8 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         ev_in.record(main_st)
         slots_local = [slots.pop()]                    # (the local layer's status slot: taken now, the streams pop independently)
         keep_all = []
-        pre = {}                                       # activation planes of the conv weight gradients (they depend on saved tensors only)
         if use_side:
-            with torch.cuda.stream(side_a):            # ... made beside the backward recurrences, ahead of the LSTM weight gradients
-                side_a.wait_event(ev_in)
-                plf = _Planes(B, F2, T, 3, dev)
-                pre["fa"] = (plf, plf.make(sv["r2"], 128, 128, (2, 1, 0)))
-                for name_ in ("rb2", "rb1"):
-                    st_ = sv[name_]
-                    pl_ = _Planes(B, st_["Fin"], T, 1, dev)
-                    pre[name_] = (pl_, pl_.make(st_["xin"], st_["cin"], st_["cin"], (2, 1, 0)), pl_.make(st_["y1"], st_["cout"], st_["cout"], (2, 1, 0)))
-                for v_ in pre.values():
-                    for t_ in v_[1:]:
-                        t_.record_stream(main_st)
+            side_a.wait_event(ev_in)
             with torch.cuda.stream(side_b):
                 side_b.wait_event(ev_in)
                 keep_all += _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
@@ -697,6 +643,21 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
                 model._early_taken.add(k_)
         dX0 = torch.empty(M, K0, **f32)
         _gemm(dG0, ldg, pk["ml_wihT"], ldg, dX0, K0, M, K0, ldg)
+        # ---- convolution stack.  Weight gradients (csrc/conv_wgrad.hip: matrix-pipe bound, at most one workgroup per CU) go to side
+        #      stream A as soon as their dz exists, beside the chain of BatchNorm backward passes (HBM bound) and input-gradient
+        #      convolutions on the calling stream; joined at the end.
+        def wgrad(key, dz_hi, dz_lo, dzp, xt, xp, Fx, co, ci, KH, KW):
+            if not use_side:
+                g[key] = conv_wgrad_direct(dz_hi, dz_lo, dzp, xt, xp, B, Fx, T, co, ci, KH, KW, torch.empty(co, ci, KH, KW, **f32))
+                return
+            ev = torch.cuda.Event()
+            ev.record(main_st)
+            with torch.cuda.stream(side_a):
+                side_a.wait_event(ev)
+                g[key] = conv_wgrad_direct(dz_hi, dz_lo, dzp, xt, xp, B, Fx, T, co, ci, KH, KW, torch.empty(co, ci, KH, KW, **f32))
+                g[key].record_stream(main_st)
+                for t_ in (dz_hi, dz_lo, xt):           # allocated on the calling stream, read here: not to be reused before this is done
+                    t_.record_stream(side_a)
         # ---- freq_aware_conv
         masks = sv["masks"]
         z256 = pk["zeros256"]
@@ -707,13 +668,7 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         dr2 = torch.empty(B * F2 * T, 128, **bf)
         _conv(dzf, None, pk["fa_wdA"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256)
         _conv(dzf.reshape(-1)[128:], None, pk["fa_wdB"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256, accum=1)
-        pl, r2P = pre["fa"] if "fa" in pre else (None, None)
-        if pl is None:
-            pl = _Planes(B, F2, T, 3, dev)
-            r2P = pl.make(sv["r2"], 128, 128, (2, 1, 0))
-        g["freq_aware_conv.0.weight"] = torch.empty(256, 128, 7, 3, **f32)
-        _conv_wgrad(pl, [pl.make(dzf, 256, 256, (1,)), pl.make(dzf_lo, 256, 256, (1,))], r2P, 256, 128, 7, (0, 1, 2),
-                    g["freq_aware_conv.0.weight"])
+        wgrad("freq_aware_conv.0.weight", dzf, dzf_lo, 256, sv["r2"], 128, F2, 256, 128, 7, 3)
         g["freq_aware_conv.0.bias"] = torch.zeros(256, **f32)          # a conv bias in front of a BatchNorm: analytically zero
         # ---- residual blocks, top down
         dout = dr2
@@ -726,6 +681,9 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             _bn_act_bwd(dout, cout, None, 0, st["z2"], st["s2"], st["zs"], st["ss"], st["mask"], dz2, dzs,
                         (gr["bn2.weight"], gr["bn2.bias"], gr["skip.1.weight"], gr["skip.1.bias"]), B, Fin, T, cout, 1, pool, dev,
                         dza_lo=dz2_lo, dzb_lo=dzs_lo)
+            pfx = "res_block1" if name == "rb1" else "res_block2"
+            wgrad(pfx + ".conv2.weight", dz2, dz2_lo, cout, st["y1"], cout, Fin, cout, cout, 3, 3)
+            wgrad(pfx + ".skip.0.weight", dzs, dzs_lo, cout, xin, cin, Fin, cout, cin, 1, 1)
             dy1 = torch.empty(N, cout, **bf)
             _conv(dz2, None, pk[name + "c2_wd"], z256, dy1, B, Fin, T, cout, 0, cout, 3)
             dz1, dz1_lo = torch.empty(N, cout, **bf), torch.empty(N, cout, **bf)
@@ -734,18 +692,7 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             cin_p = max(cin, 64)
             dxin = torch.empty(N, cin_p, **bf)
             _conv(dz1, dzs, pk[name + "c1s_wd"], z256, dxin, B, Fin, T, cout, cout, cin_p, 3)
-            # weight gradients
-            if name in pre:
-                pl, xP, yP = pre[name]
-            else:
-                pl = _Planes(B, Fin, T, 1, dev)
-                xP = pl.make(xin, cin, cin, (2, 1, 0))
-                yP = pl.make(st["y1"], cout, cout, (2, 1, 0))
-            pfx = "res_block1" if name == "rb1" else "res_block2"
-            two = lambda hi, lo: [pl.make(hi, cout, cout, (1,)), pl.make(lo, cout, cout, (1,))]
-            g[pfx + ".conv1.weight"] = _conv_wgrad(pl, two(dz1, dz1_lo), xP, cout, cin, 3, (0, 1, 2), torch.empty(cout, cin, 3, 3, **f32))
-            g[pfx + ".conv2.weight"] = _conv_wgrad(pl, two(dz2, dz2_lo), yP, cout, cout, 3, (0, 1, 2), torch.empty(cout, cout, 3, 3, **f32))
-            g[pfx + ".skip.0.weight"] = _conv_wgrad(pl, two(dzs, dzs_lo), xP, cout, cin, 1, (1,), torch.empty(cout, cin, 1, 1, **f32))
+            wgrad(pfx + ".conv1.weight", dz1, dz1_lo, cout, xin, cin, Fin, cout, cin, 3, 3)
             for k in ("conv1.bias", "conv2.bias", "skip.0.bias"):
                 g[f"{pfx}.{k}"] = torch.zeros(cout, **f32)
             for k, v in gr.items():
@@ -758,6 +705,10 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         check(lib.mt_conv1_bwd(ptr(x), ptr(pk["w1"]), ptr(pk["b1"]), ptr(sv["mean1"]), ptr(sv["rstd1"]), ptr(pk["g1"]), ptr(pk["be1"]),
                                ptr(dout), 64, ptr(sums[128:]), ptr(g["conv1.0.weight"]), ptr(g["conv1.0.bias"]), ptr(g["conv1.1.weight"]),
                                ptr(g["conv1.1.bias"]), B, F, T, _st()), "mt_conv1_bwd")
+        if use_side:
+            evj = torch.cuda.Event()
+            evj.record(side_a)
+            main_st.wait_event(evj)
     return g
 
 

@@ -161,29 +161,39 @@ def test_bn_act_forward_backward_vs_autograd(mta, C, F_, T, B, two, relu, pool, 
         assert (gr[3].cpu() - bbr.grad).abs().max() < 2e-3 * max(1.0, float(bbr.grad.abs().max()))
 
 
-@pytest.mark.parametrize("B,F_,T,Cin,Cout,KH", [(2, 6, 21, 32, 64, 3), (1, 9, 70, 64, 128, 3), (2, 8, 33, 128, 256, 7), (3, 5, 17, 64, 64, 3)])
-def test_conv_weight_gradient_over_position_planes(mta, B, F_, T, Cin, Cout, KH):
-    """mt_cl_to_planar + batched GEMM == torch's conv2d weight gradient (and the 1x1 skip's), bf16 operands."""
+@pytest.mark.parametrize("B,F_,T,Cin,Cout,KH,xp,dp", [(2, 6, 21, 32, 64, 3, 32, 64), (1, 9, 70, 64, 128, 3, 64, 136), (2, 8, 133, 128, 256, 7, 128, 256),
+                                                      (3, 5, 17, 64, 64, 3, 72, 64), (1, 3, 64, 128, 128, 3, 128, 128), (2, 4, 65, 32, 128, 3, 64, 128),
+                                                      (1, 1, 1, 128, 64, 3, 128, 64), (4, 30, 200, 64, 128, 3, 64, 128)])
+def test_conv_weight_gradient_direct(mta, B, F_, T, Cin, Cout, KH, xp, dp):
+    """mt_conv_wgrad (transposed LDS reads of the channels-last tensors, two pieces of dz into one accumulator) == torch's conv2d weight
+    gradient for every channel tiling of the kernel (64 / 128 / 256 output, 32 / 64 / 128 input channels), ragged T (a partial last
+    64-frame tile, T = 64 exactly, T = 1), position pitches wider than the channel count, with and without the remainder piece, and
+    for the 1 x 1 skip; twice: bitwise reproducible."""
     from music_transcription_amd import train_step_large as TL
     g = torch.Generator().manual_seed(B * 100 + T + Cin)
-    x = _bf(torch.randn(B, F_, T, Cin, generator=g))
-    dz = _bf(torch.randn(B, F_, T, Cout + 8, generator=g))              # with a position pitch wider than the channel count
+    x = _bf(torch.randn(B, F_, T, xp, generator=g))
+    dzf = torch.randn(B, F_, T, dp, generator=g)
+    hi = _bf(dzf)
+    lo = _bf(dzf - hi)
+    xd, hid, lod = x.bfloat16().cuda().contiguous(), hi.bfloat16().cuda().contiguous(), lo.bfloat16().cuda().contiguous()
     ph = KH // 2
-    pl = TL._Planes(B, F_, T, ph, torch.device("cuda"))
+    xc = x[..., :Cin].permute(0, 3, 1, 2)
+    for pieces in (2, 1):
+        dz = (hi + lo) if pieces == 2 else hi
+        w = torch.zeros(Cout, Cin, KH, 3, requires_grad=True)
+        F.conv2d(xc.double(), w.double(), padding=(ph, 1)).backward(dz[..., :Cout].permute(0, 3, 1, 2).double())
+        with torch.cuda.device(0):
+            out = TL.conv_wgrad_direct(hid, lod if pieces == 2 else None, dp, xd, xp, B, F_, T, Cout, Cin, KH, 3, torch.empty(Cout, Cin, KH, 3, device="cuda"))
+            out2 = TL.conv_wgrad_direct(hid, lod if pieces == 2 else None, dp, xd, xp, B, F_, T, Cout, Cin, KH, 3, torch.empty(Cout, Cin, KH, 3, device="cuda"))
+        sc = float(w.grad.abs().max())
+        err = float((out.cpu() - w.grad).abs().max())
+        assert err < 1e-4 * sc + 1e-5, (pieces, err, sc)                # exact bf16 x bf16 products, f32 accumulation
+        assert torch.equal(out, out2)
+    w1 = torch.zeros(Cout, Cin, 1, 1, requires_grad=True)
+    F.conv2d(xc.double(), w1.double()).backward((hi + lo)[..., :Cout].permute(0, 3, 1, 2).double())
     with torch.cuda.device(0):
-        xP = pl.make(x.bfloat16().cuda().contiguous(), Cin, Cin, (2, 1, 0))
-        dP = pl.make(dz.bfloat16().cuda().contiguous(), Cout + 8, Cout, (1,))
-        out = TL._conv_wgrad(pl, [dP], xP, Cout, Cin, KH, (0, 1, 2), torch.empty(Cout, Cin, KH, 3, device="cuda"))
-        out1 = TL._conv_wgrad(pl, [dP], xP, Cout, Cin, 1, (1,), torch.empty(Cout, Cin, 1, 1, device="cuda")) if KH == 3 else None
-    w = torch.zeros(Cout, Cin, KH, 3, requires_grad=True)
-    xc, dzc = x.permute(0, 3, 1, 2), dz[..., :Cout].permute(0, 3, 1, 2)
-    F.conv2d(xc, w, padding=(ph, 1)).backward(dzc)
-    sc = float(w.grad.abs().max())
-    assert (out.cpu() - w.grad).abs().max() < 2e-3 * sc, ((out.cpu() - w.grad).abs().max(), sc)
-    if out1 is not None:
-        w1 = torch.zeros(Cout, Cin, 1, 1, requires_grad=True)
-        F.conv2d(xc, w1).backward(dzc)
-        assert (out1.cpu() - w1.grad).abs().max() < 2e-3 * float(w1.grad.abs().max())
+        out1 = TL.conv_wgrad_direct(hid, lod, dp, xd, xp, B, F_, T, Cout, Cin, 1, 1, torch.empty(Cout, Cin, 1, 1, device="cuda"))
+    assert float((out1.cpu() - w1.grad).abs().max()) < 1e-4 * float(w1.grad.abs().max()) + 1e-5
 
 
 def test_conv_cl_channel_slices_and_accumulate(mta):
