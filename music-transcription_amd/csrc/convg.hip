@@ -306,6 +306,11 @@ template <int DT>
 static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStream_t st) {
     // 64-channel weight chunks and 128-channel tiles where they apply and the tile still fits the 160 KB of LDS (a 128 + 128
     // channel input pair -- the fused input gradient of a residual block -- leaves room for 32-channel chunks only)
+    // 256-channel tiles (a wave = 64 positions x 128 channels: 0.75 KB of LDS reads per MFMA instead of 1 KB -- with 64 x 64 wave tiles
+    // the kernel sits AT the LDS bandwidth when the matrix pipe is full -- and the input tile staged once for all 256 channels):
+    // freq_aware_conv (128 -> 256, 7 x 3), 32-channel weight chunks so that tile + ring stay inside 160 KB
+    const bool bn256 = (a.Cout % 256 == 0) && !a.accum && !a.tie && cg_lds_bytes(a, 32, 256) <= 160 * 1024 &&
+                       (size_t)(pool ? CG_TF / 2 : CG_TF) * CG_TT * 256 * 2 <= 160 * 1024;
     const bool bn128 = (a.Cout % 128 == 0) && cg_lds_bytes(a, 32, 128) <= 160 * 1024;
     const bool kc64 = (a.C1 % 64 == 0) && (a.C2 % 64 == 0) && cg_lds_bytes(a, 64, bn128 ? 128 : 64) <= 160 * 1024;
 #define CG_DISPATCH(KC_, BN__)                                                                     \
@@ -315,6 +320,7 @@ static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStrea
         if (out_mode == 1) return cg_launch<KC_, BN__, false, CG_OUT_X, DT>(a, st);               \
         return cg_launch<KC_, BN__, false, CG_OUT_CL, DT>(a, st);                                 \
     } while (0)
+    if (bn256) CG_DISPATCH(32, 256);
     if (kc64 && bn128) CG_DISPATCH(64, 128);
     if (kc64) CG_DISPATCH(64, 64);
     if (bn128) CG_DISPATCH(32, 128);
