@@ -311,6 +311,10 @@ static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStrea
     // freq_aware_conv (128 -> 256, 7 x 3), 32-channel weight chunks so that tile + ring stay inside 160 KB
     const bool bn256 = (a.Cout % 256 == 0) && !a.accum && !a.tie && cg_lds_bytes(a, 32, 256) <= 160 * 1024 &&
                        (size_t)(pool ? CG_TF / 2 : CG_TF) * CG_TT * 256 * 2 <= 160 * 1024;
+    // (Measured and dropped, round 3: 32-row tiles with one wave across ALL channels for the 64 / 128-channel layers -- wave tiles of
+    //  64 x 64 / 64 x 128 instead of 64 x 32 / 64 x 64.  res_block1 went from 0.56 to 0.72 ms: the taller tile takes the CU alone,
+    //  and with one workgroup per CU nothing overlaps its synchronous input staging; two small workgroups per CU beat the lower LDS
+    //  traffic.  res_block2's first convolution: unchanged.)
     const bool bn128 = (a.Cout % 128 == 0) && cg_lds_bytes(a, 32, 128) <= 160 * 1024;
     const bool kc64 = (a.C1 % 64 == 0) && (a.C2 % 64 == 0) && cg_lds_bytes(a, 64, bn128 ? 128 : 64) <= 160 * 1024;
 #define CG_DISPATCH(KC_, BN__)                                                                     \
