@@ -104,144 +104,184 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs a) {
     }
 }
 
-template <bool APPLY>
+// Backward of the same.  One thread = FOUR channels of one output position (one or two pre-pool rows), two positions per loop pass
+// with every load of both issued before the first is used: a streaming pass needs tens of bytes in flight per lane to reach the HBM rate,
+// and the first version (8 channels per thread, 190 - 230 registers = two waves per SIMD, one position at a time) ran at 30 % of it.
+// TWO / POOL are compile-time so that a single-branch call does not carry the second branch's constants.
+//   pass 1 (APPLY = false): sums[c] += sum dy, sums[C + c] += sum dy*xhat_a, sums[2C + c] += sum dy*xhat_b
+//   pass 2 (APPLY = true):  dz_x = gamma_x rstd_x (dy - sum_dy/N - xhat_x sum_dyxhat_x/N), and the rounding remainders
+template <bool TWO> struct BnRaw { uint2 za[2], zb[2]; f32x4 g; bool has_out; int t, fh, b; };
+
+__device__ __forceinline__ void unpack4(const uint2& v, float (&f)[4]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint2 pack4(const float (&f)[4]) { return make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3])); }
+
+template <bool APPLY, bool TWO, bool POOL>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActArgs a) {
-    __shared__ float red[24][256];
-    const int ncg = a.C >> 3, cg = threadIdx.x % ncg, c0 = cg * 8;
+    __shared__ float red[APPLY ? 1 : (TWO ? 12 : 8)][256];
+    const int ncg = a.C >> 2, cg = threadIdx.x % ncg, c0 = cg * 4;
     const int ppb = 256 / ncg;
-    const int Fo = a.pool ? a.F >> 1 : a.F, Fh = a.pool ? (a.F + 1) >> 1 : a.F;     // Fh: row groups (a last single row when F is odd)
-    const bool two = a.zb != nullptr;
-    float mua[8], rsa[8], gaa[8], bea[8], mub[8], rsb[8], gab[8], beb[8], m1[8], m2a[8], m2b[8];
+    const int Fo = POOL ? a.F >> 1 : a.F, Fh = POOL ? (a.F + 1) >> 1 : a.F;         // Fh: row groups (a last single row when F is odd)
+    float mua[4], rsa[4], gaa[4], bea[4], mub[4], rsb[4], gab[4], beb[4], m1[4], m2a[4], m2b[4];
     const double cnt = (double)a.B * a.F * a.T;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
         mua[j] = a.mean_a[c0 + j]; rsa[j] = a.rstd_a[c0 + j]; gaa[j] = a.gamma_a[c0 + j]; bea[j] = a.beta_a[c0 + j];
-        mub[j] = two ? a.mean_b[c0 + j] : 0.0f; rsb[j] = two ? a.rstd_b[c0 + j] : 0.0f;
-        gab[j] = two ? a.gamma_b[c0 + j] : 0.0f; beb[j] = two ? a.beta_b[c0 + j] : 0.0f;
+        mub[j] = TWO ? a.mean_b[c0 + j] : 0.0f; rsb[j] = TWO ? a.rstd_b[c0 + j] : 0.0f;
+        gab[j] = TWO ? a.gamma_b[c0 + j] : 0.0f; beb[j] = TWO ? a.beta_b[c0 + j] : 0.0f;
         m1[j] = m2a[j] = m2b[j] = 0.0f;
         if (APPLY) {
             m1[j] = (float)(a.sums[c0 + j] / cnt);
             m2a[j] = (float)(a.sums[a.C + c0 + j] / cnt);
-            m2b[j] = (float)(a.sums[2 * a.C + c0 + j] / cnt);
+            if (TWO) m2b[j] = (float)(a.sums[2 * a.C + c0 + j] / cnt);
         }
     }
-    float s1[8], s2a[8], s2b[8];
+    float s1[4], s2a[4], s2b[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s1[j] = s2a[j] = s2b[j] = 0.0f;
+    for (int j = 0; j < 4; ++j) s1[j] = s2a[j] = s2b[j] = 0.0f;
+    float msk[4] = {1.0f, 1.0f, 1.0f, 1.0f};
     const long long n = (long long)a.B * Fh * a.T;
-    for (long long i = (long long)blockIdx.x * ppb + threadIdx.x / ncg; i < n; i += (long long)gridDim.x * ppb) {
-        const int t = (int)(i % a.T), fh = (int)((i / a.T) % Fh), b = (int)(i / ((long long)a.T * Fh));
-        const bool has_out = fh < Fo;                   // (pool with odd F: the last row has no pooled output)
-        const int nrow = (a.pool && has_out) ? 2 : 1;
-        float xa[2][8], xb[2][8], y[2][8];
-        for (int rr = 0; rr < nrow; ++rr) {
-            const int f = a.pool ? 2 * fh + rr : fh;
-            const size_t p = (((size_t)b * a.F + f) * a.T + t) * a.C + c0;
-            float za[8];
-            unpack8(*(const uint4*)(a.za + p), za);
+    const long long stride = (long long)gridDim.x * ppb;
+    for (long long i0 = (long long)blockIdx.x * ppb + threadIdx.x / ncg; i0 < n; i0 += 2 * stride) {
+        BnRaw<TWO> rw[2];
+        bool act[2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                xa[rr][j] = (za[j] - mua[j]) * rsa[j];
-                y[rr][j] = fmaf(gaa[j], xa[rr][j], bea[j]);
+        for (int u = 0; u < 2; ++u) {                    // ---- every load of both positions
+            const long long i = i0 + u * stride;
+            act[u] = i < n;
+            BnRaw<TWO>& r = rw[u];
+            r.t = r.fh = r.b = 0; r.has_out = false;
+            r.za[0] = r.za[1] = r.zb[0] = r.zb[1] = make_uint2(0, 0);
+            r.g = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (!act[u]) continue;
+            r.t = (int)(i % a.T); r.fh = (int)((i / a.T) % Fh); r.b = (int)(i / ((long long)a.T * Fh));
+            r.has_out = r.fh < Fo;                       // (pool with odd F: the last row has no pooled output)
+            const int nrow = (POOL && r.has_out) ? 2 : 1;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr >= nrow) break;
+                const int f = POOL ? 2 * r.fh + rr : r.fh;
+                const size_t p = (((size_t)r.b * a.F + f) * a.T + r.t) * a.C + c0;
+                r.za[rr] = *(const uint2*)(a.za + p);
+                if (TWO) r.zb[rr] = *(const uint2*)(a.zb + p);
             }
-            if (two) {
-                float zb[8];
-                unpack8(*(const uint4*)(a.zb + p), zb);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    xb[rr][j] = (zb[j] - mub[j]) * rsb[j];
-                    y[rr][j] += fmaf(gab[j], xb[rr][j], beb[j]);
+            if (r.has_out) {
+                if (a.dcl) {
+                    const uint2 gv = *(const uint2*)(a.dcl + (((size_t)r.b * Fo + r.fh) * a.T + r.t) * a.ldd_cl + c0);
+                    float gf[4];
+                    unpack4(gv, gf);
+                    r.g = f32x4{gf[0], gf[1], gf[2], gf[3]};
+                } else {
+                    r.g = *(const f32x4*)(a.dx + ((size_t)r.t * a.B + r.b) * a.ldd_x + (size_t)r.fh * a.C + c0);
                 }
             }
         }
-        // gradient of the output at this position (after dropout2d): routed to the pool winner (tie -> first row) if its
-        // ReLU is active
-        float g[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = 0.0f;
-        if (has_out) {
-            if (a.dcl) {
-                unpack8(*(const uint4*)(a.dcl + (((size_t)b * Fo + fh) * a.T + t) * a.ldd_cl + c0), g);
-            } else {
-                const float* gp = a.dx + ((size_t)t * a.B + b) * a.ldd_x + (size_t)fh * a.C + c0;
-                const f32x4 g0 = *(const f32x4*)gp, g1 = *(const f32x4*)(gp + 4);
+        for (int u = 0; u < 2; ++u) {                    // ---- the arithmetic of the first version, position by position
+            if (!act[u]) continue;
+            const BnRaw<TWO>& r = rw[u];
+            const int nrow = (POOL && r.has_out) ? 2 : 1;
+            float xa[2][4], xb[2][4], y[2][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { g[j] = g0[j]; g[4 + j] = g1[j]; }
-            }
-            if (a.mask2d) {
+            for (int rr = 0; rr < 2; ++rr) {
+                float za[4], zb[4];
+                unpack4(r.za[rr], za);
+                unpack4(r.zb[rr], zb);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) g[j] *= a.mask2d[(size_t)b * a.C + c0 + j];
-            }
-        }
-        float d[2][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            d[0][j] = d[1][j] = 0.0f;
-            if (has_out) {
-                if (nrow == 2) {
-                    const float y0 = a.relu ? fmaxf(y[0][j], 0.0f) : y[0][j], y1 = a.relu ? fmaxf(y[1][j], 0.0f) : y[1][j];
-                    if (y1 > y0) { if (!a.relu || y[1][j] > 0.0f) d[1][j] = g[j]; }
-                    else if (!a.relu || y[0][j] > 0.0f) d[0][j] = g[j];
-                } else if (!a.relu || y[0][j] > 0.0f) d[0][j] = g[j];
-            }
-        }
-        if (APPLY) {
-            for (int rr = 0; rr < nrow; ++rr) {
-                const int f = a.pool ? 2 * fh + rr : fh;
-                const size_t pos = ((size_t)b * a.F + f) * a.T + t;
-                float oa[8], ol[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) oa[j] = gaa[j] * rsa[j] * (d[rr][j] - m1[j] - xa[rr][j] * m2a[j]);
-                const uint4 hi = pack8(oa);
-                *(uint4*)(a.dza + pos * a.pa + c0) = hi;
-                if (a.dza_lo) {
-                    float hf[8];
-                    unpack8(hi, hf);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ol[j] = oa[j] - hf[j];
-                    *(uint4*)(a.dza_lo + pos * a.pa + c0) = pack8(ol);
-                }
-                if (two) {
-                    float ob[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ob[j] = gab[j] * rsb[j] * (d[rr][j] - m1[j] - xb[rr][j] * m2b[j]);
-                    const uint4 hb = pack8(ob);
-                    *(uint4*)(a.dzb + pos * a.pb + c0) = hb;
-                    if (a.dzb_lo) {
-                        float hf[8], olb[8];
-                        unpack8(hb, hf);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) olb[j] = ob[j] - hf[j];
-                        *(uint4*)(a.dzb_lo + pos * a.pb + c0) = pack8(olb);
+                for (int j = 0; j < 4; ++j) {
+                    xa[rr][j] = (za[j] - mua[j]) * rsa[j];
+                    y[rr][j] = fmaf(gaa[j], xa[rr][j], bea[j]);
+                    xb[rr][j] = 0.0f;
+                    if (TWO) {
+                        xb[rr][j] = (zb[j] - mub[j]) * rsb[j];
+                        y[rr][j] += fmaf(gab[j], xb[rr][j], beb[j]);
                     }
                 }
             }
-        } else {
-            for (int rr = 0; rr < nrow; ++rr) {
+            // gradient of the output at this position (after dropout2d): routed to the pool winner (tie -> first row) if its ReLU is active
+            float g[4] = {r.g[0], r.g[1], r.g[2], r.g[3]};
+            if (a.mask2d && r.has_out) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    s1[j] += d[rr][j];
-                    s2a[j] = fmaf(d[rr][j], xa[rr][j], s2a[j]);
-                    if (two) s2b[j] = fmaf(d[rr][j], xb[rr][j], s2b[j]);
+                for (int j = 0; j < 4; ++j) msk[j] = a.mask2d[(size_t)r.b * a.C + c0 + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] *= msk[j];
+            }
+            float d[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d[0][j] = d[1][j] = 0.0f;
+                if (r.has_out) {
+                    if (nrow == 2) {
+                        const float y0 = a.relu ? fmaxf(y[0][j], 0.0f) : y[0][j], y1 = a.relu ? fmaxf(y[1][j], 0.0f) : y[1][j];
+                        if (y1 > y0) { if (!a.relu || y[1][j] > 0.0f) d[1][j] = g[j]; }
+                        else if (!a.relu || y[0][j] > 0.0f) d[0][j] = g[j];
+                    } else if (!a.relu || y[0][j] > 0.0f) d[0][j] = g[j];
+                }
+            }
+            if (APPLY) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    if (rr >= nrow) break;
+                    const int f = POOL ? 2 * r.fh + rr : r.fh;
+                    const size_t pos = ((size_t)r.b * a.F + f) * a.T + r.t;
+                    float oa[4], ol[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) oa[j] = gaa[j] * rsa[j] * (d[rr][j] - m1[j] - xa[rr][j] * m2a[j]);
+                    const uint2 hi = pack4(oa);
+                    *(uint2*)(a.dza + pos * a.pa + c0) = hi;
+                    if (a.dza_lo) {
+                        float hf[4];
+                        unpack4(hi, hf);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ol[j] = oa[j] - hf[j];
+                        *(uint2*)(a.dza_lo + pos * a.pa + c0) = pack4(ol);
+                    }
+                    if (TWO) {
+                        float ob[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ob[j] = gab[j] * rsb[j] * (d[rr][j] - m1[j] - xb[rr][j] * m2b[j]);
+                        const uint2 hb = pack4(ob);
+                        *(uint2*)(a.dzb + pos * a.pb + c0) = hb;
+                        if (a.dzb_lo) {
+                            float hf[4], olb[4];
+                            unpack4(hb, hf);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) olb[j] = ob[j] - hf[j];
+                            *(uint2*)(a.dzb_lo + pos * a.pb + c0) = pack4(olb);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    if (rr >= nrow) break;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s1[j] += d[rr][j];
+                        s2a[j] = fmaf(d[rr][j], xa[rr][j], s2a[j]);
+                        if (TWO) s2b[j] = fmaf(d[rr][j], xb[rr][j], s2b[j]);
+                    }
                 }
             }
         }
     }
     if (!APPLY) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             red[j][threadIdx.x] = s1[j];
-            red[8 + j][threadIdx.x] = s2a[j];
-            red[16 + j][threadIdx.x] = s2b[j];
+            red[4 + j][threadIdx.x] = s2a[j];
+            if (TWO) red[8 + j][threadIdx.x] = s2b[j];
         }
         __syncthreads();
-        // thread (k, cg'): k = threadIdx.x / ncg in [0, 24) x channel group
-        for (int id = threadIdx.x; id < 24 * ncg; id += 256) {
+        // thread (k, channel group): k in [0, 8 or 12)
+        for (int id = threadIdx.x; id < (TWO ? 12 : 8) * ncg; id += 256) {
             const int k = id / ncg, g2 = id % ncg;
             float s = 0.0f;
             for (int r = 0; r < ppb; ++r) s += red[k][r * ncg + g2];
-            const int which = k >> 3, j = k & 7;
-            if (which < 2 || two) atomicAdd(a.sums + (size_t)which * a.C + g2 * 8 + j, (double)s);
+            const int which = k >> 2, j = k & 3;
+            atomicAdd(a.sums + (size_t)which * a.C + g2 * 4 + j, (double)s);
         }
     }
 }
@@ -558,13 +598,21 @@ extern "C" int mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_
     MT_CHECK_HIP(hipMemsetAsync(sums, 0, 3 * (size_t)C * sizeof(double), ST(stream)));
     const int Fh = pool ? (F + 1) / 2 : F;
     const long long n = (long long)B * Fh * T;
-    const int ppb = 256 / (C / 8);
-    long long g = (n + ppb - 1) / ppb;
-    if (g > 2048) g = 2048;                       // (pass 1 ends in 24 C/8 f64 atomics per workgroup)
-    hipLaunchKernelGGL(bn_act_bwd_kernel<false>, dim3((unsigned)g), dim3(256), 0, ST(stream), a);
-    MT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_act_bwd_kernel<true>, dim3((unsigned)g), dim3(256), 0, ST(stream), a);
-    MT_CHECK_LAUNCH();
+    const int ppb = 256 / (C / 4);                // positions per workgroup and pass (a thread = 4 channels), two passes per loop trip
+    long long g = (n + 2 * ppb - 1) / (2 * ppb);
+    if (g > 2048) g = 2048;                       // (pass 1 ends in 8 - 12 C/4 f64 atomics per workgroup)
+#define BN_BWD_LAUNCH(TWO_, POOL_)                                                                                  \
+    do {                                                                                                            \
+        hipLaunchKernelGGL((bn_act_bwd_kernel<false, TWO_, POOL_>), dim3((unsigned)g), dim3(256), 0, ST(stream), a); \
+        MT_CHECK_LAUNCH();                                                                                          \
+        hipLaunchKernelGGL((bn_act_bwd_kernel<true, TWO_, POOL_>), dim3((unsigned)g), dim3(256), 0, ST(stream), a);  \
+        MT_CHECK_LAUNCH();                                                                                          \
+    } while (0)
+    if (zb && pool) BN_BWD_LAUNCH(true, true);
+    else if (zb) BN_BWD_LAUNCH(true, false);
+    else if (pool) BN_BWD_LAUNCH(false, true);
+    else BN_BWD_LAUNCH(false, false);
+#undef BN_BWD_LAUNCH
     hipLaunchKernelGGL(bn_act_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST(stream), sums, dbeta_a, dgamma_a, dbeta_b, dgamma_b, C);
     MT_CHECK_LAUNCH();
     return MT_OK;
