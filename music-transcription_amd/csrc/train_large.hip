@@ -71,36 +71,61 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs a) {
         tb[j] = a.zb ? a.beta_b[c0 + j] - a.mean_b[c0 + j] * sb[j] : 0.0f;
     }
     const long long n = (long long)a.B * Fo * a.T;
-    for (long long i = (long long)blockIdx.x * ppb + threadIdx.x / ncg; i < n; i += (long long)gridDim.x * ppb) {
-        const int t = (int)(i % a.T), fo = (int)((i / a.T) % Fo), b = (int)(i / ((long long)a.T * Fo));
-        float y[8];
-        const int nrow = a.pool ? 2 : 1;
-        for (int rr = 0; rr < nrow; ++rr) {
-            const int f = a.pool ? 2 * fo + rr : fo;
-            const size_t p = (((size_t)b * a.F + f) * a.T + t) * a.C + c0;
-            float za[8], v[8];
-            unpack8(*(const uint4*)(a.za + p), za);
+    const long long stride = (long long)gridDim.x * ppb;
+    const int nrow = a.pool ? 2 : 1;
+    const bool two = a.zb != nullptr;
+    // two positions per loop pass, every load of both issued before the first is used (bytes in flight per lane: see bn_act_bwd_kernel)
+    for (long long i0 = (long long)blockIdx.x * ppb + threadIdx.x / ncg; i0 < n; i0 += 2 * stride) {
+        uint4 ra[2][2], rb[2][2];
+        int tt[2], ff[2], bb[2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaf(za[j], sa[j], ta[j]);
-            if (a.zb) {
-                float zb[8];
-                unpack8(*(const uint4*)(a.zb + p), zb);
+        for (int u = 0; u < 2; ++u) {
+            const long long i = i0 + u * stride;
+            tt[u] = ff[u] = bb[u] = 0;
+            ra[u][0] = ra[u][1] = rb[u][0] = rb[u][1] = make_uint4(0, 0, 0, 0);
+            if (i >= n) continue;
+            tt[u] = (int)(i % a.T); ff[u] = (int)((i / a.T) % Fo); bb[u] = (int)(i / ((long long)a.T * Fo));
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += fmaf(zb[j], sb[j], tb[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (a.relu) v[j] = fmaxf(v[j], 0.0f);
-                y[j] = rr == 0 ? v[j] : fmaxf(y[j], v[j]);
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr >= nrow) break;
+                const int f = a.pool ? 2 * ff[u] + rr : ff[u];
+                const size_t p = (((size_t)bb[u] * a.F + f) * a.T + tt[u]) * a.C + c0;
+                ra[u][rr] = *(const uint4*)(a.za + p);
+                if (two) rb[u][rr] = *(const uint4*)(a.zb + p);
             }
         }
-        if (a.mask2d) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] *= a.mask2d[(size_t)b * a.C + c0 + j];
+        for (int u = 0; u < 2; ++u) {
+            if (i0 + u * stride >= n) continue;
+            const int t = tt[u], fo = ff[u], b = bb[u];
+            float y[8];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (rr >= nrow) break;
+                float za[8], v[8];
+                unpack8(ra[u][rr], za);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(za[j], sa[j], ta[j]);
+                if (two) {
+                    float zb[8];
+                    unpack8(rb[u][rr], zb);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += fmaf(zb[j], sb[j], tb[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (a.relu) v[j] = fmaxf(v[j], 0.0f);
+                    y[j] = rr == 0 ? v[j] : fmaxf(y[j], v[j]);
+                }
+            }
+            if (a.mask2d) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] *= a.mask2d[(size_t)b * a.C + c0 + j];
+            }
+            bf16_t* o = a.out_mode == 0 ? a.out + (((size_t)b * Fo + fo) * a.T + t) * a.C + c0
+                                        : a.out + ((size_t)t * a.B + b) * a.ldx + (size_t)fo * a.C + c0;
+            *(uint4*)o = pack8(y);
         }
-        bf16_t* o = a.out_mode == 0 ? a.out + (((size_t)b * Fo + fo) * a.T + t) * a.C + c0
-                                    : a.out + ((size_t)t * a.B + b) * a.ldx + (size_t)fo * a.C + c0;
-        *(uint4*)o = pack8(y);
     }
 }
 
@@ -567,7 +592,7 @@ extern "C" int mt_bn_act_fwd(const void* za, const float* mean_a, const float* r
     MT_REQUIRE(out && (out_mode == 0 || (out_mode == 1 && ldx >= Fo * C && ldx % 8 == 0)), MT_EINVAL, "mt_bn_act_fwd: bad output arguments");
     const long long n = (long long)B * Fo * T;
     const int ppb = 256 / (C / 8);
-    long long g = (n + ppb - 1) / ppb;
+    long long g = (n + 2 * ppb - 1) / (2 * ppb);
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)g), dim3(256), 0, ST(stream), a);
     MT_CHECK_LAUNCH();

@@ -49,8 +49,10 @@ def _conv_dgrad_w(w, rows_pad=None):
     return wd
 
 
-def pack_train_large(model, dev) -> Dict[str, object]:
-    """bf16 operand layouts of the CURRENT parameters (redone every step: the optimizer moves them)."""
+def pack_train_large(model, dev, side=None) -> Dict[str, object]:
+    """bf16 operand layouts of the CURRENT parameters (redone every step: the optimizer moves them).  With `side` (a stream) everything
+    above the convolution stack -- 99 % of the bytes: LSTM, attention and head weights, the layer-0 column permutation -- is packed on
+    that stream beside the convolution stack's forward; t["_ready"] is the event to wait for before touching those entries."""
     from .model import _pack_bilstm
     H, L, Hl, F = model.hidden_size, model.num_layers, model.hidden_size // 2, model.n_mels
     Hp, Hlp, K1 = _ru(H, 16), _ru(Hl, 16), _ru(2 * H, 64)
@@ -86,6 +88,33 @@ def pack_train_large(model, dev) -> Dict[str, object]:
     t["fa_wdB"] = _conv_dgrad_w(wf[128:]).to(bf).contiguous()
     t["fa_g"], t["fa_be"] = g(model.freq_aware_conv[1].weight).contiguous(), g(model.freq_aware_conv[1].bias).contiguous()
     t["zeros256"] = torch.zeros(256, **f32)
+    t["dims"] = d
+    if side is None:
+        _pack_upper(model, dev, t, d)
+    else:
+        main_st = torch.cuda.current_stream(dev)
+        conv_keys = set(t.keys())
+        side.wait_stream(main_st)                       # the optimizer's update of the parameters is ordered on the calling stream
+        with torch.cuda.stream(side):
+            _pack_upper(model, dev, t, d)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for k_, v_ in t.items():                        # allocated under the side stream, used (and freed) under the calling one
+            if k_ in conv_keys:
+                continue
+            for t_ in (v_ if isinstance(v_, (list, tuple)) else [v_]):
+                if isinstance(t_, torch.Tensor):
+                    t_.record_stream(main_st)
+        t["_ready"] = ev
+    return t
+
+
+def _pack_upper(model, dev, t, d):
+    from .model import _pack_bilstm
+    H, L, Hl, Hp, Hlp, K0, K1, F3, comb, Cp = (d[k] for k in ("H", "L", "Hl", "Hp", "Hlp", "K0", "K1", "F3", "comb", "Cp"))
+    f32 = dict(device=dev, dtype=torch.float32)
+    bf = torch.bfloat16
+    g = lambda p: p.detach().to(**f32)
     # LSTMs (layer-0 columns re-ordered: reference feature c*F3+f -> kernel column f*256+c)
     cols = (torch.arange(256)[None, :] * F3 + torch.arange(F3)[:, None]).reshape(-1)
     t["m_wih"], t["m_b"], t["m_whh"] = _pack_bilstm(model.rnn_main, L, H, cols, dev)
@@ -135,8 +164,6 @@ def pack_train_large(model, dev) -> Dict[str, object]:
         t["fc_w"], t["fc_b"] = fw.to(bf), g(model.fc.bias).contiguous()
         fwT = torch.zeros(_ru(comb, 128), 128, **f32); fwT[:comb] = fw[:, :comb].t()
         t["fc_wT"] = fwT.to(bf)
-    t["dims"] = d
-    return t
 
 
 # ---------------------------------------------------------------------------------------------------------------- small wrappers
@@ -228,7 +255,7 @@ def _lstm_forward(X0, K0, w_ih, b_g, w_hh, L, Hp, Hv, K1, B, T, dropout, seed, l
 
 
 def _lstm_backward(sv, dh, w_hh, w_ihT, L, Hp, Hv, K0, K1, B, T, dropout, seed, layer_id0, dev, sync_slots, dG0, ldg0, col0, names, g, rnn_prefix,
-                   k0_gather, wg_stream=None):
+                   k0_gather, wg_stream=None, parts=None):
     """BPTT through the stack.  dh: gradient of the top layer's output in the backward recurrence's layout.  Layer 0's gate
     gradients go to dG0[:, col0 : col0 + 8 Hp] (row pitch ldg0): the caller turns them into the input gradient.  Parameter
     gradients land in g under rnn_prefix; k0_gather(gwi, di) produces layer 0's W_ih gradient in the reference layout."""
@@ -239,11 +266,12 @@ def _lstm_backward(sv, dh, w_hh, w_ihT, L, Hp, Hv, K0, K1, B, T, dropout, seed, 
     keep = []
     for l in range(L - 1, -1, -1):
         K = K0 if l == 0 else K1
-        part = torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
+        # parts: partial-product workspaces the caller has already poisoned (1 GB each at H = 512: done on a side stream, early)
+        part = parts[l] if parts is not None else torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
         dgx = torch.empty(lib.mt_lstm_dgx_bytes(B, T, Hp), device=dev, dtype=torch.uint8)
         sync = sync_slots.pop(0)
-        check(lib.mt_lstm_bidir_bwd(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(w_hh[l]), ptr(dgx), ptr(part), part.numel(),
-                                    ptr(sync), sync.numel(), B, T, Hp, _st()), "mt_lstm_bidir_bwd")
+        check(lib.mt_lstm_bidir_bwd_ex(ptr(sv["gates"][l]), ptr(sv["cxs"][l]), ptr(dh), ptr(w_hh[l]), ptr(dgx), ptr(part), part.numel(),
+                                       ptr(sync), sync.numel(), B, T, Hp, 1 if parts is not None else 0, _st()), "mt_lstm_bidir_bwd")
         if l == 0:
             dG, ldg = dG0[:, col0:], ldg0
             dGv = dG0.reshape(-1)[col0:]
@@ -301,7 +329,9 @@ def forward_train_large(model, x: torch.Tensor, p_drop: float, seed: int, p2d=DR
     """Returns (logits [NH][B][88][T] f32 (NH = 3 with the heads, else 1), saved state).  Updates BatchNorm running statistics."""
     dev = x.device
     B, _, F, T = x.shape
-    pk = pack_train_large(model, dev)
+    use_side = os.environ.get("MT_TRAIN_LARGE_STREAMS", "1") != "0"
+    with torch.cuda.device(dev):
+        pk = pack_train_large(model, dev, _side_streams(dev)[0] if use_side else None)
     d = pk["dims"]
     H, Hp, Hl, Hlp, L, F1, F2, F3, K0, K1, comb, Cp = (d[k] for k in ("H", "Hp", "Hl", "Hlp", "L", "F1", "F2", "F3", "K0", "K1", "comb", "Cp"))
     M, Mpad = T * B, _ru(T * B, 128)
@@ -376,8 +406,9 @@ def forward_train_large(model, x: torch.Tensor, p_drop: float, seed: int, p2d=DR
         # ---- LSTMs
         pm = p_drop if L > 1 else 0.0
         # the local layer (an independent recurrence on the same input) runs on a side stream beside the main stack
-        use_side = os.environ.get("MT_TRAIN_LARGE_STREAMS", "1") != "0"
         slots_local = [slots.pop()]
+        if "_ready" in pk:
+            torch.cuda.current_stream(dev).wait_event(pk["_ready"])     # the weights above the convolutions were packed on a side stream
         if use_side:
             main_st, side_b = torch.cuda.current_stream(dev), _side_streams(dev)[1]
             ev_x0 = torch.cuda.Event()
@@ -464,6 +495,25 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
     feat = sv["feat"]
     ph = 1.5 * p_drop
     with torch.cuda.device(dev):
+        use_side = os.environ.get("MT_TRAIN_LARGE_STREAMS", "1") != "0"
+        main_st = torch.cuda.current_stream(dev)
+        side_a, side_b = _side_streams(dev) if use_side else (None, None)
+        # the backward recurrences' partial-product workspaces are poisoned (0xFF, 1 GB per layer at H = 512) before they run: on side
+        # stream A now, beside the heads' and the attention's backward, instead of in front of every recurrence
+        parts_main = parts_local = ev_poison = None
+        if use_side:
+            parts_main = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8) for _ in range(L)]
+            parts_local = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hlp), device=dev, dtype=torch.uint8)]
+            ev0 = torch.cuda.Event()
+            ev0.record(main_st)
+            with torch.cuda.stream(side_a):
+                side_a.wait_event(ev0)
+                for p_, h_ in [(q_, Hp) for q_ in parts_main] + [(parts_local[0], Hlp)]:
+                    check(lib.mt_lstm_bwd_poison(ptr(p_), p_.numel(), B, T, h_, _st()), "mt_lstm_bwd_poison")
+                    p_.record_stream(side_a)
+                parts_local[0].record_stream(side_b)
+                ev_poison = torch.cuda.Event()
+                ev_poison.record(side_a)
         featT = torch.empty(_ru(Cp, 128) * Mpad, **bf)
         check(lib.mt_transpose_bf16(ptr(feat), Cp, M, Cp, ptr(featT), Mpad, Cp, _st()), "mt_transpose_bf16")
         dfeat = torch.empty(M, comb, **f32)
@@ -602,9 +652,8 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         # Stream plan: the main stack's recurrences on the calling stream, its weight-gradient GEMMs on side stream A beside the
         # next layer's recurrence, the local layer's whole chain (an independent recurrence writing its own columns of dG0)
         # on side stream B beside the main stack.  MT_TRAIN_LARGE_STREAMS=0: everything on the calling stream.
-        use_side = os.environ.get("MT_TRAIN_LARGE_STREAMS", "1") != "0"
-        main_st = torch.cuda.current_stream(dev)
-        side_a, side_b = _side_streams(dev) if use_side else (None, None)
+        if use_side:
+            main_st.wait_event(ev_poison)
         ev_in = torch.cuda.Event()
         ev_in.record(main_st)
         slots_local = [slots.pop()]                    # (the local layer's status slot: taken now, the streams pop independently)
@@ -614,9 +663,9 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             with torch.cuda.stream(side_b):
                 side_b.wait_event(ev_in)
                 keep_all += _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
-                                           slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp))
+                                           slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp), parts=parts_local)
         keep_all += _lstm_backward(sv["main"], dh_m, pk["m_whh"], pk["m_wihT"], L, Hp, H, K0, K1, B, T, pm, seed, 0, dev, slots, dG0, ldg, 0, None, g,
-                                   "rnn_main", k0_gather(H, Hp), wg_stream=side_a)
+                                   "rnn_main", k0_gather(H, Hp), wg_stream=side_a, parts=parts_main)
         if not use_side:
             keep_all += _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
                                        slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp))
