@@ -325,6 +325,10 @@ static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStrea
         return cg_launch<KC_, BN__, false, CG_OUT_CL, DT>(a, st);                                 \
     } while (0)
     if (bn256) CG_DISPATCH(32, 256);
+    // Two 64-channel workgroups per CU beat one 128-channel one where both fit (97 against 146 registers; input tile + ring <= 80 KB):
+    // the second workgroup's MFMAs run under the first one's synchronous input staging and epilogue.  res_block2's first convolution
+    // (64 -> 128): 0.99 -> 0.93 ms for the block, although each input tile is now staged twice.
+    if (kc64 && bn128 && cg_lds_bytes(a, 64, 64) <= 80 * 1024) CG_DISPATCH(64, 64);
     if (kc64 && bn128) CG_DISPATCH(64, 128);
     if (kc64) CG_DISPATCH(64, 64);
     if (bn128) CG_DISPATCH(32, 128);

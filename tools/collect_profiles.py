@@ -19,7 +19,7 @@ for k, n in names.items():
         latest = [f for f in stats if newest - os.path.getmtime(f) < 300]
         shutil.copy(max(latest, key=os.path.getsize), os.path.join(dst, f"{R}_{n}_kernel_stats.csv"))
 for f in ("pmc_traffic.json", "pmc_mfma_util.json", "pmc_traffic_b32.json", "pmc_mfma_util_b32.json", "pmc_traffic_large.json", "pmc_mfma_util_large.json",
-          "pmc_traffic_train.json", "pmc_mfma_util_train.json"):
+          "pmc_traffic_train.json", "pmc_mfma_util_train.json", "pmc_traffic_train_large.json", "pmc_mfma_util_train_large.json"):
     if os.path.exists(os.path.join(pmc, f)):
         shutil.copy(os.path.join(pmc, f), os.path.join(dst, f"{R}_{f}"))
 print("\n".join(sorted(os.listdir(dst))))

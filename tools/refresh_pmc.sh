@@ -30,8 +30,9 @@ if [ $PART = sections ] || [ $PART = all ]; then
 # the Large forward (BASELINE configs[2]) and the training step (configs[3]): the kernels the sections' rooflines name
 CMDL="bench.py --model cnn_rnn_large --batch 16 --steps 3 --warmup 1 --streams 1"
 CMDT="bench.py --mode train --batch 16 --steps 3 --warmup 1"
-for tag in L T; do
-  if [ $tag = L ]; then CMD="$CMDL"; else CMD="$CMDT"; fi
+CMDU="bench.py --mode train --model cnn_rnn_large --batch 16 --steps 3 --warmup 1"
+for tag in L T U; do
+  if [ $tag = L ]; then CMD="$CMDL"; elif [ $tag = T ]; then CMD="$CMDT"; else CMD="$CMDU"; fi
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch$tag -- python3 $R/$CMD > $O/fetch$tag.log 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write$tag -- python3 $R/$CMD > $O/write$tag.log 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/mfma$tag -- python3 $R/$CMD > $O/mfma$tag.log 2>&1
@@ -41,6 +42,8 @@ python3 tools/pmc_summary.py $O/fetchL $O/writeL $O/pmc_traffic_large.json "rocp
 python3 tools/pmc_mfma_summary.py $O/mfmaL $O/pmc_mfma_util_large.json "rocprofv3 --kernel-trace --pmc MfmaUtil -- python3 $CMDL" > $O/mfma_lt.txt
 python3 tools/pmc_summary.py $O/fetchT $O/writeT $O/pmc_traffic_train.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 $CMDT" 1 >> $O/traffic_lt.txt
 python3 tools/pmc_mfma_summary.py $O/mfmaT $O/pmc_mfma_util_train.json "rocprofv3 --kernel-trace --pmc MfmaUtil -- python3 $CMDT" >> $O/mfma_lt.txt
-rm -rf $O/fetchL $O/writeL $O/mfmaL $O/fetchT $O/writeT $O/mfmaT
+python3 tools/pmc_summary.py $O/fetchU $O/writeU $O/pmc_traffic_train_large.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 $CMDU" 1 >> $O/traffic_lt.txt
+python3 tools/pmc_mfma_summary.py $O/mfmaU $O/pmc_mfma_util_train_large.json "rocprofv3 --kernel-trace --pmc MfmaUtil -- python3 $CMDU" >> $O/mfma_lt.txt
+rm -rf $O/fetchL $O/writeL $O/mfmaL $O/fetchT $O/writeT $O/mfmaT $O/fetchU $O/writeU $O/mfmaU
 cat $O/mfma_lt.txt
 fi

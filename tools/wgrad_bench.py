@@ -18,7 +18,7 @@ B, T = args.batch, args.frames
 dev = torch.device("cuda", 0)
 shapes = [("rb1.conv1", 114, 32, 64, 3, 3), ("rb1.conv2", 114, 64, 64, 3, 3), ("rb1.skip", 114, 32, 64, 1, 1),
           ("rb2.conv1", 57, 64, 128, 3, 3), ("rb2.conv2", 57, 128, 128, 3, 3), ("rb2.skip", 57, 64, 128, 1, 1),
-          ("freq_aware", 28, 128, 256, 7, 3)]
+          ("freq_aware", 57, 128, 256, 7, 3)]          # (res_block2 does not pool: 57 rows)
 tot_new = tot_old = 0.0
 for name, F, Cin, Cout, KH, KW in shapes:
     x = torch.randn(B, F, T, Cin, device=dev).bfloat16()
