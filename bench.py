@@ -204,6 +204,9 @@ def bench_train(args):
         return loss
     for j in range(W):
         step(j)
+    # the side streams the step runs fastest with (every rank the same number of steps)
+    from music_transcription_amd.train_step_large import autotune_side_streams
+    autotune_side_streams(lambda: step(0), dev, candidates=4, steps=1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -520,6 +523,8 @@ def section_train(mta, dev, cores, do_cpu):
         return loss
     for _ in range(W):
         step()
+    from music_transcription_amd.train_step_large import autotune_side_streams
+    tuned = autotune_side_streams(step, dev, candidates=4, steps=2)     # (see section_train_large)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -549,7 +554,8 @@ def section_train(mta, dev, cores, do_cpu):
     sec = {"workload": "CNNRNNModel training step, batch=16 cached-format chunks, 1 GPU (BASELINE.json configs[3] per-GPU shape)",
            "value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_step": round(1e3 * el / K, 3), "steps": K,
            "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "model_tflops_per_s": round(3.0 * 72.76e9 * B * T / 938.0 * K / el / 1e12, 1),
-           "roofline": roof, "stages_timed": stages, "final_loss": round(float(loss.item()), 5)}
+           "roofline": roof, "stages_timed": stages, "final_loss": round(float(loss.item()), 5),
+           "side_stream_autotune_ms_per_step": [round(1e3 * t, 2) for t in tuned]}
     if do_cpu:
         from oracle import model_ref
         torch.set_num_threads(cores)
@@ -592,6 +598,10 @@ def section_train_large(mta, dev, cores, do_cpu):
         return loss
     for _ in range(W):
         step()
+    # the step's two side streams: the pair it runs fastest with (train_step_large.autotune_side_streams: which streams of torch's pool
+    # they are decides whether their work overlaps the calling stream's; by now this process has used a dozen streams)
+    from music_transcription_amd.train_step_large import autotune_side_streams
+    tuned = autotune_side_streams(step, dev, candidates=4, steps=1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -606,7 +616,8 @@ def section_train_large(mta, dev, cores, do_cpu):
            "roofline": {"kernel": "whole training step (3 x forward FLOPs)", "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "per_kernel": "profiles/r03_train_large_b16_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --mode train --model cnn_rnn_large`)"},
-           "final_loss": round(float(loss.item()), 5)}
+           "final_loss": round(float(loss.item()), 5),
+           "side_stream_autotune_ms_per_step": [round(1e3 * t, 2) for t in tuned]}
     if do_cpu:
         from oracle import model_ref
         torch.set_num_threads(cores)

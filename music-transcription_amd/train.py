@@ -47,8 +47,17 @@ def train_one_epoch(model, dataloader: Iterable, optimizer: FusedAdamClip, devic
     model.train()
     optimizer.max_norm = float(max_grad_norm)
     total, step_losses, nan_count, n_batches = 0.0, [], 0, 0
+    net0 = getattr(model, "model", model)
+    tuner = None
+    if type(net0).__name__ in ("CNNRNNModel", "CNNRNNModelLarge"):   # the step's side streams are chosen by measurement over the first dozen steps
+        from .train_step_large import SideStreamTuner
+        tuner = getattr(net0, "_side_stream_tuner", None)
+        if tuner is None:
+            tuner = net0._side_stream_tuner = SideStreamTuner(device)
     for batch in dataloader:
         n_batches += 1
+        if tuner is not None:
+            tuner.step_begin()
         optimizer.zero_grad()
         mel, roll, lengths = batch
         mel, roll = mel.to(device, non_blocking=True), roll.to(device, non_blocking=True)
@@ -69,6 +78,8 @@ def train_one_epoch(model, dataloader: Iterable, optimizer: FusedAdamClip, devic
             continue
         loss.backward()
         stats = optimizer.step().tolist()              # {grad norm before clipping, 1.0 if the step was taken}
+        if tuner is not None:
+            tuner.step_end()
         net = getattr(model, "model", model)
         if hasattr(net, "raise_on_train_handoff_timeout"):
             net.raise_on_train_handoff_timeout()       # (the .tolist() above synchronised with the whole step)

@@ -217,6 +217,79 @@ def _side_streams(dev):
     return _SIDE2[key]
 
 
+def autotune_side_streams(step, dev, candidates: int = 4, steps: int = 2):
+    """Picks, by measurement, the pair of side streams the training step runs fastest with, and keeps it for the process.
+    `step()` runs one full training step (they are real steps: nothing is thrown away).  Why: which streams of torch's pool the two
+    side streams happen to be decides whether their work overlaps the calling stream's at all -- 49.6 ms per step for most pairs,
+    51 - 52 for some, 55.7 (the single-stream time) for about one in eight, and no pairwise concurrency probe tells them apart
+    (tools/train_large_queue_probe.py, profiles/r03_train_large_stream_mapping.txt).  Returns the seconds per step of every candidate."""
+    import time
+    dev = torch.device(dev)
+    key = str(dev)
+    seen = []
+    for _ in range(max(1, candidates)):
+        _forget_side_streams(key)
+        step()                                          # (creates the step's side streams; first use of a stream sets its queue up)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(max(1, steps)):
+            step()
+        torch.cuda.synchronize(dev)
+        seen.append(((time.perf_counter() - t0) / max(1, steps), _current_side_streams(key)))
+    _restore_side_streams(key, min(seen, key=lambda e: e[0])[1])
+    return [t for t, _ in seen]
+
+
+def _forget_side_streams(key):                          # both training steps' side streams (CNNRNNModel has one, CNNRNNModelLarge two)
+    from . import train_step
+    _SIDE2.pop(key, None)
+    train_step._SIDE.pop(key, None)
+
+
+def _current_side_streams(key):
+    from . import train_step
+    return (_SIDE2.get(key), train_step._SIDE.get(key))
+
+
+def _restore_side_streams(key, saved):
+    from . import train_step
+    for d_, v_ in ((_SIDE2, saved[0]), (train_step._SIDE, saved[1])):
+        if v_ is not None:
+            d_[key] = v_
+
+
+class SideStreamTuner:
+    """The same choice made inside a training loop whose steps end in a host synchronisation (train.train_one_epoch): candidate pair c
+    serves steps [c (steps + 1), (c + 1)(steps + 1)), the first of them untimed; after the last candidate the fastest pair stays."""
+
+    def __init__(self, dev, candidates: int = 4, steps: int = 2):
+        self.dev, self.key = torch.device(dev), str(torch.device(dev))
+        self.candidates, self.steps = max(1, candidates), max(1, steps)
+        self.i, self.seen, self.acc, self.done = 0, [], 0.0, os.environ.get("MT_TRAIN_STREAM_AUTOTUNE", "1") == "0"
+
+    def step_begin(self):
+        if self.done:
+            return
+        import time
+        if self.i % (self.steps + 1) == 0:
+            _forget_side_streams(self.key)
+            self.acc = 0.0
+        self.t0 = time.perf_counter()
+
+    def step_end(self):                                 # call after the step's host synchronisation
+        if self.done:
+            return
+        import time
+        if self.i % (self.steps + 1) != 0:
+            self.acc += time.perf_counter() - self.t0
+        self.i += 1
+        if self.i % (self.steps + 1) == 0:
+            self.seen.append((self.acc / self.steps, _current_side_streams(self.key)))
+            if len(self.seen) == self.candidates:
+                _restore_side_streams(self.key, min(self.seen, key=lambda e: e[0])[1])
+                self.done = True
+
+
 def conv_wgrad_direct(dz_hi, dz_lo, dz_pitch, x, x_pitch, B, F, T, Cout, Cin, KH, KW, out):
     """out[Cout][Cin][KH][KW] (f32) = the convolution's weight gradient straight from the channels-last tensors (csrc/conv_wgrad.hip:
     no planes, both MFMA operands through transposed LDS reads, every kernel row of a K range on one XCD).  dz_hi + dz_lo = dz."""
