@@ -38,6 +38,27 @@ struct ConvGArgs {
 
 constexpr int CG_TF = 16, CG_TT = 16;
 
+// Diagnostic build only (-DMT_CONVG_DIAG, tools/convg_diag.py): per-phase wall clock of a tile, accumulated by thread 0 of every workgroup
+// (10-ns ticks): [0] input staging, [1] first weight chunk, [2] main loop, [3] epilogue, [4] tiles.  Never in the shipped build.
+// Round 3, B = 16, T = 938, f16 (us per tile; MFMA time of the main loop at the matrix peak in brackets):
+//   res_block1 conv1      staging 4.2   first weights 2.5   main loop  7.8 [0.97]   epilogue 5.1
+//   res_block1 conv2+skip         6.8                 1.8             11.3 [2.0]             3.2
+//   res_block2 conv1              5.5                 2.2              8.7 [3.9]             4.6
+//   res_block2 conv2+skip         9.7                 0.6             16.5 [8.2]             4.4
+//   freq_aware 7x3                7.6                 0.6             74.2 [36.1]            5.3
+// A chunk costs 0.6 - 0.9 us whatever its arithmetic.  Built on that reading and dropped: the weight stream requested four chunks ahead
+// (asm loads into four register sets, hand-counted vmcnt, a barrier without the fence's vmcnt(0)) -- main loops 6.4 / 9.7 / 7.5 / 16.4 /
+// 73.5 us, i.e. the L2 latency of the next chunk's weights is NOT what a chunk waits for; and the compiler copied registers whose data
+// was still in flight unless every request was made unconditional.  For the wide layers the chunk time equals LDS time PLUS MFMA time
+// (128 KB of fragment reads = 0.42 us at 128 B/clk, 0.43 us of MFMAs for two waves per SIMD): all eight waves read, then all multiply --
+// what the projection GEMM avoids with its ping-pong schedule (half of the waves one barrier ahead).  That is the next step here.
+#ifdef MT_CONVG_DIAG
+__device__ unsigned long long g_convg_diag[8];
+#define CD_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_convg_diag[k], (unsigned long long)(n_ - tl_)); tl_ = n_; } } while (0)
+#else
+#define CD_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ int cg_swz(int col, int nc_log2) {
     // positions per 256-B bank row = 16 / NC; swizzle = (col / PR) mod NC
     return (col >> (4 - nc_log2)) & ((1 << nc_log2) - 1);
@@ -67,6 +88,9 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     constexpr int WB = BN_ * KC * 2;
     const int Ktot = KH * 3 * C1 + C2;
 
+#ifdef MT_CONVG_DIAG
+    long long tl_ = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- stage the input tile(s), zero outside the image
     for (int id = tid; id < rows1 * 18 * nc1; id += 512) {
         const int ch = id % nc1, pos = id / nc1, col = pos % 18, row = pos / 18;
@@ -85,6 +109,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
         }
     }
 
+    CD_STAMP(0);
     // ---- weight chunk staging: chunk q covers K columns [q*KC, (q+1)*KC) of rows n0 .. n0+BN_
     constexpr int WCH = BN_ * KC / 8;                  // 16-B pieces per chunk
     constexpr int WPT = (WCH + 511) / 512;             // per thread (1 or 2; half the threads idle when WCH = 256)
@@ -169,6 +194,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     CG_WLOAD(0);
     CG_WSTORE(0);
     __syncthreads();
+    CD_STAMP(1);
     const int cpt = C1 / KC;                            // chunks per main tap
     int q = 0;
     for (int kh = 0; kh < KH; ++kh)
@@ -182,6 +208,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #undef CG_READ
 #undef CG_MFMA
 
+    CD_STAMP(2);
     // ---- epilogue: + bias, (pool), (ReLU), 16-bit store
     const int Fo = POOL ? a.F / 2 : a.F;
     // Straight from the accumulators a lane stores single 16-bit values (lanes = channels: 64 contiguous bytes per position and
@@ -266,6 +293,10 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
             }
         }
     }
+    CD_STAMP(3);
+#ifdef MT_CONVG_DIAG
+    if (threadIdx.x == 0) atomicAdd(&g_convg_diag[4], 1ull);
+#endif
 #undef CG_WLOAD
 #undef CG_WSTORE
 #undef CG_WSWZ
@@ -375,3 +406,14 @@ extern "C" int mt_conv_cl_bf16(const void* A, const void* S, const void* W, cons
                                mt_stream_t stream) {
     return mt_conv_cl_dt(A, S, W, bias, out, B, F, T, C1, C2, Cout, KH, relu, pool, out_mode, ldx, MT_DT_BF16, stream);
 }
+
+#ifdef MT_CONVG_DIAG
+extern "C" int mt_convg_diag_read(unsigned long long* host_out /*[8]*/, int reset) {
+    MT_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_convg_diag), sizeof(unsigned long long) * 8));
+    if (reset) {
+        unsigned long long z[8] = {};
+        MT_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_convg_diag), z, sizeof(z)));
+    }
+    return MT_OK;
+}
+#endif
