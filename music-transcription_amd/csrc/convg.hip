@@ -79,9 +79,9 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     const int pr1 = 16 >> nc1_l2;                      // positions per bank row
     const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
     const int rows1 = CG_TF + KH - 1;
-    const int in1_bytes = rows1 * pitch1 * C1 * 2;
+    const int in1_bytes = (rows1 * pitch1 * C1 * 2 + 1023) & ~1023;        // whole 1-KB LDS-DMA instructions
     const int nc2 = C2 >> 3, nc2_l2 = C2 ? 31 - __builtin_clz(nc2) : 0;
-    const int in2_bytes = C2 ? CG_TF * CG_TT * C2 * 2 : 0;
+    const int in2_bytes = C2 ? (CG_TF * CG_TT * C2 * 2 + 1023) & ~1023 : 0;
     char* in1 = smem;
     char* in2 = smem + in1_bytes;
     char* wbuf = smem + in1_bytes + in2_bytes;         // 2 x [BN_][KC] bf16
@@ -91,21 +91,35 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #ifdef MT_CONVG_DIAG
     long long tl_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    // ---- stage the input tile(s), zero outside the image
-    for (int id = tid; id < rows1 * 18 * nc1; id += 512) {
-        const int ch = id % nc1, pos = id / nc1, col = pos % 18, row = pos / 18;
-        const int f = f0 - ph + row, t = t0 - 1 + col;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (f >= 0 && f < a.F && t >= 0 && t < a.T) v = *(const uint4*)(a.A + (((size_t)b * a.F + f) * a.T + t) * a.pitchA + ch * 8);
-        *(uint4*)(in1 + ((row * pitch1 + col) * nc1 + (ch ^ cg_swz(col, nc1_l2))) * 16) = v;
-    }
-    if (C2) {
-        for (int id = tid; id < CG_TF * CG_TT * nc2; id += 512) {
-            const int ch = id % nc2, pos = id / nc2, col = pos % CG_TT, row = pos / CG_TT;
-            const int f = f0 + row, t = t0 + col;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (f < a.F && t < a.T) v = *(const uint4*)(a.S + (((size_t)b * a.F + f) * a.T + t) * a.pitchS + ch * 8);
-            *(uint4*)(in2 + ((row * CG_TT + col) * nc2 + (ch ^ cg_swz(col, nc2_l2))) * 16) = v;
+    // ---- stage the input tile(s): LDS-DMA through a buffer descriptor over the chunk (positions outside the image are out-of-range
+    //      offsets: hardware zeros; the chunk swizzle is applied on the source side: a lane fetches the channel chunk that belongs where the
+    //      DMA will put its 16 bytes).  Every request of the tile is in flight at once -- the first version moved the tile through registers,
+    //      one 16-byte piece per thread and round trip: 4 - 10 us per tile (tools/convg_diag.py) -- and the first weight chunk travels
+    //      beside them.
+    {
+        typedef __attribute__((address_space(3))) void lvoid_t;
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (size_t)b * a.F * a.T * a.pitchA), 0,
+                                                                             a.F * a.T * a.pitchA * 2, 0x00020000);
+        const int wvu = __builtin_amdgcn_readfirstlane(wv);
+        const int n1 = rows1 * pitch1 * nc1;
+        for (int qd = wvu; qd * 64 < n1; qd += 8) {
+            const int L = qd * 64 + lane, pos = L >> nc1_l2, chs = L & (nc1 - 1), row = pos / pitch1, col = pos - row * pitch1;
+            const int f = f0 - ph + row, t = t0 - 1 + col;
+            const bool ok = row < rows1 && col < 18 && f >= 0 && f < a.F && t >= 0 && t < a.T;
+            const int off = ok ? ((f * a.T + t) * a.pitchA + ((chs ^ cg_swz(col, nc1_l2)) << 3)) * 2 : 0x7fffffff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lvoid_t*)(in1 + qd * 1024), 16, off, 0, 0, 0);
+        }
+        if (C2) {
+            const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.S + (size_t)b * a.F * a.T * a.pitchS), 0,
+                                                                                 a.F * a.T * a.pitchS * 2, 0x00020000);
+            const int n2 = CG_TF * CG_TT * nc2;
+            for (int qd = wvu; qd * 64 < n2; qd += 8) {
+                const int L = qd * 64 + lane, pos = L >> nc2_l2, chs = L & (nc2 - 1), row = pos >> 4, col = pos & 15;
+                const int f = f0 + row, t = t0 + col;
+                const bool ok = row < CG_TF && f < a.F && t < a.T;
+                const int off = ok ? ((f * a.T + t) * a.pitchS + ((chs ^ cg_swz(col, nc2_l2)) << 3)) * 2 : 0x7fffffff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lvoid_t*)(in2 + qd * 1024), 16, off, 0, 0, 0);
+            }
         }
     }
 
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     } while (0)
 
     CG_WLOAD(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of the input tile(s) have landed (and the first weight chunk)
     CG_WSTORE(0);
     __syncthreads();
     CD_STAMP(1);
@@ -306,7 +321,7 @@ template <int KC, int BN_, bool POOL, int OUT, int DT>
 static int cg_launch(const ConvGArgs& a, hipStream_t st) {
     const int nc1 = a.C1 / 8, pr1 = 16 / nc1 > 0 ? 16 / nc1 : 1;
     const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
-    size_t lds = (size_t)(CG_TF + a.KH - 1) * pitch1 * a.C1 * 2 + (a.C2 ? (size_t)CG_TF * CG_TT * a.C2 * 2 : 0) + 2 * BN_ * KC * 2;
+    size_t lds = align_up((size_t)(CG_TF + a.KH - 1) * pitch1 * a.C1 * 2, 1024) + (a.C2 ? align_up((size_t)CG_TF * CG_TT * a.C2 * 2, 1024) : 0) + 2 * BN_ * KC * 2;
     const size_t stage = (size_t)(POOL ? CG_TF / 2 : CG_TF) * CG_TT * BN_ * 2;       // the epilogue's output rows reuse the buffers
     if (lds < stage) lds = stage;
     MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "conv: tile needs %zu B of LDS", lds);
@@ -330,7 +345,7 @@ using namespace mt;
 static size_t cg_lds_bytes(const ConvGArgs& a, int KC, int BN_) {
     const int nc1 = a.C1 / 8, pr1 = 16 / nc1 > 0 ? 16 / nc1 : 1;
     const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
-    return (size_t)(CG_TF + a.KH - 1) * pitch1 * a.C1 * 2 + (a.C2 ? (size_t)CG_TF * CG_TT * a.C2 * 2 : 0) + 2 * (size_t)BN_ * KC * 2;
+    return align_up((size_t)(CG_TF + a.KH - 1) * pitch1 * a.C1 * 2, 1024) + (a.C2 ? align_up((size_t)CG_TF * CG_TT * a.C2 * 2, 1024) : 0) + 2 * (size_t)BN_ * KC * 2;
 }
 
 template <int DT>
@@ -376,6 +391,8 @@ extern "C" int mt_conv_cl_ex(const void* A, int pitchA, const void* S, int pitch
     MT_REQUIRE(A && W && bias && out, MT_EINVAL, "mt_conv_cl: null pointer");
     MT_REQUIRE(pitchA >= C1 && pitchA % 8 == 0 && (C2 == 0 || (pitchS >= C2 && pitchS % 8 == 0)), MT_EINVAL, "mt_conv_cl: bad position pitch");
     MT_REQUIRE_DT(dt, "mt_conv_cl");
+    MT_REQUIRE((long long)F * T * pitchA * 2 < (1ll << 31) && (long long)F * T * (C2 ? pitchS : 0) * 2 < (1ll << 31), MT_EUNSUPPORTED,
+               "mt_conv_cl: a chunk's activation must stay below 2 GB (one buffer descriptor per chunk)");
     MT_REQUIRE(B > 0 && F > 0 && T > 0 && (KH == 3 || KH == 7) && (C1 == 32 || C1 == 64 || C1 == 128) &&
                (C2 == 0 || C2 == 32 || C2 == 64 || C2 == 128) && (C2 == 0 || S) && (Cout % 64 == 0), MT_EUNSUPPORTED,
                "mt_conv_cl: unsupported shape C1=%d C2=%d Cout=%d KH=%d", C1, C2, Cout, KH);
