@@ -64,6 +64,17 @@ __device__ __forceinline__ int cg_swz(int col, int nc_log2) {
     return (col >> (4 - nc_log2)) & ((1 << nc_log2) - 1);
 }
 
+// Epilogue staging: a lane holds ONE channel of a position, lanes 2k and 2k + 1 adjacent channels.  Two 16-bit values per lane (xa for
+// row A of the staging buffer, xb for row B) leave as one 32-bit LDS write: the even lane writes row A's channel pair (its xa and its
+// neighbour's, fetched with one DPP quad permute), the odd lane row B's -- half the ds_write instructions of one 16-bit write per value.
+__device__ __forceinline__ void cg_stage_pair(bf16_t* stg, int idxA, int idxB, int col, unsigned xa, unsigned xb, int lane) {
+    const bool odd = lane & 1;
+    const unsigned give = odd ? xa : xb;
+    const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1 /* quad_perm [1, 0, 3, 2] */, 0xF, 0xF, true);
+    const unsigned word = odd ? (got | (xb << 16)) : (xa | (got << 16));
+    *(unsigned*)(stg + (odd ? idxB : idxA) + (col & ~1)) = word;
+}
+
 template <int KC, int BN_, bool POOL, int OUT, int DT>
 __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -259,15 +270,18 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
                     }
                     const float v0 = acc[i][j][4 * qq + p] + bv, v1 = acc[i][j][4 * (qq + 2) + p] + bv;
                     if (staged) {
-                        if (POOL) {
-                            float v = fmaxf(v0, v1);
-                            if (a.relu) v = fmaxf(v, 0.0f);
-                            stg[((2 * wm + i) * CG_TT + tl) * BN_ + col] = f32_to_h16<DT>(v);
-                        } else {
+                        if (POOL) {                        // frames p and p + 1 of the pooled row: one 32-bit write per lane for the two
+                            if (p & 1) continue;
+                            float va = fmaxf(v0, v1);
+                            float vb = fmaxf(acc[i][j][4 * qq + p + 1], acc[i][j][4 * (qq + 2) + p + 1]) + bv;
+                            if (a.relu) { va = fmaxf(va, 0.0f); vb = fmaxf(vb, 0.0f); }
+                            const int ia = ((2 * wm + i) * CG_TT + tl) * BN_;
+                            cg_stage_pair(stg, ia, ia + BN_, col, f32_to_h16<DT>(va), f32_to_h16<DT>(vb), lane);
+                        } else {                           // the two frequency rows of the position
                             float u0 = v0, u1 = v1;
                             if (a.relu) { u0 = fmaxf(u0, 0.0f); u1 = fmaxf(u1, 0.0f); }
-                            stg[((4 * wm + 2 * i) * CG_TT + tl) * BN_ + col] = f32_to_h16<DT>(u0);
-                            stg[((4 * wm + 2 * i + 1) * CG_TT + tl) * BN_ + col] = f32_to_h16<DT>(u1);
+                            const int ia = ((4 * wm + 2 * i) * CG_TT + tl) * BN_;
+                            cg_stage_pair(stg, ia, ia + CG_TT * BN_, col, f32_to_h16<DT>(u0), f32_to_h16<DT>(u1), lane);
                         }
                         continue;
                     }
