@@ -51,7 +51,10 @@ constexpr int CG_TF = 16, CG_TT = 16;
 // 73.5 us, i.e. the L2 latency of the next chunk's weights is NOT what a chunk waits for; and the compiler copied registers whose data
 // was still in flight unless every request was made unconditional.  For the wide layers the chunk time equals LDS time PLUS MFMA time
 // (128 KB of fragment reads = 0.42 us at 128 B/clk, 0.43 us of MFMAs for two waves per SIMD): all eight waves read, then all multiply --
-// what the projection GEMM avoids with its ping-pong schedule (half of the waves one barrier ahead).  That is the next step here.
+// what the projection GEMM avoids with its ping-pong schedule (half of the waves one barrier ahead).  Built here as well (the waves of the
+// lower and the upper M half paced one barrier apart, 2 KS + 1 pacing barriers per chunk, for the 128- and 256-channel tiles): correct,
+// and no faster (7 x 3: 1.70 - 1.75 ms with and without, res_block2 0.79) -- so the chunk is not "reads then multiplies" either.  Kept
+// from this series: the input tile by LDS-DMA (res blocks 0.56 / 0.93 -> 0.50 / 0.79 ms).
 #ifdef MT_CONVG_DIAG
 __device__ unsigned long long g_convg_diag[8];
 #define CD_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_convg_diag[k], (unsigned long long)(n_ - tl_)); tl_ = n_; } } while (0)
