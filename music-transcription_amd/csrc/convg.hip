@@ -17,6 +17,7 @@
 //     16 lanes of a ds_read_b128 group -- 16 distinct frames -- never collide, whatever the tap;
 //   weights are streamed per (tap, KC channels) through a double-buffered LDS ring, one barrier per chunk.
 #include "mt_common.h"
+#include <stdlib.h>
 
 namespace mt {
 
@@ -55,6 +56,14 @@ constexpr int CG_TF = 16, CG_TT = 16;
 // lower and the upper M half paced one barrier apart, 2 KS + 1 pacing barriers per chunk, for the 128- and 256-channel tiles): correct,
 // and no faster (7 x 3: 1.70 - 1.75 ms with and without, res_block2 0.79) -- so the chunk is not "reads then multiplies" either.  Kept
 // from this series: the input tile by LDS-DMA (res blocks 0.56 / 0.93 -> 0.50 / 0.79 ms).
+// (timing experiments of the diagnostic build, WRONG results: -DCG_EXP_NOW=1 no weight streaming after the first chunk, -DCG_EXP_NOBAR=1 no
+//  barrier at the chunk boundary)
+#ifndef CG_EXP_NOW
+#define CG_EXP_NOW 0
+#endif
+#ifndef CG_EXP_NOBAR
+#define CG_EXP_NOBAR 0
+#endif
 #ifdef MT_CONVG_DIAG
 __device__ unsigned long long g_convg_diag[8];
 #define CD_STAMP(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_convg_diag[k], (unsigned long long)(n_ - tl_)); tl_ = n_; } } while (0)
@@ -78,13 +87,19 @@ __device__ __forceinline__ void cg_stage_pair(bf16_t* stg, int idxA, int idxB, i
     *(unsigned*)(stg + (odd ? idxB : idxA) + (col & ~1)) = word;
 }
 
-template <int KC, int BN_, bool POOL, int OUT, int DT>
-__global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
+// NW = waves per workgroup: 8 (4 along M x 2 along N), or 16 (4 x 4) for the tiles whose input tile leaves room for ONE workgroup per CU only:
+// with two waves per SIMD the fragment-read + MFMA loop itself runs at 60 % of the matrix rate (tools/convg_diag.py with the weight stream and the
+// barriers compiled out: 61 us against 36 for the 7 x 3 convolution, 13.3 against 8.2 for res_block2's second one), with four (two 8-wave
+// workgroups per CU: res_block2's first convolution) at 90 %.  Sixteen waves share one input tile and one weight stream; a wave's tile narrows
+// to 64 positions x BN_/4 channels and its fragments are single-buffered (128 registers per lane at 1024 threads).
+template <int KC, int BN_, bool POOL, int OUT, int DT, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void convg_kernel(ConvGArgs a) {
+    constexpr int NTHR = NW * 64, WNW = NW / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int r = lane & 31, h = lane >> 5, t_l = r & 15, fbit = r >> 4;
-    const int wm = wv >> 1, wn = wv & 1;
-    constexpr int NT = BN_ / 64;                       // N tiles (32 wide) per wave
+    const int wm = wv / WNW, wn = wv % WNW;
+    constexpr int NT = BN_ / (32 * WNW);               // N tiles (32 wide) per wave
     const int tiles_t = (a.T + CG_TT - 1) / CG_TT;
     const int t0 = (blockIdx.x % tiles_t) * CG_TT, n0 = (blockIdx.x / tiles_t) * BN_;
     const int f0 = blockIdx.y * CG_TF, b = blockIdx.z;
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
                                                                              a.F * a.T * a.pitchA * 2, 0x00020000);
         const int wvu = __builtin_amdgcn_readfirstlane(wv);
         const int n1 = rows1 * pitch1 * nc1;
-        for (int qd = wvu; qd * 64 < n1; qd += 8) {
+        for (int qd = wvu; qd * 64 < n1; qd += NW) {
             const int L = qd * 64 + lane, pos = L >> nc1_l2, chs = L & (nc1 - 1), row = pos / pitch1, col = pos - row * pitch1;
             const int f = f0 - ph + row, t = t0 - 1 + col;
             const bool ok = row < rows1 && col < 18 && f >= 0 && f < a.F && t >= 0 && t < a.T;
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
             const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.S + (size_t)b * a.F * a.T * a.pitchS), 0,
                                                                                  a.F * a.T * a.pitchS * 2, 0x00020000);
             const int n2 = CG_TF * CG_TT * nc2;
-            for (int qd = wvu; qd * 64 < n2; qd += 8) {
+            for (int qd = wvu; qd * 64 < n2; qd += NW) {
                 const int L = qd * 64 + lane, pos = L >> nc2_l2, chs = L & (nc2 - 1), row = pos >> 4, col = pos & 15;
                 const int f = f0 + row, t = t0 + col;
                 const bool ok = row < CG_TF && f < a.F && t < a.T;
@@ -140,15 +155,15 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     CD_STAMP(0);
     // ---- weight chunk staging: chunk q covers K columns [q*KC, (q+1)*KC) of rows n0 .. n0+BN_
     constexpr int WCH = BN_ * KC / 8;                  // 16-B pieces per chunk
-    constexpr int WPT = (WCH + 511) / 512;             // per thread (1 or 2; half the threads idle when WCH = 256)
+    constexpr int WPT = (WCH + NTHR - 1) / NTHR;       // per thread (1 or 2; some threads idle when WCH < NTHR)
     constexpr int CPR = KC / 8;                        // pieces per weight row (4 or 8)
-    constexpr bool WFULL = (WCH % 512 == 0);
+    constexpr bool WFULL = (WCH % NTHR == 0);
     constexpr int KS = KC / 16;
     const int nchunks = Ktot / KC;
     uint4 wreg0 = make_uint4(0, 0, 0, 0), wreg1 = wreg0;
     // weight rows are KC*2 bytes (64 or 128): swizzle the piece index so that 16 rows distinct mod 16 do not collide
 #define CG_WSWZ(row) (KC == 64 ? (((row) >> 1) & 7) : (((row) >> 2) & 3))
-    const int wl_row0 = tid / CPR, wl_pc0 = tid % CPR, wl_row1 = (tid + 512) / CPR, wl_pc1 = (tid + 512) % CPR;
+    const int wl_row0 = tid / CPR, wl_pc0 = tid % CPR, wl_row1 = (tid + NTHR) / CPR, wl_pc1 = (tid + NTHR) % CPR;
     const bf16_t* wl_g0 = a.W + (size_t)(n0 + wl_row0) * Ktot + wl_pc0 * 8;
     const bf16_t* wl_g1 = a.W + (size_t)(n0 + wl_row1) * Ktot + wl_pc1 * 8;
     const int wl_l0 = wl_row0 * (KC * 2) + ((wl_pc0 ^ CG_WSWZ(wl_row0)) << 4);
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     int wf_off[NT], wf_sw[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int row = wn * (BN_ / 2) + j * 32 + r;
+        const int row = wn * (BN_ / WNW) + j * 32 + r;
         wf_off[j] = row * (KC * 2);
         wf_sw[j] = CG_WSWZ(row);
     }
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 
     // One chunk: the fragments of k-step ks+1 are fetched before the MFMAs of k-step ks are issued (two register sets),
     // the next chunk's weights travel global -> registers under the whole chunk and go to the other LDS buffer after it.
-    bf16x8 fb[2][NT], fa[2][2];
+    bf16x8 fb[NW == 16 ? 1 : 2][NT], fa[NW == 16 ? 1 : 2][2];
 #define CG_READ(S, ks, inp, abase, tapoff, cb, sw)                                                                \
     _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                                             \
         fb[S][j_] = *(const bf16x8*)(wb_ + wf_off[j_] + ((((ks) * 2 + h) ^ wf_sw[j_]) << 4));                     \
@@ -205,18 +220,25 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #define CG_CHUNK(inp, abase, tapoff, cb, sw)                                                                      \
     do {                                                                                                          \
         const char* wb_ = wbuf + (q & 1) * WB;                                                                    \
-        if (q + 1 < nchunks) CG_WLOAD(q + 1);                                                                     \
-        CG_READ(0, 0, inp, abase, tapoff, cb, sw)                                                                 \
-        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                       \
-            if (ks + 1 < KS) {                                                                                    \
-                if (ks & 1) { CG_READ(0, ks + 1, inp, abase, tapoff, cb, sw) } else { CG_READ(1, ks + 1, inp, abase, tapoff, cb, sw) } \
+        if (!CG_EXP_NOW && q + 1 < nchunks) CG_WLOAD(q + 1);                                                      \
+        if (NW == 16) {                                 /* four waves per SIMD cover the LDS latency: one fragment set */ \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                   \
+                CG_READ(0, ks, inp, abase, tapoff, cb, sw)                                                        \
+                CG_MFMA(0)                                                                                        \
             }                                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            if (ks & 1) { CG_MFMA(1) } else { CG_MFMA(0) }                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        } else {                                                                                                  \
+            CG_READ(0, 0, inp, abase, tapoff, cb, sw)                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                   \
+                if (ks + 1 < KS) {                                                                                \
+                    if (ks & 1) { CG_READ(0, ks + 1, inp, abase, tapoff, cb, sw) } else { CG_READ(1, ks + 1, inp, abase, tapoff, cb, sw) } \
+                }                                                                                                 \
+                __builtin_amdgcn_sched_barrier(0);                                                                \
+                if (ks & 1) { CG_MFMA(1) } else { CG_MFMA(0) }                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                                \
+            }                                                                                                     \
         }                                                                                                         \
-        if (q + 1 < nchunks) CG_WSTORE((q & 1) ^ 1);                                                              \
-        __syncthreads();                                                                                          \
+        if (!CG_EXP_NOW && q + 1 < nchunks) CG_WSTORE((q & 1) ^ 1);                                               \
+        if (!CG_EXP_NOBAR) __syncthreads();                                                                       \
     } while (0)
 
     CG_WLOAD(0);
@@ -252,7 +274,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
     bf16_t* stg = (bf16_t*)smem;                                        // [NP][BN_]
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int col = wn * (BN_ / 2) + j * 32 + r, co = n0 + col;
+        const int col = wn * (BN_ / WNW) + j * 32 + r, co = n0 + col;
         const float bv = a.bias[co];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
                         const unsigned long long gt = __ballot(z0 > z1), lt = __ballot(z0 < z1);
                         const int f = f0 + 4 * wm + 2 * i;
                         if (r == 0 && t < a.T && f + 1 < a.F) {
-                            const size_t w_ = ((((size_t)b * (a.F >> 1) + (f >> 1)) * a.T + t) * (a.Cout >> 5) + ((n0 + wn * (BN_ / 2) + j * 32) >> 5)) * 2;
+                            const size_t w_ = ((((size_t)b * (a.F >> 1) + (f >> 1)) * a.T + t) * (a.Cout >> 5) + ((n0 + wn * (BN_ / WNW) + j * 32) >> 5)) * 2;
                             a.tie[w_] = (unsigned)(h ? gt >> 32 : gt);
                             a.tie[w_ + 1] = (unsigned)(h ? lt >> 32 : lt);
                         }
@@ -316,7 +338,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
         constexpr int UPP = BN_ / 8;                                    // 16-byte units per position
         const int fbase = POOL ? (f0 >> 1) : f0;
 #pragma unroll 2
-        for (int u = tid; u < NP * UPP; u += 512) {
+        for (int u = tid; u < NP * UPP; u += NTHR) {
             const int pos = u / UPP, c = u - pos * UPP, f = fbase + (pos >> 4), t = t0 + (pos & 15);
             if (f < Fo && t < a.T) {
                 bf16_t* o = OUT == CG_OUT_CL ? a.out + (((size_t)b * Fo + f) * a.T + t) * a.Cout + n0 + c * 8
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(512) void convg_kernel(ConvGArgs a) {
 #undef CG_WSWZ
 }
 
-template <int KC, int BN_, bool POOL, int OUT, int DT>
+template <int KC, int BN_, bool POOL, int OUT, int DT, int NW = 8>
 static int cg_launch(const ConvGArgs& a, hipStream_t st) {
     const int nc1 = a.C1 / 8, pr1 = 16 / nc1 > 0 ? 16 / nc1 : 1;
     const int pitch1 = (18 + pr1 - 1) / pr1 * pr1;
@@ -344,12 +366,12 @@ static int cg_launch(const ConvGArgs& a, hipStream_t st) {
     MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "conv: tile needs %zu B of LDS", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)convg_kernel<KC, BN_, POOL, OUT, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MT_CHECK_HIP(hipFuncSetAttribute((const void*)convg_kernel<KC, BN_, POOL, OUT, DT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     const int tiles_t = cdiv(a.T, CG_TT);
     dim3 grid(tiles_t * (a.Cout / BN_), cdiv(a.F, CG_TF), a.B);
-    hipLaunchKernelGGL((convg_kernel<KC, BN_, POOL, OUT, DT>), grid, dim3(512), lds, st, a);
+    hipLaunchKernelGGL((convg_kernel<KC, BN_, POOL, OUT, DT, NW>), grid, dim3(NW * 64), lds, st, a);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
@@ -380,22 +402,24 @@ static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStrea
     //  traffic.  res_block2's first convolution: unchanged.)
     const bool bn128 = (a.Cout % 128 == 0) && cg_lds_bytes(a, 32, 128) <= 160 * 1024;
     const bool kc64 = (a.C1 % 64 == 0) && (a.C2 % 64 == 0) && cg_lds_bytes(a, 64, bn128 ? 128 : 64) <= 160 * 1024;
-#define CG_DISPATCH(KC_, BN__)                                                                     \
+#define CG_DISPATCH(KC_, BN__, NW_)                                                                \
     do {                                                                                           \
-        if (pool && out_mode == 1) return cg_launch<KC_, BN__, true, CG_OUT_X, DT>(a, st);        \
-        if (pool) return cg_launch<KC_, BN__, true, CG_OUT_CL, DT>(a, st);                        \
-        if (out_mode == 1) return cg_launch<KC_, BN__, false, CG_OUT_X, DT>(a, st);               \
-        return cg_launch<KC_, BN__, false, CG_OUT_CL, DT>(a, st);                                 \
+        if (pool && out_mode == 1) return cg_launch<KC_, BN__, true, CG_OUT_X, DT, NW_>(a, st);   \
+        if (pool) return cg_launch<KC_, BN__, true, CG_OUT_CL, DT, NW_>(a, st);                   \
+        if (out_mode == 1) return cg_launch<KC_, BN__, false, CG_OUT_X, DT, NW_>(a, st);          \
+        return cg_launch<KC_, BN__, false, CG_OUT_CL, DT, NW_>(a, st);                            \
     } while (0)
-    if (bn256) CG_DISPATCH(32, 256);
+    // sixteen waves per workgroup where only one workgroup fits a CU (see convg_kernel); MT_CONVG_WAVES=8 keeps eight
+    static const bool w16 = !(getenv("MT_CONVG_WAVES") && atoi(getenv("MT_CONVG_WAVES")) == 8);
+    if (bn256) { if (w16) CG_DISPATCH(32, 256, 16); CG_DISPATCH(32, 256, 8); }
     // Two 64-channel workgroups per CU beat one 128-channel one where both fit (97 against 146 registers; input tile + ring <= 80 KB):
     // the second workgroup's MFMAs run under the first one's synchronous input staging and epilogue.  res_block2's first convolution
     // (64 -> 128): 0.99 -> 0.93 ms for the block, although each input tile is now staged twice.
-    if (kc64 && bn128 && cg_lds_bytes(a, 64, 64) <= 80 * 1024) CG_DISPATCH(64, 64);
-    if (kc64 && bn128) CG_DISPATCH(64, 128);
-    if (kc64) CG_DISPATCH(64, 64);
-    if (bn128) CG_DISPATCH(32, 128);
-    CG_DISPATCH(32, 64);
+    if (kc64 && bn128 && cg_lds_bytes(a, 64, 64) <= 80 * 1024) CG_DISPATCH(64, 64, 8);
+    if (kc64 && bn128) { if (w16) CG_DISPATCH(64, 128, 16); CG_DISPATCH(64, 128, 8); }
+    if (kc64) CG_DISPATCH(64, 64, 8);
+    if (bn128) { if (w16) CG_DISPATCH(32, 128, 16); CG_DISPATCH(32, 128, 8); }
+    CG_DISPATCH(32, 64, 8);
 #undef CG_DISPATCH
 }
 

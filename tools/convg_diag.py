@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "music-transcription_amd", "csrc")
 so = "/tmp/libmt_convg_diag.so"
 srcs = [os.path.join(csrc, f) for f in ("api.hip", "convg.hip")]
-subprocess.check_call(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMT_CONVG_DIAG -I{ROOT}/include -shared {' '.join(srcs)} -o {so}", shell=True)
+extra = " ".join(a for a in sys.argv[1:] if a.startswith("-D"))
+subprocess.check_call(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMT_CONVG_DIAG {extra} -I{ROOT}/include -shared {' '.join(srcs)} -o {so}", shell=True)
 lib = C.CDLL(so)
 vp, i32 = C.c_void_p, C.c_int
 lib.mt_conv_cl_ex.argtypes = [vp, i32, vp, i32, vp, vp, vp] + [i32] * 13 + [vp]
