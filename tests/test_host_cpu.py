@@ -334,3 +334,42 @@ def test_lpt_balances_a_maestro_sized_corpus_over_eight_ranks():
         assert shards == lpt_assign(list(dur), 8)
     # degenerate shapes: fewer recordings than ranks, one rank
     assert [len(s_) for s_ in lpt_assign([3.0, 1.0], 4)] == [1, 1, 0, 0] and lpt_assign([1.0, 2.0, 3.0], 1) == [[2, 1, 0]]
+
+
+def test_side_stream_tuner_keeps_the_fastest_candidate(mta, monkeypatch):
+    """train_step_large.SideStreamTuner (the choice of the training step's side streams by measurement, made inside a loop whose steps end in
+    a host synchronisation): candidate c serves steps [c (steps + 1), (c + 1)(steps + 1)), the first of them untimed; after the last candidate
+    the fastest one is restored into BOTH training steps' stream tables and the tuner goes quiet.  Streams and clock are faked: host logic only."""
+    from music_transcription_amd import train_step, train_step_large as TL
+    import time as _time
+    made = []
+
+    def fake_pair(dev):
+        key = str(dev)
+        if key not in TL._SIDE2:
+            made.append(("pair", len(made)))
+            TL._SIDE2[key] = made[-1]
+            train_step._SIDE[key] = ("single", len(made) - 1)
+        return TL._SIDE2[key]
+
+    monkeypatch.setattr(TL, "_side_streams", fake_pair)
+    monkeypatch.setenv("MT_TRAIN_STREAM_AUTOTUNE", "1")
+    clock = [0.0]
+    monkeypatch.setattr(_time, "perf_counter", lambda: clock[0])
+    TL._SIDE2.clear(); train_step._SIDE.clear()
+    tuner = TL.SideStreamTuner("cpu", candidates=3, steps=2)
+    cost = {0: 5.0, 1: 3.0, 2: 4.0}                    # seconds per step under candidate 0, 1, 2
+    for i in range(12):
+        tuner.step_begin()
+        c = fake_pair(torch.device("cpu"))[1] if not tuner.done else None      # (the step itself creates the streams)
+        clock[0] += 100.0 if (not tuner.done and i % 3 == 0) else (cost[c] if c is not None else 1.0)   # first step of a candidate: warm-up, any length
+        tuner.step_end()
+    assert tuner.done and [round(t, 6) for t, _ in tuner.seen] == [5.0, 3.0, 4.0]
+    assert TL._SIDE2["cpu"] == ("pair", 1) and train_step._SIDE["cpu"] == ("single", 1)
+    n = len(made)
+    tuner.step_begin(); tuner.step_end()               # quiet afterwards: no further candidates
+    assert len(made) == n == 3
+    TL._SIDE2.clear(); train_step._SIDE.clear()
+    off = TL.SideStreamTuner("cpu")
+    monkeypatch.setenv("MT_TRAIN_STREAM_AUTOTUNE", "0")
+    assert TL.SideStreamTuner("cpu").done and not off.done
