@@ -165,56 +165,113 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           double* __restrict__ sums, bf16_t* __restrict__ dz, bf16_t* __restrict__ dz_lo,
                                                           const unsigned* __restrict__ tie, int B, int F, int T) {
-    __shared__ float red[2][256];
-    const int c = threadIdx.x & 63, Fo = F >> 1, Fh = (F + 1) >> 1;     // Fh pairs; the last one is a single row when F is odd
-    const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+    // one thread = FOUR channels of one pooled position (two pre-pool rows), two positions per loop pass with all their loads issued
+    // first (8-byte loads of z, 16-byte loads of dX; the first version moved one 2-byte value per thread and round trip: 25 % of the HBM rate)
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 15, c0 = cg * 4, Fo = F >> 1, Fh = (F + 1) >> 1;     // Fh pairs; the last one is a single row when F is odd
+    float mu[4], rs[4], ga[4], be[4], m1[4], m2[4], s1[4], s2[4];
     const double cnt = (double)B * F * T;
-    float m1 = 0.0f, m2 = 0.0f;
-    if (APPLY) { m1 = (float)(sums[c] / cnt); m2 = (float)(sums[64 + c] / cnt); }
-    float s1 = 0.0f, s2 = 0.0f;
-    const long long n = (long long)B * Fh * T;
-    for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long long)gridDim.x * 4) {
-        const int t = (int)(i % T), fo = (int)((i / T) % Fh), b = (int)(i / ((long long)T * Fh));
-        const size_t p0 = (((size_t)b * F + 2 * fo) * T + t) * 64 + c;
-        const bool pair = fo < Fo;
-        const float x0 = (bf16_to_f32(z[p0]) - mu) * rs;
-        const float x1 = pair ? (bf16_to_f32(z[p0 + (size_t)T * 64]) - mu) * rs : 0.0f;
-        float d0 = 0.0f, d1 = 0.0f;
-        if (pair) {
-            const float y0 = fmaf(ga, x0, be), y1 = fmaf(ga, x1, be);
-            const float g = dX[((size_t)t * B + b) * ldd + (size_t)fo * 64 + c];
-            bool second = y1 > y0;
-            if (tie) {       // order of the conv's f32 results before their bf16 rounding (mt_conv_cl_tie): ties only where f32 ties
-                const unsigned* w_ = tie + ((((size_t)b * Fo + fo) * T + t) * 2 + (c >> 5)) * 2;
-                const bool gt = (w_[0] >> (c & 31)) & 1u, lt = (w_[1] >> (c & 31)) & 1u;
-                const float sc = ga * rs;
-                second = sc > 0.0f ? lt : (sc < 0.0f ? gt : false);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mu[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
+        m1[j] = APPLY ? (float)(sums[c0 + j] / cnt) : 0.0f;
+        m2[j] = APPLY ? (float)(sums[64 + c0 + j] / cnt) : 0.0f;
+        s1[j] = s2[j] = 0.0f;
+    }
+    const long long n = (long long)B * Fh * T, stride = (long long)gridDim.x * 16;
+    for (long long i0 = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); i0 < n; i0 += 2 * stride) {
+        uint2 r0[2], r1[2];
+        float g4[2][4];
+        unsigned tw[2][2];
+        size_t pp[2];
+        bool act[2], pr[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long i = i0 + u * stride;
+            act[u] = i < n; pr[u] = false; pp[u] = 0;
+            r0[u] = r1[u] = make_uint2(0, 0);
+            tw[u][0] = tw[u][1] = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g4[u][j] = 0.0f;
+            if (!act[u]) continue;
+            const int t = (int)(i % T), fo = (int)((i / T) % Fh), b = (int)(i / ((long long)T * Fh));
+            pp[u] = (((size_t)b * F + 2 * fo) * T + t) * 64 + c0;
+            pr[u] = fo < Fo;
+            r0[u] = *(const uint2*)(z + pp[u]);
+            if (pr[u]) {
+                r1[u] = *(const uint2*)(z + pp[u] + (size_t)T * 64);
+                const float4 gv = *(const float4*)(dX + ((size_t)t * B + b) * ldd + (size_t)fo * 64 + c0);
+                g4[u][0] = gv.x; g4[u][1] = gv.y; g4[u][2] = gv.z; g4[u][3] = gv.w;
+                if (tie) {
+                    const unsigned* w_ = tie + ((((size_t)b * Fo + fo) * T + t) * 2 + (c0 >> 5)) * 2;
+                    tw[u][0] = w_[0]; tw[u][1] = w_[1];
+                }
             }
-            if (second) { if (y1 > 0.0f) d1 = g; }
-            else if (y0 > 0.0f) d0 = g;
         }
-        if (APPLY) {
-            const float k = ga * rs;
-            const float g0 = k * (d0 - m1 - x0 * m2), g1 = k * (d1 - m1 - x1 * m2);
-            const bf16_t h0 = f32_to_bf16(g0), h1 = f32_to_bf16(g1);
-            dz[p0] = h0;
-            if (pair) dz[p0 + (size_t)T * 64] = h1;
-            if (dz_lo) {                               // second bf16 piece: dz = hi + lo to ~2^-17 (see mt_bn_pool_bwd)
-                dz_lo[p0] = f32_to_bf16(g0 - bf16_to_f32(h0));
-                if (pair) dz_lo[p0 + (size_t)T * 64] = f32_to_bf16(g1 - bf16_to_f32(h1));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!act[u]) continue;
+            const unsigned zw0[2] = {r0[u].x, r0[u].y}, zw1[2] = {r1[u].x, r1[u].y};
+            float o0[4], o1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned w0 = zw0[j >> 1], w1 = zw1[j >> 1];
+                const float z0 = __uint_as_float((j & 1) ? (w0 & 0xFFFF0000u) : (w0 << 16));
+                const float z1 = __uint_as_float((j & 1) ? (w1 & 0xFFFF0000u) : (w1 << 16));
+                const float x0 = (z0 - mu[j]) * rs[j];
+                const float x1 = pr[u] ? (z1 - mu[j]) * rs[j] : 0.0f;
+                float d0 = 0.0f, d1 = 0.0f;
+                if (pr[u]) {
+                    const float y0 = fmaf(ga[j], x0, be[j]), y1 = fmaf(ga[j], x1, be[j]);
+                    const float g = g4[u][j];
+                    bool second = y1 > y0;
+                    if (tie) {       // order of the conv's f32 results before their bf16 rounding (mt_conv_cl_tie): ties only where f32 ties
+                        const int c = c0 + j;
+                        const bool gt = (tw[u][0] >> (c & 31)) & 1u, lt = (tw[u][1] >> (c & 31)) & 1u;
+                        const float sc = ga[j] * rs[j];
+                        second = sc > 0.0f ? lt : (sc < 0.0f ? gt : false);
+                    }
+                    if (second) { if (y1 > 0.0f) d1 = g; }
+                    else if (y0 > 0.0f) d0 = g;
+                }
+                if (APPLY) {
+                    const float k = ga[j] * rs[j];
+                    o0[j] = k * (d0 - m1[j] - x0 * m2[j]);
+                    o1[j] = k * (d1 - m1[j] - x1 * m2[j]);
+                } else {
+                    s1[j] += d0 + d1;
+                    s2[j] = fmaf(d0, x0, fmaf(d1, x1, s2[j]));
+                }
             }
-        } else {
-            s1 += d0 + d1;
-            s2 = fmaf(d0, x0, fmaf(d1, x1, s2));
+            if (APPLY) {
+                const uint2 h0 = make_uint2(pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3]));
+                const uint2 h1 = make_uint2(pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]));
+                *(uint2*)(dz + pp[u]) = h0;
+                if (pr[u]) *(uint2*)(dz + pp[u] + (size_t)T * 64) = h1;
+                if (dz_lo) {                               // second bf16 piece: dz = hi + lo to ~2^-17 (see mt_bn_pool_bwd)
+                    const unsigned hw0[2] = {h0.x, h0.y}, hw1[2] = {h1.x, h1.y};
+                    float l0[4], l1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float b0 = __uint_as_float((j & 1) ? (hw0[j >> 1] & 0xFFFF0000u) : (hw0[j >> 1] << 16));
+                        const float b1 = __uint_as_float((j & 1) ? (hw1[j >> 1] & 0xFFFF0000u) : (hw1[j >> 1] << 16));
+                        l0[j] = o0[j] - b0; l1[j] = o1[j] - b1;
+                    }
+                    *(uint2*)(dz_lo + pp[u]) = make_uint2(pack_bf16x2(l0[0], l0[1]), pack_bf16x2(l0[2], l0[3]));
+                    if (pr[u]) *(uint2*)(dz_lo + pp[u] + (size_t)T * 64) = make_uint2(pack_bf16x2(l1[0], l1[1]), pack_bf16x2(l1[2], l1[3]));
+                }
+            }
         }
     }
     if (!APPLY) {
-        red[0][threadIdx.x] = s1;
-        red[1][threadIdx.x] = s2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[j][threadIdx.x] = s1[j]; red[4 + j][threadIdx.x] = s2[j]; }
         __syncthreads();
-        if (threadIdx.x < 64) {
-            atomicAdd(sums + c, (double)(red[0][c] + red[0][64 + c] + red[0][128 + c] + red[0][192 + c]));
-            atomicAdd(sums + 64 + c, (double)(red[1][c] + red[1][64 + c] + red[1][128 + c] + red[1][192 + c]));
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, c = threadIdx.x & 63, g2 = c >> 2, j = c & 3;
+            float acc = 0.0f;
+            for (int r = 0; r < 16; ++r) acc += red[which * 4 + j][r * 16 + g2];
+            atomicAdd(sums + which * 64 + c, (double)acc);
         }
     }
 }
@@ -646,8 +703,9 @@ extern "C" int mt_bn_pool_bwd_tie(const float* dX, int ldd, const void* z, const
                                   const float* beta, double* sums128, void* dz, void* dz_lo, float* dgamma, float* dbeta, const unsigned* tie,
                                   int B, int F, int T, mt_stream_t stream) {
     MT_REQUIRE(dX && z && mean && rstd && gamma && beta && sums128 && dz && B > 0 && F >= 2 && T > 0, MT_EINVAL, "mt_bn_pool_bwd: bad arguments");
+    MT_REQUIRE(ldd % 4 == 0 && ((size_t)dX & 15) == 0, MT_EINVAL, "mt_bn_pool_bwd: dX rows must be 16-byte aligned (ldd %% 4 == 0)");
     MT_CHECK_HIP(hipMemsetAsync(sums128, 0, 128 * sizeof(double), ST(stream)));
-    long long g = ((long long)B * ((F + 1) / 2) * T + 63) / 64;
+    long long g = ((long long)B * ((F + 1) / 2) * T + 127) / 128;     // 16 positions per workgroup and pass, a few passes per thread
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(bn_pool_bwd_kernel<false>, dim3((unsigned)g), dim3(256), 0, ST(stream), dX, ldd, (const bf16_t*)z, mean, rstd, gamma, beta,
                        sums128, (bf16_t*)nullptr, (bf16_t*)nullptr, tie, B, F, T);
