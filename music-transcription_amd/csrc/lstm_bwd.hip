@@ -62,7 +62,11 @@ __device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builti
 // partial-product MFMAs (TPW x 8 per wave) are both on the step's critical path and halve against a 4-wave workgroup.
 template <int TPW>
 __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16_t img[8][64][8];      // this workgroup's dgates of the step, as 8 MFMA B-operand images
+    // this workgroup's dgates of the step, as 8 MFMA B-operand images; TWO sets, alternating by step, so that a step needs ONE barrier (images
+    // complete): a wave rewrites a set two steps later, behind the other set's barrier, which every wave reaches after its reads of this one
+    // (round 3.  The second barrier of the single-set version was 0.24 us of the step's clock but NOT on its critical chain -- gather, cell math,
+    //  images, barrier, MFMAs, publish -- : the step time did not change, 21.3 - 21.6 ms per training step before and after.)
+    __shared__ __attribute__((aligned(16))) bf16_t img2[2][8][64][8];
     __shared__ int abort_s;
     typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         if (s + 1 < T) BPTT_FETCH(s + 1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- cell backward (lane-local)
+        bf16_t (*img)[64][8] = img2[s & 1];
         bf16_t o4[4][2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         for (int p = 0; p < 4; ++p)
             *(unsigned*)(&img[2 * p + (wv >> 2)][((wv >> 1) & 1) * 32 + b][jl0]) = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16);
         BD_STAMP(1);
-        __syncthreads();                                // images complete (and every wave is past the previous step's reads of img)
+        __syncthreads();                                // images complete (the other set's readers are two barriers behind: see img2)
         BD_STAMP(2);
         if (abort_s) return;                            // a payload spin gave up (status word says where)
         // ---- reduce-scatter, producer side: partial[k][b] = sum over OWN gate rows of W_hh[rho][k] dgates[rho][b] for the
@@ -256,7 +261,6 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
             uint4* dst = (uint4*)(dgx_g + ((((size_t)t * 2 + d) * NW + w) * 8) * 1024);
             dst[tid] = *(const uint4*)(&img[tid >> 6][tid & 63][0]);
         }
-        __syncthreads();                                // every wave is done reading img before the next step rewrites it
         BD_STAMP(4);
     }
 #ifdef MT_BPTT_DIAG
