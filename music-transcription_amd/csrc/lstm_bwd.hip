@@ -60,8 +60,13 @@ __device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builti
 
 // TPW = consumer tiles (32 hidden units each) per wave: ceil(NW / 8).  Eight waves: the cell math (2 cells per thread) and the
 // partial-product MFMAs (TPW x 8 per wave) are both on the step's critical path and halve against a 4-wave workgroup.
-template <int TPW>
+// ONE (B <= 16, one batch group): a batch group's 32 columns are half empty then, and with two cells per thread (units 2hh, 2hh + 1 of batch
+// lane & 31) half of the lanes idle through the step's fetches and cell math while the other half does double work.  ONE maps a thread to ONE
+// cell: batch lane & 15, unit 4wv + (lane >> 4) -- six fetches and one cell per lane instead of twelve and two on the step's critical chain;
+// images, MFMAs, slices and the dgx output keep their layout (the upper 16 batch columns stay zero).
+template <int TPW, bool ONE = false>
 __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
+    constexpr int NE = ONE ? 1 : 2;                      // cells per thread
     // this workgroup's dgates of the step, as 8 MFMA B-operand images; TWO sets, alternating by step, so that a step needs ONE barrier (images
     // complete): a wave rewrites a set two steps later, behind the other set's barrier, which every wave reaches after its reads of this one
     // (round 3.  The second barrier of the single-set version was 0.24 us of the step's clock but NOT on its critical chain -- gather, cell math,
@@ -94,9 +99,10 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
             }
     }
 
-    // this thread's cells: units u = 4wv + 2hh + e (e = 0, 1) of the workgroup, batch row b
-    const int kb = 4 * w + (wv >> 1), jl0 = 4 * (wv & 1) + 2 * hh;
-    const bool live = (kb < nkb) && (b < Bg);
+    // this thread's cells: units u = 4wv + 2hh + e (e = 0, 1) of the workgroup, batch row b (ONE: unit 4wv + (lane >> 4), batch lane & 15)
+    const int cb = ONE ? (lane & 15) : b;
+    const int kb = 4 * w + (wv >> 1), jl0 = ONE ? 4 * (wv & 1) + (lane >> 4) : 4 * (wv & 1) + 2 * hh;
+    const bool live = (kb < nkb) && (cb < Bg);
     const size_t g_blocks = (size_t)T * 2 * nkb;
     const float* gates_g = a.gates + g * g_blocks * 1024;
     const float* cx_g = a.cx + g * g_blocks * 256;
@@ -106,6 +112,9 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
     char* part_g = (char*)a.part + g * part_bytes;
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(part_g, 0, (int)part_bytes, 0x00020000);
     if (tid == 0) abort_s = 0;
+    if (ONE) {                                           // the batch columns nobody writes
+        for (int i = tid; i < 2 * 8 * 64 * 8 / 8; i += 512) ((uint4*)&img2[0][0][0][0])[i] = make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
 
     float carry[2] = {0.0f, 0.0f};                   // dc[t_next] * f[t_next]
@@ -118,8 +127,8 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         const int t_ = d ? (S_) : (T - 1 - (S_));                                                                   \
         const int tp_ = d ? (t_ + 1) : (t_ - 1);                                                                    \
         const size_t blk_ = ((size_t)t_ * 2 + d) * nkb + kb, blkp_ = ((size_t)tp_ * 2 + d) * nkb + kb;             \
-        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                             \
-            const int off_ = (jl0 + e) * 32 + b;                                                                    \
+        _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                                            \
+            const int off_ = (jl0 + e) * 32 + cb;                                                                   \
             _Pragma("unroll") for (int p = 0; p < 4; ++p) gt[p][e] = live ? gates_g[blk_ * 1024 + p * 256 + off_] : 0.0f; \
             dhin[e] = live ? dh_g[blk_ * 256 + off_] : 0.0f;                                                        \
             cprev[e] = (live && tp_ >= 0 && tp_ < T) ? cx_g[blkp_ * 256 + off_] : 0.0f;                             \
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
     {
         const size_t blk0 = ((size_t)(d ? 0 : T - 1) * 2 + d) * nkb + kb;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) ccur[e] = live ? cx_g[blk0 * 256 + (jl0 + e) * 32 + b] : 0.0f;
+        for (int e = 0; e < NE; ++e) ccur[e] = live ? cx_g[blk0 * 256 + (jl0 + e) * 32 + cb] : 0.0f;
     }
     BPTT_FETCH(0);
 #ifdef MT_BPTT_DIAG
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         const int tn = d ? (t - 1) : (t + 1);         // the step processed just before this one
         float g_i[2], g_f[2], g_g[2], g_o[2], c_prev[2], dh_in[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) { g_i[e] = gt[0][e]; g_f[e] = gt[1][e]; g_g[e] = gt[2][e]; g_o[e] = gt[3][e]; c_prev[e] = cprev[e]; dh_in[e] = dhin[e]; }
+        for (int e = 0; e < NE; ++e) { g_i[e] = gt[0][e]; g_f[e] = gt[1][e]; g_g[e] = gt[2][e]; g_o[e] = gt[3][e]; c_prev[e] = cprev[e]; dh_in[e] = dhin[e]; }
         float rec[2] = {0.0f, 0.0f};                  // (W_hh^T dgates[t_next]) for this thread's 2 units
         // Everything of the cell backward that does not depend on the gathered dh is computed HERE, in front of the gather: the
         // per-phase clock (tools/bptt_diag.py) had 0.55 us of fetch issue + cell math behind the gather and a 0.3 us sleep in front
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         // cell on the critical path.
         float fA[2], fO[2], fI[2], fF[2], fG[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const float ig = g_i[e], fg = g_f[e], gg = g_g[e], og = g_o[e];
             const float tc = tanh_fast(ccur[e]);
             fA[e] = og * (1.0f - tc * tc);            // d c / d h-gradient
@@ -162,7 +171,8 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
             //      for this workgroup; this thread's 2 units x 1 batch row are half an 8-B word of each slice.  No flag: the
             //      loads poll the poison pattern (as lstm.hip); the short sleep keeps the certain-to-fail first attempt,
             //      issued right behind this workgroup's own publish, off the fabric.
-            const int gbase = (((tn * 2 + d) * NW + w) * NW) * 2048 + (wv * 32 + b) * 8 + hh * 4;
+            // (ONE: the 4-byte half of the word that holds this thread's unit; the other unit of the half is dropped below)
+            const int gbase = (((tn * 2 + d) * NW + w) * NW) * 2048 + (wv * 32 + cb) * 8 + (ONE ? ((lane >> 5) & 1) : hh) * 4;
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
                 unsigned raw[TPW * 8];
@@ -178,7 +188,8 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
                     sum[1] += __uint_as_float(raw[i] & 0xFFFF0000u);
                 }
                 if (!__any(worst == DG_POISON)) {
-                    rec[0] = sum[0]; rec[1] = sum[1];
+                    if (ONE) rec[0] = ((lane >> 4) & 1) ? sum[1] : sum[0];
+                    else { rec[0] = sum[0]; rec[1] = sum[1]; }
                     break;
                 }
 #ifdef MT_BPTT_DIAG
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         bf16_t (*img)[64][8] = img2[s & 1];
         bf16_t o4[4][2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const float dhv = dh_in[e] + rec[e];
             const float dc = fmaf(dhv, fA[e], carry[e]);
             float di = dc * fI[e];
@@ -227,8 +238,10 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         // ---- the workgroup's dgates as 8 B-operand images: (gate p, unit u) -> image 2p + (u >> 4),
         //      lane ((u >> 3) & 1)*32 + batch, element u & 7;  u = 4wv + 2hh + e
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            *(unsigned*)(&img[2 * p + (wv >> 2)][((wv >> 1) & 1) * 32 + b][jl0]) = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16);
+        for (int p = 0; p < 4; ++p) {
+            if (ONE) img[2 * p + (wv >> 2)][((wv >> 1) & 1) * 32 + cb][jl0] = o4[p][0];
+            else *(unsigned*)(&img[2 * p + (wv >> 2)][((wv >> 1) & 1) * 32 + b][jl0]) = (unsigned)o4[p][0] | ((unsigned)o4[p][1] << 16);
+        }
         BD_STAMP(1);
         __syncthreads();                                // images complete (the other set's readers are two barriers behind: see img2)
         BD_STAMP(2);
@@ -251,7 +264,8 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {           // registers 4q..4q+3 = units 8q + 4hh + (0..3): word (unit/4 = 2q + hh, batch b)
                     const u32x2 v = {pack_bf16x2(acc[4 * q], acc[4 * q + 1]), pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(v, prsrc, obase + q * 512, 0, 16 /*sc1: write-through*/);
+                    // (ONE: the consumers read batch columns 0..15 only -- the other half of every slice stays poisoned and is never looked at)
+                    if (!ONE || b < 16) __builtin_amdgcn_raw_buffer_store_b64(v, prsrc, obase + q * 512, 0, 16 /*sc1: write-through*/);
                 }
             }
         }
@@ -434,11 +448,15 @@ extern "C" int mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const f
     dim3 grid(NW, 2, NG);
     MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);
     // every workgroup of this persistent launch must be resident: admission check (residency.hip), completion event behind it
-    const void* kern = NW <= 8 ? (const void*)lstm_bptt_kernel<1> : (const void*)lstm_bptt_kernel<2>;
+    const bool one = B <= 16;                              // one cell per thread (see lstm_bptt_kernel)
+    const void* kern = NW <= 8 ? (one ? (const void*)lstm_bptt_kernel<1, true> : (const void*)lstm_bptt_kernel<1, false>)
+                               : (one ? (const void*)lstm_bptt_kernel<2, true> : (const void*)lstm_bptt_kernel<2, false>);
     int rc = persistent_admit(kern, 512, 0, NW * 2 * NG, st, "mt_lstm_bidir_bwd");
     if (rc != MT_OK) return rc;
-    if (NW <= 8) hipLaunchKernelGGL(lstm_bptt_kernel<1>, grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(lstm_bptt_kernel<2>, grid, dim3(512), 0, st, a);
+    if (NW <= 8 && one) hipLaunchKernelGGL((lstm_bptt_kernel<1, true>), grid, dim3(512), 0, st, a);
+    else if (NW <= 8) hipLaunchKernelGGL((lstm_bptt_kernel<1, false>), grid, dim3(512), 0, st, a);
+    else if (one) hipLaunchKernelGGL((lstm_bptt_kernel<2, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((lstm_bptt_kernel<2, false>), grid, dim3(512), 0, st, a);
     MT_CHECK_LAUNCH_OR_CANCEL();
     return persistent_mark(st);
 }

@@ -232,13 +232,15 @@ def test_train_grads_match_oracle_autograd(mta, nm, H, L, B, T):
     assert not bad and cos > GRAD_COS, (bad, cos)
 
 
-def test_lstm_bptt_canonical_width(mta):
+@pytest.mark.parametrize("B", [16, 9, 24, 40])
+def test_lstm_bptt_canonical_width(mta, B):
     """The backward recurrence at the canonical hidden size (H = 512: 16 workgroups per direction) on a short
-    sequence, against torch autograd through the oracle's explicit LSTM loop."""
+    sequence, against torch autograd through the oracle's explicit LSTM loop.  B <= 16 runs the one-cell-per-thread variant of the
+    kernel, 24 the two-cell one with a ragged batch group, 40 two batch groups."""
     from music_transcription_amd import _lib
     from music_transcription_amd._lib import lib, check, ptr
     torch.manual_seed(3)
-    B, T, H, K = 16, 24, 512, 64
+    T, H, K = 24, 512, 64
     x = torch.randn(B, T, K) * 0.5
     w_ih = (torch.rand(2, 4 * H, K) - 0.5) * 0.08
     w_hh = (torch.rand(2, 4 * H, H) - 0.5) * 0.08
