@@ -83,20 +83,39 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
     // ---- W_hh slices as MFMA A-operands.  Tile i of this wave serves consumer wc = wv*TPW + i (hidden units k = 32wc + r):
     //      lane (row r, k half hh) holds, for k-step ks over this workgroup's OWN 128 gate rows rho = 16ks + 8hh + e
     //      (gate p = rho >> 5, unit u = rho & 31):  W_hh[p*H + 32w + u][32wc + r]
+    //      ONE: 16x16x32 tiles (the batch fills 16 columns): 16-unit tile mt of this wave = units 16 mt .. of its 32 TPW consumers' units;
+    //      lane (row i = lane & 15, k group kg = lane >> 4) holds, for k-step ks2 over gate rows rho = 32 ks2 + 8 kg + e (gate p = ks2, unit u = 8 kg + e),
+    //      the same matrix element.  Half the MFMA passes, half the fragment reads, and a lane's 4 results are one 8-byte word of a slice.
     const int r = lane & 31;
-    bf16x8 wt[TPW][8];
+    bf16x8 wt[ONE ? 2 * TPW : TPW][ONE ? 4 : 8];
+    if (ONE) {
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int wc = wv * TPW + i, k = 32 * wc + r;
+        for (int mt = 0; mt < 2 * TPW; ++mt) {
+            const int wc = wv * TPW + (mt >> 1), k = 32 * wc + 16 * (mt & 1) + (lane & 15);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+            for (int ks2 = 0; ks2 < 4; ++ks2)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int rho = ks * 16 + 8 * hh + e, p = rho >> 5, u = rho & 31, jo = 32 * w + u;
-                float v = 0.0f;
-                if (wc < NW && k < H && jo < H) v = a.w_hh[((size_t)d * 4 * H + (size_t)p * H + jo) * H + k];
-                wt[i][ks][e] = (short)f32_to_bf16(v);
-            }
+                for (int e = 0; e < 8; ++e) {
+                    const int u = 8 * (lane >> 4) + e, jo = 32 * w + u;
+                    float v = 0.0f;
+                    if (wc < NW && k < H && jo < H) v = a.w_hh[((size_t)d * 4 * H + (size_t)ks2 * H + jo) * H + k];
+                    wt[mt][ks2][e] = (short)f32_to_bf16(v);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int wc = wv * TPW + i, k = 32 * wc + r;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int rho = ks * 16 + 8 * hh + e, p = rho >> 5, u = rho & 31, jo = 32 * w + u;
+                    float v = 0.0f;
+                    if (wc < NW && k < H && jo < H) v = a.w_hh[((size_t)d * 4 * H + (size_t)p * H + jo) * H + k];
+                    wt[i][ks][e] = (short)f32_to_bf16(v);
+                }
+        }
     }
 
     // this thread's cells: units u = 4wv + 2hh + e (e = 0, 1) of the workgroup, batch row b (ONE: unit 4wv + (lane >> 4), batch lane & 15)
@@ -248,24 +267,45 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         if (abort_s) return;                            // a payload spin gave up (status word says where)
         // ---- reduce-scatter, producer side: partial[k][b] = sum over OWN gate rows of W_hh[rho][k] dgates[rho][b] for the
         //      consumer tiles of this wave, stored as bf16 slices [consumer][producer][unit/4][batch][4]
-        bf16x8 bfr[8];
+        if (ONE) {
+            // B fragments of the 16x16x32 form straight from the same images: k-step ks2, lane (batch lane & 15, k group kg) = image 2 ks2 + (kg >> 1),
+            // image lane (kg & 1) * 32 + batch
+            const int kg = lane >> 4, bb = lane & 15;
+            bf16x8 bfr[4];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) bfr[ks] = *(const bf16x8*)(&img[ks][lane][0]);
+            for (int ks2 = 0; ks2 < 4; ++ks2) bfr[ks2] = *(const bf16x8*)(&img[2 * ks2 + (kg >> 1)][(kg & 1) * 32 + bb][0]);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int wc = wv * TPW + i;
-            if (wc < NW) {
-                f32x16 acc;
+            for (int mt = 0; mt < 2 * TPW; ++mt) {
+                const int wc = wv * TPW + (mt >> 1);
+                if (wc < NW) {
+                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+                    for (int ks2 = 0; ks2 < 4; ++ks2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[mt][ks2], bfr[ks2], acc, 0, 0, 0);
+                    // lane (batch bb, kg): results = units 16 (mt & 1) + 4 kg + (0..3) of consumer wc: word (unit/4 = 4 (mt & 1) + kg, batch bb)
+                    const int obase = (((t * 2 + d) * NW + wc) * NW + w) * 2048 + ((4 * (mt & 1) + kg) * 32 + bb) * 8;
+                    const u32x2 v = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(v, prsrc, obase, 0, 16 /*sc1: write-through*/);
+                }
+            }
+        } else {
+            bf16x8 bfr[8];
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[i][ks], bfr[ks], acc, 0, 0, 0);
-                const int obase = (((t * 2 + d) * NW + wc) * NW + w) * 2048 + (hh * 32 + b) * 8;
+            for (int ks = 0; ks < 8; ++ks) bfr[ks] = *(const bf16x8*)(&img[ks][lane][0]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {           // registers 4q..4q+3 = units 8q + 4hh + (0..3): word (unit/4 = 2q + hh, batch b)
-                    const u32x2 v = {pack_bf16x2(acc[4 * q], acc[4 * q + 1]), pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3])};
-                    // (ONE: the consumers read batch columns 0..15 only -- the other half of every slice stays poisoned and is never looked at)
-                    if (!ONE || b < 16) __builtin_amdgcn_raw_buffer_store_b64(v, prsrc, obase + q * 512, 0, 16 /*sc1: write-through*/);
+            for (int i = 0; i < TPW; ++i) {
+                const int wc = wv * TPW + i;
+                if (wc < NW) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[i][ks], bfr[ks], acc, 0, 0, 0);
+                    const int obase = (((t * 2 + d) * NW + wc) * NW + w) * 2048 + (hh * 32 + b) * 8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {           // registers 4q..4q+3 = units 8q + 4hh + (0..3): word (unit/4 = 2q + hh, batch b)
+                        const u32x2 v = {pack_bf16x2(acc[4 * q], acc[4 * q + 1]), pack_bf16x2(acc[4 * q + 2], acc[4 * q + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b64(v, prsrc, obase + q * 512, 0, 16 /*sc1: write-through*/);
+                    }
                 }
             }
         }
