@@ -51,6 +51,7 @@ struct LstmBwdArgs {
     unsigned* flags;      // (unused by the flagless hand-off)
     unsigned* status;     // abort word, zeroed before every launch
     int B, T, H;
+    int sleep_first;      // s_sleep units (64 clocks) in front of a step's first poll (MT_BPTT_POLL_FIRST; default 0)
 };
 
 #ifdef MT_BPTT_DIAG
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
             fG[e] = ig * (1.0f - gg * gg);
         }
         if (s > 0) {
+            for (int i_ = 0; i_ < a.sleep_first; ++i_) __builtin_amdgcn_s_sleep(1);
             // ---- reduce-scatter, consumer side: every producer wp left a 32-unit x 32-batch slice of ITS partial product
             //      for this workgroup; this thread's 2 units x 1 batch row are half an 8-B word of each slice.  No flag: the
             //      loads poll the poison pattern (as lstm.hip); the short sleep keeps the certain-to-fail first attempt,
@@ -488,7 +490,8 @@ extern "C" int mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const f
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, 256, st));
     if (!(flags & 1)) MT_CHECK_HIP(hipMemsetAsync(part_ws, 0xFF, mt_lstm_bwd_part_bytes(B, T, H), st));     // poison: see the hand-off note
-    LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, part_ws, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H};
+    static const int env_first = getenv("MT_BPTT_POLL_FIRST") ? atoi(getenv("MT_BPTT_POLL_FIRST")) : 0;
+    LstmBwdArgs a{gates, cx, dh, w_hh, (bf16_t*)dgx, part_ws, (unsigned*)((char*)sync_ws + 256), (unsigned*)sync_ws, B, T, H, env_first};
     dim3 grid(NW, 2, NG);
     MT_REQUIRE(NW * 2 * NG <= 256, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: %d workgroups must be co-resident (<= 256 CUs)", NW * 2 * NG);
     // every workgroup of this persistent launch must be resident: admission check (residency.hip), completion event behind it
