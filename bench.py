@@ -14,16 +14,16 @@ Chunks are independent (main.py:258-266 keeps no cross-chunk state), so N GPUs r
 schedules with no data-path collective (weak scaling); the only collectives are the timing barrier
 and a MAX over ranks of the elapsed time.
 
-Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+Rank 0 prints ONE JSON line of at most 4 KB as the LAST line of stdout (compact_line): the contract fields,
   roofline     -- the kernel that dominates the step, timed with HIP events on the launch stream (recorded
                   natively by mt_cnnrnn_forward_ex) in an un-overlapped pass of this run: ONE forward of the
-                  timed region's shape in flight (roofline_one_batch: one batch of 32; roofline_overlapped: the
-                  timed region itself, forwards overlapping);
-  stages       -- the same for every kernel of the step;
+                  timed region's shape in flight; roofline.all = {stage: fraction of its roofline};
   cpu_baseline -- the CPU oracle (a port of the reference path, oracle/*.py) timed on this node's
-                  host cores on a bounded sample of the same workload (batch 1 and batch 8), rank 0, N = 1 only;
-  configs1_other_schedules, configs2_large_b16, configs3_train_b16 -- the neighbouring BASELINE configs and
-                  schedules, each with its own throughput / roofline / cpu_baseline.
+                  host cores on a bounded sample of the same workload, rank 0, N = 1 only;
+  configs1_literal_b32 -- BASELINE configs[1] as written: ONE batch of 32 chunks per forward;
+  sections     -- one short object per neighbouring BASELINE config (Large inference, both training steps, corpus).
+Everything else (stage tables of every pass, schedules, autotune lists, samples) goes to bench_detail.json
+(repo root and gpurun_out/; MT_BENCH_DETAIL overrides the path).
 """
 import argparse
 import json
@@ -434,7 +434,7 @@ def section_large(mta, dev, cores, do_cpu):
     ms = [float(np.mean([evs[i][k].elapsed_time(evs[i][k + 1]) for i in range(K1)])) for k in range(nst)]
     stages = _stage_rows(large_stage_table(B, T, N_MELS, HIDDEN, LAYERS), ms)
     dom, roof = _roofline_from_stages(stages)
-    roof["traffic"], roof["traffic_source"] = _pmc_traffic(("r03_pmc_traffic_large.json",), dom)
+    roof["traffic"], roof["traffic_source"] = _pmc_traffic(("r04_pmc_traffic_large.json", "r03_pmc_traffic_large.json"), dom)
     # the same with 8 batches of 16 per forward (four batch groups of 32 interleaved in each persistent recurrence launch)
     cos = None
     try:
@@ -550,7 +550,7 @@ def section_train(mta, dev, cores, do_cpu):
                 table.append((nm_, bound, work, "FLOP")); ms.append(float(np.mean(spans[nm_])))
     stages = _stage_rows(table, ms)
     dom, roof = _roofline_from_stages(stages, share_of=1e3 * el / K)
-    roof["traffic"], roof["traffic_source"] = _pmc_traffic(("r03_pmc_traffic_train.json",), dom)
+    roof["traffic"], roof["traffic_source"] = _pmc_traffic(("r04_pmc_traffic_train.json", "r03_pmc_traffic_train.json"), dom)
     sec = {"workload": "CNNRNNModel training step, batch=16 cached-format chunks, 1 GPU (BASELINE.json configs[3] per-GPU shape)",
            "value": round(B * K / el, 2), "unit": "chunks/s", "ms_per_step": round(1e3 * el / K, 3), "steps": K,
            "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "model_tflops_per_s": round(3.0 * 72.76e9 * B * T / 938.0 * K / el / 1e12, 1),
@@ -615,7 +615,7 @@ def section_train_large(mta, dev, cores, do_cpu):
            "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "model_tflops_per_s": round(tf, 1),
            "roofline": {"kernel": "whole training step (3 x forward FLOPs)", "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                        "per_kernel": "profiles/r03_train_large_b16_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --mode train --model cnn_rnn_large`)"},
+                        "per_kernel": "profiles/r04_train_large_b16_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --mode train --model cnn_rnn_large`)"},
            "final_loss": round(float(loss.item()), 5),
            "side_stream_autotune_ms_per_step": [round(1e3 * t, 2) for t in tuned]}
     if do_cpu:
@@ -663,14 +663,143 @@ def section_corpus(mta, dev, cores, do_cpu):
                                   threshold=0.5, want_notes=True, reference_roll_of=ref_roll)
     n, wall = res["chunks"], res["wall_s"]
     f1 = list(res["f1"].values())
-    return {"workload": f"offline corpus transcription, {n_rec} synthetic recordings / {hours:g} h of 16 kHz audio, CNNRNNModelLarge, 1 GPU "
-                        "(BASELINE.json configs[4]; on 8 GPUs the recordings are LPT-sharded over the ranks, no data-path collective)",
-            "value": round(n / wall, 1), "unit": "chunks/s", "wall_s": round(wall, 3), "chunks": n, "slabs_of_128": res["slabs"],
-            "audio_hours_per_wall_second": round(hours / wall, 2), "notes": res["n_notes"], "finite": res["finite"],
-            "mean_f1_vs_random_reference": round(float(sum(f1) / max(len(f1), 1)), 5),
-            "d2h": "note lists only (two ints per note + 88 counts per recording); rolls and logits stay on the GPU",
-            "timed": "slab assembly across recordings, mel + forward of every slab (3 streams), per-recording notes (mt_roll_to_notes) and F1 counts; "
-                     f"not timed: synthesis of the audio ({t_synth:.1f} s, resident in HBM), weight packing"}
+    sec = {"workload": f"offline corpus transcription, {n_rec} synthetic recordings / {hours:g} h of 16 kHz audio, CNNRNNModelLarge, 1 GPU "
+                       "(BASELINE.json configs[4]; on 8 GPUs the recordings are LPT-sharded over the ranks, no data-path collective)",
+           "value": round(n / wall, 1), "unit": "chunks/s", "wall_s": round(wall, 3), "chunks": n, "slabs_of_128": res["slabs"],
+           "audio_hours_per_wall_second": round(hours / wall, 2), "notes": res["n_notes"], "finite": res["finite"],
+           "mean_f1_vs_random_reference": round(float(sum(f1) / max(len(f1), 1)), 5),
+           "d2h": "note lists only (two ints per note + 88 counts per recording); rolls and logits stay on the GPU",
+           "timed": "slab assembly across recordings, mel + forward of every slab (3 streams), per-recording notes (mt_roll_to_notes) and F1 counts "
+                    "as soon as a recording's last slab is done (logits held per slab); "
+                    f"not timed: synthesis of the audio ({t_synth:.1f} s, resident in HBM), weight packing"}
+    # ---- the same corpus END TO END from what a MAESTRO .wav holds: 44.1 kHz stereo int16 PCM in pinned host memory.  Timed: H2D of
+    #      every recording (copy stream, two recordings ahead), channel mean + PCM scaling + polyphase resampling to 16 kHz
+    #      (mt_resample_polyphase = librosa.load(sr=16000, mono=True), main.py:76), chunking (main.py:60-100), then as above.
+    try:
+        del chunks
+        torch.cuda.empty_cache()
+        rate = 44100
+        t1 = time.perf_counter()
+        pcm, off = {}, 0
+        frames = [int(durations[i] * rate) for i in range(n_rec)]
+        big = torch.empty(sum(frames), 2, dtype=torch.int16, pin_memory=True)      # ONE pinned region (12.7 GB), a view per recording
+        for i in range(n_rec):
+            g = torch.Generator(device=dev).manual_seed(777 + i)
+            m = frames[i]
+            t = torch.arange(m, device=dev, dtype=torch.float32) / rate
+            y = 0.1 * torch.randn(m, device=dev, generator=g)
+            for k in range(4):
+                f0 = 27.5 * 2.0 ** (float(torch.randint(0, 88, (1,), device=dev, generator=g)) / 12.0)
+                y += 0.3 * torch.exp(-((t * (0.5 + k)) % 3.0)) * torch.sin(2 * torch.pi * f0 * t)
+            st = torch.stack([y, 0.8 * y + 0.02 * torch.randn(m, device=dev, generator=g)], 1).clamp_(-1, 1)
+            pcm[i] = big[off:off + m]
+            pcm[i].copy_((st * 32767.0).to(torch.int16))
+            off += m
+            del t, y, st
+        torch.cuda.synchronize()
+        t_pcm = time.perf_counter() - t1
+        src = corpus.PcmSource(lambda i: pcm[i], lambda i: rate, list(range(n_rec)), dev, ahead=2)
+        src(0)                                                 # the resampler's filter table for (44100, 16000): built once, not timed
+        src = corpus.PcmSource(lambda i: pcm[i], lambda i: rate, list(range(n_rec)), dev, ahead=2)
+        torch.cuda.synchronize()
+        res2 = corpus.transcribe_shard(model, list(range(n_rec)), src, n_mels=N_MELS, device=dev, batch=128, streams=3,
+                                       threshold=0.5, want_notes=True, reference_roll_of=ref_roll)
+        n2, wall2 = res2["chunks"], res2["wall_s"]
+        sec["_extra"] = {"configs4_corpus_from_pcm": {
+            "workload": f"the same corpus end to end from {rate / 1000:g} kHz stereo int16 PCM in pinned host memory ({src.bytes_h2d / 1e9:.1f} GB): H2D + "
+                        "channel mean + polyphase resampling to 16 kHz + chunking + mel + CNNRNNModelLarge forward + notes + F1, 1 GPU",
+            "value": round(n2 / wall2, 1), "unit": "chunks/s", "wall_s": round(wall2, 3), "chunks": n2, "notes": res2["n_notes"], "finite": res2["finite"],
+            "audio_hours_per_wall_second": round(hours / wall2, 2), "h2d_gb": round(src.bytes_h2d / 1e9, 2),
+            "h2d_gb_per_s_needed": round(src.bytes_h2d / 1e9 / wall2, 1),
+            "timed": "everything from the pinned host PCM to the note lists; not timed: synthesis of the PCM "
+                     f"({t_pcm:.1f} s), the resampler's filter table (316 KB, built once per rate pair), weight packing"}}
+        del pcm, big
+    except Exception as e:
+        import traceback
+        sec["_extra"] = {"configs4_corpus_from_pcm": {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}}
+    return sec
+
+
+LINE_LIMIT = 4096          # bytes: the driver keeps a bounded tail of stdout; round 3's 21.7 KB line was cut and could not be parsed
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(d):
+    """The ONE JSON line of the contract, <= LINE_LIMIT bytes: the contract's scalar fields, `roofline` (dominant kernel + every
+    stage's fraction as {kernel: frac}), `cpu_baseline`, the literal configs[1] schedule (one batch of 32 per forward) and one
+    short object per neighbouring BASELINE config.  Stage tables, schedules and autotune lists live in bench_detail.json."""
+    rf = d.get("roofline") or {}
+    roof = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "share_of_step", "mfma_dtype"))
+    roof.setdefault("traffic", None)
+    roof["all"] = {k: round(v, 3) for k, v in (rf.get("all") or {}).items()}
+    cfg = d.get("config") or {}
+    config = _pick(cfg, ("workload", "batch_per_gpu", "frames", "coscheduled_batches_per_forward", "streams_per_gpu", "batches_in_flight", "parallelism"))
+    cpu = d.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        c2 = _pick(cpu, ("value", "unit", "cores", "kind", "error"))
+        if "sample" in cpu:
+            c2["sample"] = str(cpu["sample"])[:120]
+        if isinstance(cpu.get("batch8"), dict):
+            c2["batch8_value"] = cpu["batch8"].get("value")
+        cpu = c2
+    out = _pick(d, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    out["vs_baseline"] = d.get("vs_baseline")
+    out.update({"dtype": "f16", "data": d.get("data", "synthetic"), "config": config, "roofline": roof, "cpu_baseline": cpu})
+    if isinstance(d.get("roofline_one_batch"), dict):
+        out["roofline_one_batch"] = _pick(d["roofline_one_batch"], ("kernel", "frac", "avg_launch_ms"))
+    lit = d.get("configs1_literal_b32")
+    if isinstance(lit, dict):
+        out["configs1_literal_b32"] = _pick(lit, ("value", "unit", "ms_per_step", "streams", "one_in_flight", "error"))
+    secs = {}
+    for name in ("configs2_large_b16", "configs3_train_b16", "train_large_b16", "configs4_corpus", "configs4_corpus_from_pcm"):
+        sec = d.get(name)
+        if not isinstance(sec, dict):
+            continue
+        if "error" in sec:
+            secs[name] = {"error": str(sec["error"])[:160]}
+            continue
+        o = _pick(sec, ("value", "unit", "ms_per_step", "wall_s", "chunks", "notes"))
+        r_ = sec.get("roofline")
+        if isinstance(r_, dict):
+            o["roofline_kernel"], o["roofline_frac"] = str(r_.get("kernel"))[:40], r_.get("frac")
+        cb = sec.get("cpu_baseline")
+        if isinstance(cb, dict):
+            o["cpu_baseline"] = cb.get("value")
+        secs[name] = o
+    out["sections"] = secs
+    for key in ("all_large", "all_train"):
+        if rf.get(key):
+            out["roofline"][key] = {k: round(v, 3) for k, v in rf[key].items()}
+    out["detail"] = "bench_detail.json"
+    line = json.dumps(out, separators=(",", ":"))
+    for drop in (("roofline", "all_train"), ("roofline", "all_large"), ("roofline_one_batch",), ("sections",)):     # never over the limit
+        if len(line) <= LINE_LIMIT:
+            break
+        tgt = out
+        for k in drop[:-1]:
+            tgt = tgt.get(k, {})
+        tgt.pop(drop[-1], None)
+        line = json.dumps(out, separators=(",", ":"))
+    return line
+
+
+def emit(detail):
+    """Full record -> bench_detail.json (repo root, and gpurun_out/ when it exists so that it travels back from a GPU box);
+    compact record -> the LAST line of stdout."""
+    paths = ([os.environ["MT_BENCH_DETAIL"]] if os.environ.get("MT_BENCH_DETAIL") else
+             [os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")])
+    for path in paths:
+        try:
+            if os.path.isdir(os.path.dirname(os.path.abspath(path))):
+                with open(path, "w") as f:
+                    json.dump(detail, f)
+        except OSError as e:
+            log(f"could not write {path}: {e}")
+    sys.stderr.flush()
+    print(compact_line(detail), flush=True)
 
 
 def main():
@@ -904,7 +1033,7 @@ def main():
         # rocprofv3 --pmc passes of this same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950), and the line says so
         traffic, tsrc = None, None
-        for fname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for fname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
                 hit = [v for k, v in prof.items() if ("lstm_rec_kernel" in k if dom_key == "lstm_rec" else dom_key.split("_l")[0] in k.replace("::", "_"))]
@@ -942,12 +1071,22 @@ def main():
                 t1 = time.perf_counter()
                 try:
                     sections[name] = fn(mta, dev, cores, not args.no_cpu_baseline)
+                    sections.update(sections[name].pop("_extra", {}))
                 except Exception as e:                      # a section must not cost the headline line
                     import traceback
                     sections[name] = {"error": f"{type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
                 log(f"section {name}: {time.perf_counter() - t1:.1f} s")
                 torch.cuda.empty_cache()
 
+        # the LITERAL configs[1] schedule, first-class: one batch of 32 chunks per forward (3 forwards in flight; and one alone)
+        lit = (sections.get("configs1_other_schedules") or {}).get("b32_streams_3")
+        if isinstance(lit, dict) and "value" in lit:
+            sections["configs1_literal_b32"] = {
+                "workload": "CNNRNNModel inference, ONE batch of 32 chunks per forward (BASELINE.json configs[1] as written), mel + forward",
+                "value": lit["value"], "unit": "chunks/s", "ms_per_step": lit["ms_per_forward"], "streams": 3,
+                "one_in_flight": round(1e3 * B / sum(one_ms[1]), 1) if 1 in one_ms else None}
+        elif isinstance(lit, dict):
+            sections["configs1_literal_b32"] = lit
         # every kernel's fraction of its roofline in one compact object (survives a truncated log): the headline forward's stages,
         # the Large forward's and the training step's timed launches
         roofline["all"] = {s_["kernel"]: s_["frac"] for s_ in stages if s_["work_per_launch"] > 0}
@@ -955,26 +1094,26 @@ def main():
             sec_ = sections.get(sec_name)
             if isinstance(sec_, dict) and key in sec_:
                 roofline["all_" + sec_name.split("_")[1]] = {s_["kernel"]: s_["frac"] for s_ in sec_[key] if s_["work_per_launch"] > 0}
-        out = {"metric": "30 s audio chunks/sec (mel+CNNRNN forward)", "value": round(world * B * K / elapsed, 2),
-               "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f16 MFMA operands with f32 accumulate (conv2, input projections, recurrence, fc), f32 LSTM state / gates, "
-                        "f32 FFT and conv1",
-               "data": "synthetic",
-               "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
-                                      "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
-                          "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)",
-                          "coscheduled_batches_per_forward": C, "streams_per_gpu": NS, "batches_in_flight": C * NS,
-                          "forwards_in_timed_region": {f"{nb_}x{B}": sizes.count(nb_) for nb_ in sorted(set(sizes))},
-                          "scheduling": f"a step = one batch of {B} chunks; the {K} timed steps are issued as forwards over {C} batches (the recurrence interleaves "
-                                        f"their batch groups in one persistent launch), dealt round-robin over {NS} streams: "
-                                        f"{NS} forwards in flight; the batches beyond whole rounds of {NS} x {C} run as a last round of smaller forwards side by side.  One batch of {B} per forward, the literal configs[1] schedule: configs1_other_schedules.b32_streams_3",
-                          "distinct_chunks_per_forward": True,
-                          "fused_input_projection": bool(net.fuse_input_projection)},
-               "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
-               "roofline_one_batch": roofline_one_batch, "stages_one_batch": stages_one_batch,
-               "roofline_overlapped": roofline_overlapped, "stages_overlapped": stages_overlapped, **sections}
-        print(json.dumps(out))
+        detail = {"metric": "30 s audio chunks/sec (mel+CNNRNN forward)", "value": round(world * B * K / elapsed, 2),
+                  "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * elapsed / K, 3),
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                  "dtype": "f16 MFMA operands with f32 accumulate (conv2, input projections, recurrence, fc), f32 LSTM state / gates, "
+                           "f32 FFT and conv1",
+                  "data": "synthetic",
+                  "config": {"workload": "CNNRNNModel inference, batch=32x30 s synthetic 16 kHz audio, mel+CNN-RNN HIP path "
+                                         "(BASELINE.json configs[1])", "batch_per_gpu": B, "n_samples": N_SAMPLES,
+                             "n_mels": N_MELS, "hidden": HIDDEN, "layers": LAYERS, "frames": T, "parallelism": f"dp{world} (independent chunks)",
+                             "coscheduled_batches_per_forward": C, "streams_per_gpu": NS, "batches_in_flight": C * NS,
+                             "forwards_in_timed_region": {f"{nb_}x{B}": sizes.count(nb_) for nb_ in sorted(set(sizes))},
+                             "scheduling": f"a step = one batch of {B} chunks; the {K} timed steps are issued as forwards over {C} batches (the recurrence interleaves "
+                                           f"their batch groups in one persistent launch), dealt round-robin over {NS} streams: "
+                                           f"{NS} forwards in flight; the batches beyond whole rounds of {NS} x {C} run as a last round of smaller forwards side by side.  One batch of {B} per forward, the literal configs[1] schedule: configs1_literal_b32",
+                             "distinct_chunks_per_forward": True,
+                             "fused_input_projection": bool(net.fuse_input_projection)},
+                  "roofline": roofline, "cpu_baseline": cpu, "stages": stages,
+                  "roofline_one_batch": roofline_one_batch, "stages_one_batch": stages_one_batch,
+                  "roofline_overlapped": roofline_overlapped, "stages_overlapped": stages_overlapped, **sections}
+        emit(detail)
     if world > 1:
         dist.destroy_process_group()
 

@@ -164,11 +164,7 @@ template <int DT, int DP>
 static int af_launch(const bf16_t* qkv, int ld3, int Ca, const bf16_t* VT, int Tp, int dpr, int B, int T, int heads, float scale, float clip,
                      bf16_t* ao, int ldo, hipStream_t st) {
     using D = AfDims<DP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fused_kernel<DT, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, D::LDS_BYTES));
-        attr_set = true;
-    }
+    MT_SET_MAX_LDS((attn_fused_kernel<DT, DP>), D::LDS_BYTES);
     const float log2e = 1.4426950408889634f;
     hipLaunchKernelGGL((attn_fused_kernel<DT, DP>), dim3(cdiv(T, AF_WAVES * AF_QW), heads, B), dim3(512), D::LDS_BYTES, st,
                        qkv, ld3, Ca, VT, Tp, dpr, B, T, heads, scale * log2e, clip * log2e, ao, ldo);

@@ -207,11 +207,7 @@ extern "C" int mt_conv1_bn_relu_pool(const float* mel, const float* chunk_max_po
 template <int DT>
 static int conv2_launch(const void* act1, const void* w2, const float* bias, void* X0, int ldx, int B, int F1, int T, hipStream_t st) {
     const int Fo2 = F1 / 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv2_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, C2_LDS_BYTES));
-        attr_set = true;
-    }
+    MT_SET_MAX_LDS((conv2_kernel<DT>), C2_LDS_BYTES);
     const int tiles_t = cdiv(T, C2_TT), tiles_f = cdiv(Fo2, C2_TF), n_tiles = B * tiles_f * tiles_t;
     dim3 grid(n_tiles < 512 ? n_tiles : 512);          // persistent: two workgroups per CU walk the tiles
     hipLaunchKernelGGL(conv2_kernel<DT>, grid, dim3(256), C2_LDS_BYTES, st, (const bf16_t*)act1,

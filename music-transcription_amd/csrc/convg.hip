@@ -364,11 +364,7 @@ static int cg_launch(const ConvGArgs& a, hipStream_t st) {
     const size_t stage = (size_t)(POOL ? CG_TF / 2 : CG_TF) * CG_TT * BN_ * 2;       // the epilogue's output rows reuse the buffers
     if (lds < stage) lds = stage;
     MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "conv: tile needs %zu B of LDS", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)convg_kernel<KC, BN_, POOL, OUT, DT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    MT_SET_MAX_LDS((convg_kernel<KC, BN_, POOL, OUT, DT, NW>), 160 * 1024);
     const int tiles_t = cdiv(a.T, CG_TT);
     dim3 grid(tiles_t * (a.Cout / BN_), cdiv(a.F, CG_TF), a.B);
     hipLaunchKernelGGL((convg_kernel<KC, BN_, POOL, OUT, DT, NW>), grid, dim3(NW * 64), lds, st, a);
@@ -389,6 +385,10 @@ static size_t cg_lds_bytes(const ConvGArgs& a, int KC, int BN_) {
 
 template <int DT>
 static int conv_cl_dispatch(const ConvGArgs& a, int pool, int out_mode, hipStream_t st) {
+    // every entry point comes through here: the kernel stages its input through ONE buffer descriptor per chunk whose size is a
+    // 32-bit byte count -- an oversized chunk would wrap it and read hardware zeros instead of failing
+    MT_REQUIRE((long long)a.F * a.T * a.pitchA * 2 < (1ll << 31) && (long long)a.F * a.T * (a.C2 ? a.pitchS : 0) * 2 < (1ll << 31), MT_EUNSUPPORTED,
+               "mt_conv_cl: a chunk's activation must stay below 2 GB (one buffer descriptor per chunk)");
     // 64-channel weight chunks and 128-channel tiles where they apply and the tile still fits the 160 KB of LDS (a 128 + 128
     // channel input pair -- the fused input gradient of a residual block -- leaves room for 32-channel chunks only)
     // 256-channel tiles (a wave = 64 positions x 128 channels: 0.75 KB of LDS reads per MFMA instead of 1 KB -- with 64 x 64 wave tiles
@@ -432,8 +432,6 @@ extern "C" int mt_conv_cl_ex(const void* A, int pitchA, const void* S, int pitch
     MT_REQUIRE(A && W && bias && out, MT_EINVAL, "mt_conv_cl: null pointer");
     MT_REQUIRE(pitchA >= C1 && pitchA % 8 == 0 && (C2 == 0 || (pitchS >= C2 && pitchS % 8 == 0)), MT_EINVAL, "mt_conv_cl: bad position pitch");
     MT_REQUIRE_DT(dt, "mt_conv_cl");
-    MT_REQUIRE((long long)F * T * pitchA * 2 < (1ll << 31) && (long long)F * T * (C2 ? pitchS : 0) * 2 < (1ll << 31), MT_EUNSUPPORTED,
-               "mt_conv_cl: a chunk's activation must stay below 2 GB (one buffer descriptor per chunk)");
     MT_REQUIRE(B > 0 && F > 0 && T > 0 && (KH == 3 || KH == 7) && (C1 == 32 || C1 == 64 || C1 == 128) &&
                (C2 == 0 || C2 == 32 || C2 == 64 || C2 == 128) && (C2 == 0 || S) && (Cout % 64 == 0), MT_EUNSUPPORTED,
                "mt_conv_cl: unsupported shape C1=%d C2=%d Cout=%d KH=%d", C1, C2, Cout, KH);

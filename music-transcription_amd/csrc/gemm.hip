@@ -948,12 +948,8 @@ static bool persist_ok(const GemmEpi& ep, int M, int N, int K, const void* sched
 }
 template <int DT, bool AHX>
 static int launch_persist(const bf16_t* a, int lda, const bf16_t* w, int ldw, int M, int N, int K, const GemmEpi& ep, void* sched, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<DT, AHX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS));
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256p_kernel<DT, AHX, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS));
-        attr_set = true;
-    }
+    MT_SET_MAX_LDS((gemm256p_kernel<DT, AHX, 2>), GP_LDS);
+    MT_SET_MAX_LDS((gemm256p_kernel<DT, AHX, 3>), GP_LDS);
     static const int park = getenv("MT_GEMM_PARK") ? atoi(getenv("MT_GEMM_PARK")) : 2;
     const int total = cdiv(M, BM2) * (N / BN2);
     // a workgroup's lifetime ~ 0.4 ms (a K-tile takes ~1.7 us): long enough that one tile in `tpw` ends without overlap, short

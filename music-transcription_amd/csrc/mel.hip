@@ -461,11 +461,7 @@ extern "C" int mt_mel_db_f32(const void* plan, const mt_mel_desc* desc, const fl
     const size_t lds = (size_t)NWAVE * 2 * XREG * 4 + 2 * 1024 * 8 + (size_t)n_mels * 33 * 4 + (size_t)ngrp * 32 * 4 + 32 * 4 +
                        (size_t)desc->ell_rows * 32 * 4;
     MT_REQUIRE(lds <= 160 * 1024, MT_EUNSUPPORTED, "mt_mel_db_f32: n_mels=%d needs %zu B of LDS", n_mels, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)mel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    MT_SET_MAX_LDS((mel_kernel), 160 * 1024);
     MT_REQUIRE((size_t)B * n_samples * 4 < (size_t)0x7fffffff, MT_EUNSUPPORTED, "mt_mel_db_f32: B*n_samples too large for one launch (split the batch)");
     const int tiles_per_chunk = cdiv(T, FT), n_tiles = B * tiles_per_chunk;
     dim3 grid(n_tiles < 256 ? n_tiles : 256);          // persistent: one workgroup per CU walks the tiles

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/mt_hip.h"
 
 namespace mt {
@@ -25,6 +26,21 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 #define MT_CHECK_LAUNCH() MT_CHECK_HIP(hipGetLastError())
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the DEVICE's copy of the code object: once per (kernel, device), not
+// once per process (a process that drives a second GPU would otherwise launch there with > 64 KB of dynamic LDS and no attribute).
+// Two host threads may both find the bit clear: the call is idempotent.  `kernel` in parentheses when it has template commas.
+#define MT_SET_MAX_LDS(kernel, bytes)                                                                                        \
+    do {                                                                                                                    \
+        static std::atomic<unsigned long long> done_{0};                                                                    \
+        int dev_ = 0;                                                                                                       \
+        MT_CHECK_HIP(hipGetDevice(&dev_));                                                                                  \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                                \
+        if (!(done_.load(std::memory_order_acquire) & bit_)) {                                                              \
+            MT_CHECK_HIP(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            done_.fetch_or(bit_, std::memory_order_release);                                                                \
+        }                                                                                                                   \
+    } while (0)
 
 typedef unsigned short bf16_t;   // raw bf16 bits
 

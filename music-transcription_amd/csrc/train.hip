@@ -726,11 +726,7 @@ extern "C" int mt_conv2_wgrad_workgroups(void) { return 256; }
 extern "C" int mt_conv2_wgrad(const void* a1, const void* dz_hi, const void* dz_lo, float* P, float* Pb, int n_wg, int B, int F, int T,
                               mt_stream_t stream) {
     MT_REQUIRE(a1 && dz_hi && dz_lo && P && Pb && n_wg > 0 && B > 0 && F > 0 && T > 0, MT_EINVAL, "mt_conv2_wgrad: bad arguments");
-    static bool attr_set = false;
-    if (!attr_set) {
-        MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv2_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS));
-        attr_set = true;
-    }
+    MT_SET_MAX_LDS((conv2_wgrad_kernel), CW_LDS);
     hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(n_wg), dim3(CW_THREADS), CW_LDS, ST(stream), (const bf16_t*)a1, (const bf16_t*)dz_hi,
                        (const bf16_t*)dz_lo, P, Pb, B, F, T);
     MT_CHECK_LAUNCH();

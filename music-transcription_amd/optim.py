@@ -122,6 +122,15 @@ class EarlyBucket:
         return start
 
 
+def note_params_without_grad(net, no_grad) -> None:
+    """Called by a training step's backward pass with the names of the parameters it produced NO gradient for.  A parameter is
+    left out of the next optimizer step only if no backward pass since zero_grad() / step() reached it (torch.optim.Adam skips
+    `grad is None`, and a second backward that does reach the parameter makes its grad a tensor): the intersection over the
+    passes, not the union.  `net._params_without_grad is None` = no backward pass yet."""
+    prev = getattr(net, "_params_without_grad", None)
+    net._params_without_grad = set(no_grad) if prev is None else (set(prev) & set(no_grad))
+
+
 class FusedAdamClip:
     """clip_grad_norm_ + Adam (coupled L2) in libmt_hip.so over flat buffers.  step() returns a (2,) device tensor
     {grad norm before clipping, 1.0 if the step was taken / 0.0 if skipped for a non-finite norm}: no host sync."""
@@ -149,7 +158,7 @@ class FusedAdamClip:
     def zero_grad(self):
         self.g.zero_()
         if self.net is not None:
-            self.net._params_without_grad = set()
+            self.net._params_without_grad = None        # None = no backward pass since (the training step intersects)
 
     def _keep_ranges(self):
         """Ascending merged [lo, hi) ranges of the parameters that take part in this step: all of them, minus those the last
@@ -218,6 +227,6 @@ class FusedAdamClip:
                                            self.betas[1], self.eps, self.wd, self.max_norm, self.t, scale, kr, nk, ptr(self.stats),
                                            ptr(self.ws), self.ws.numel(), _lib.stream_ptr()), "mt_adam_clip_step_ex")
         if self.net is not None:
-            self.net._params_without_grad = set()
+            self.net._params_without_grad = None        # None = no backward pass since (the training step intersects)
         WEIGHTS_EPOCH[0] += 1
         return self.stats

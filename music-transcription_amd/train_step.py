@@ -106,8 +106,16 @@ class _ProfSpan:
 _SIDE = {}
 
 
+def device_key(dev) -> str:
+    """One spelling per device for the side-stream tables: 'cuda', torch.device('cuda') and 'cuda:0' are the same GPU (a tuner built
+    with the caller's device='cuda' must find the streams the step created under x.device = cuda:0)."""
+    dev = torch.device(dev)
+    idx = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    return f"{dev.type}:{idx}"
+
+
 def _side_stream(dev):
-    key = str(dev)
+    key = device_key(dev)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]

@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 from ._lib import lib, check, ptr
-from .train_step import _ru, _st, _gemm, _gather4, BN_EPS, BN_MOMENTUM
+from .train_step import _ru, _st, _gemm, _gather4, BN_EPS, BN_MOMENTUM, device_key
 
 LN_EPS, ATTN_CLIP = 1e-6, 10.0
 DROPOUT2D_P = (0.1, 0.1, 0.15)          # cnn_rnn_model.py:188,:192,:202 (hard-coded in the reference)
@@ -211,7 +211,7 @@ _SIDE2 = {}
 def _side_streams(dev):
     """Two side streams per device: (weight-gradient work of the LSTM stack, the local LSTM's own chain).  The backward
     recurrences are latency-bound on 16-32 CUs: everything that does not gate the next recurrence runs beside them."""
-    key = str(dev)
+    key = device_key(dev)
     if key not in _SIDE2:
         _SIDE2[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
     return _SIDE2[key]
@@ -225,7 +225,7 @@ def autotune_side_streams(step, dev, candidates: int = 4, steps: int = 2):
     (tools/train_large_queue_probe.py, profiles/r03_train_large_stream_mapping.txt).  Returns the seconds per step of every candidate."""
     import time
     dev = torch.device(dev)
-    key = str(dev)
+    key = device_key(dev)
     seen = []
     for _ in range(max(1, candidates)):
         _forget_side_streams(key)
@@ -263,7 +263,7 @@ class SideStreamTuner:
     serves steps [c (steps + 1), (c + 1)(steps + 1)), the first of them untimed; after the last candidate the fastest pair stays."""
 
     def __init__(self, dev, candidates: int = 4, steps: int = 2):
-        self.dev, self.key = torch.device(dev), str(torch.device(dev))
+        self.dev, self.key = torch.device(dev), device_key(dev)
         self.candidates, self.steps = max(1, candidates), max(1, steps)
         self.i, self.seen, self.acc, self.done = 0, [], 0.0, os.environ.get("MT_TRAIN_STREAM_AUTOTUNE", "1") == "0"
 
@@ -862,7 +862,10 @@ class CnnRnnLargeTrainFn(torch.autograd.Function):
         no_grad = {n for n in ctx.names if g[n] is None and n not in early}
         if ctx.frame_only:
             no_grad |= {n for n in ctx.names if n.startswith(("onset_head.", "offset_head."))}
-        ctx.model._params_without_grad = set(getattr(ctx.model, "_params_without_grad", ())) | no_grad
+        # a parameter is left out of the step only if NO backward pass since zero_grad() produced a gradient for it (two backward
+        # passes before one step: a frame-only pass and a return_all_heads pass -> the heads DO have a gradient): intersection
+        from .optim import note_params_without_grad
+        note_params_without_grad(ctx.model, no_grad)
         return (None, None, None, None, None, None, None) + tuple(g[n] for n in ctx.names)
 
 

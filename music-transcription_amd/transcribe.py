@@ -168,17 +168,36 @@ def load_audio_device(path: str, sr: int = SR, device="cuda") -> torch.Tensor:
     n_in, ch = data.shape
     if n_in == 0:
         return torch.zeros(0, dtype=torch.float32, device=device)
-    up, down, h, n_pre_remove, n_out = resample_plan(int(rate), sr, n_in)
     dev = torch.device(device)
-    key = (up, down, len(h), str(dev))
-    if key not in _PLAN_FILTERS:
-        _PLAN_FILTERS[key] = torch.from_numpy(polyphase_table(h, up)).to(dev)
-    hd = _PLAN_FILTERS[key]                              # [up][taps per phase]
     src = torch.from_numpy(np.ascontiguousarray(data)).to(dev, non_blocking=True)
+    return resample_pcm_device(src, int(rate), sr)
+
+
+_PCM_FMT = {torch.int16: 0, torch.int32: 1, torch.float32: 2}
+
+
+def resample_pcm_device(src: torch.Tensor, rate: int, sr: int = SR) -> torch.Tensor:
+    """(frames, channels) interleaved PCM ON THE DEVICE (int16 / int32 / float32, as a WAV file holds it) at `rate` -> mono
+    float32 at `sr`: channel mean, PCM scaling and polyphase resampling in one kernel (mt_resample_polyphase, csrc/resample.hip).
+    The filter table of a (rate, sr) pair is built once per device (resample_fir)."""
+    if not src.is_cuda or src.dim() != 2 or src.dtype not in _PCM_FMT:
+        raise ValueError("resample_pcm_device expects a (frames, channels) int16 / int32 / float32 CUDA tensor")
+    src = src.contiguous()
+    n_in, ch = int(src.shape[0]), int(src.shape[1])
+    dev = src.device
+    if n_in == 0:
+        return torch.zeros(0, dtype=torch.float32, device=dev)
+    pkey = (int(rate), int(sr), str(dev))
+    if pkey not in _PLAN_FILTERS:
+        # (the plan's trailing zero taps depend on n_in, the filter, `up`, `down` and n_pre_remove do not: taps beyond the table are zeros)
+        up, down, h, n_pre, _ = resample_plan(int(rate), sr, n_in)
+        _PLAN_FILTERS[pkey] = (up, down, torch.from_numpy(polyphase_table(h, up)).to(dev), n_pre)
+    up, down, hd, n_pre_remove = _PLAN_FILTERS[pkey]
+    n_out = n_in if up == down == 1 else (n_in * up + down - 1) // down
     out = torch.empty(n_out, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(_lib.lib.mt_resample_polyphase(_lib.ptr(src), n_in, ch, fmt, _lib.ptr(hd), hd.shape[1], up, down, n_pre_remove, _lib.ptr(out), n_out,
-                                                  _lib.stream_ptr()), "mt_resample_polyphase")
+        _lib.check(_lib.lib.mt_resample_polyphase(_lib.ptr(src), n_in, ch, _PCM_FMT[src.dtype], _lib.ptr(hd), hd.shape[1], up, down, n_pre_remove,
+                                                  _lib.ptr(out), n_out, _lib.stream_ptr()), "mt_resample_polyphase")
     return out
 
 

@@ -8,7 +8,9 @@ over the GPUs of one node (the training half of the reference's scripts/train_cn
 One process per GPU.  Every step is the HIP training step (train-mode forward, backward, fused clip + Adam); with more
 than one rank each rank draws its own shard of the shuffled chunk indices (DistributedSampler) and the flat gradient
 is all-reduced (mean) over RCCL before the clip, so all ranks hold identical weights.  Checkpoints are plain
-`state_dict` files `model_epoch_N.pth` that the reference's TranscriptionModel loads unchanged.  Background
+`state_dict` files that the reference's TranscriptionModel loads unchanged, under the reference's names
+(scripts/train_cnn.py:345-358): `checkpoints/model_epoch_N.pth` every --save_every epochs and after the last one,
+`checkpoints/model_best.pth` whenever the validation loss improves, `checkpoints/model_final.pth` at the end.  Background
 re-execution, run-directory bookkeeping and loss plots of the reference script are out of scope.
 """
 import argparse
@@ -37,6 +39,10 @@ def main():
     ap.add_argument("--hidden_size", type=int, default=512)
     ap.add_argument("--num_layers", type=int, default=3)
     ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--use_attention", action="store_true", default=True, help="attention block (cnn_rnn_large only)")
+    ap.add_argument("--no_attention", action="store_false", dest="use_attention")
+    ap.add_argument("--use_onset_offset_heads", action="store_true", default=True, help="onset / offset heads (cnn_rnn_large only)")
+    ap.add_argument("--no_onset_offset_heads", action="store_false", dest="use_onset_offset_heads")
     ap.add_argument("--run_dir", default="outputs/train_cnn")
     ap.add_argument("--num_workers", type=int, default=4)
     ap.add_argument("--seed", type=int, default=0)
@@ -60,8 +66,8 @@ def main():
     import music_transcription_amd as mta
     from music_transcription_amd import train as T
 
-    if args.model not in ("cnn_rnn", "cnn+rnn"):
-        raise SystemExit("training kernels exist for model=cnn_rnn (CNNRNNModelLarge: inference only so far)")
+    if args.model not in ("cnn_rnn", "cnn+rnn", "cnn_rnn_large", "large"):
+        raise SystemExit(f"model={args.model}: the HIP training step exists for cnn_rnn and cnn_rnn_large")
     torch.manual_seed(args.seed)                       # same initial weights on every rank
     train_ds = mta.CachedMaestroDataset(args.cached_dir, "train")
     val_ds = mta.CachedMaestroDataset(args.cached_dir, "validation")
@@ -74,7 +80,8 @@ def main():
     val_loader = DataLoader(val_ds, batch_size=args.batch_size, shuffle=False, **kw)
 
     model = mta.TranscriptionModel(model_type=args.model, n_mels=args.n_mels, hidden_size=args.hidden_size, num_layers=args.num_layers,
-                                   dropout=args.dropout, device=str(dev))
+                                   dropout=args.dropout, device=str(dev), use_attention=args.use_attention,
+                                   use_onset_offset_heads=args.use_onset_offset_heads)
     start_epoch = args.start_epoch
     if args.resume:
         model.load_state_dict(torch.load(args.resume, map_location=dev))
@@ -86,6 +93,12 @@ def main():
     if rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)
     history = []
+    best_val_loss = float("inf")
+
+    def save(name):                                    # plain state_dict with the reference's keys (rank 0 only)
+        path = os.path.join(ckpt_dir, name)
+        torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path)
+        return path
     for epoch in range(start_epoch, args.epochs + 1):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -100,10 +113,15 @@ def main():
             history.append(rec)
             print(json.dumps(rec), flush=True)
             if epoch % args.save_every == 0 or epoch == args.epochs:
-                torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, os.path.join(ckpt_dir, f"model_epoch_{epoch}.pth"))
+                print(f"Checkpoint saved to {save(f'model_epoch_{epoch}.pth')}", flush=True)
+            if val_loss < best_val_loss:               # best model = lowest validation loss (reference scripts/train_cnn.py:349-354)
+                best_val_loss = val_loss
+                save("model_best.pth")
+                print(f"New best model saved! Val loss: {val_loss:.4f}", flush=True)
         if world > 1:
             dist.barrier()
     if rank == 0:
+        print(f"Final model saved to {save('model_final.pth')}", flush=True)       # reference scripts/train_cnn.py:180,:357
         with open(os.path.join(args.run_dir, "history.json"), "w") as f:
             json.dump(history, f)
     if world > 1:

@@ -239,3 +239,57 @@ def test_large_canonical_vs_reference_golden(mta, golden_dir):
     for k, key in (("frame", f"{tag}_sample"), ("onset", f"{tag}_onset_sample"), ("offset", f"{tag}_offset_sample")):
         err = np.abs(d[k].cpu().numpy()[:, ::5, ::7] - c[key]).max()
         assert err < 3e-2, (k, err)
+
+
+# ------------------------------------------------------------------ BASELINE configs[4] at the model's full size
+CORPUS_LOGIT_TOL = 0.06      # 3 x the largest |dlogit| the f16 path shows against fp32 at this size and weight scale (0.020 of 15)
+
+
+def test_corpus_shard_full_size_large_matches_oracle_pipeline(mta):
+    """corpus.transcribe_shard -- slab assembly ACROSS recordings, three slabs on two streams, logits held per slab, notes and F1 on
+    the device -- with CNNRNNModelLarge 320/512/3 (main.py:16-20's model) on two recordings / five 30 s chunks, against the oracle
+    pipeline of main.py:60-100 (chunking), :103-130 (mel per chunk), the fp32 model, :153-159 (threshold), :164-186 (concatenation),
+    :189-226 (notes): the rolls are equal except cells whose fp32 logit is within CORPUS_LOGIT_TOL of the threshold, and the notes
+    are the reference's run-length over that roll."""
+    from oracle import frontend_ref as FR
+    from music_transcription_amd import corpus
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    durs = [41.0, 65.0]                                                # 2 + 3 chunks; both last chunks zero-padded in the waveform domain
+    waves = [FR.synth_audio(1, int(16000 * d), seed=70 + i)[0] for i, d in enumerate(durs)]
+    chunks = []
+    for w in waves:
+        n = -(-len(w) // 480000)
+        c = np.zeros(n * 480000, np.float32); c[:len(w)] = w
+        chunks.append(c.reshape(n, 480000))
+    mel_ref = torch.from_numpy(np.concatenate([FR.audio_to_mel(c, 16000, 320, 512)[None] for rec in chunks for c in rec]))   # batch-1 clamp per chunk
+    mel_ref = mel_ref.reshape(5, 1, 320, 938)
+    sd0 = R.make_state_dict("cnn_rnn_large", 320, 512, 3, seed=11)
+    sd, _ = R.trained_scale_state_dict(sd0, "cnn_rnn_large", mel_ref[:1])
+    with torch.no_grad():
+        ref = R.forward(sd, mel_ref, "cnn_rnn_large", o=R.Opts(fast_lstm=True))     # fp32 (eval-mode BatchNorm: batch-independent)
+    model = mta.TranscriptionModel("cnn_rnn_large", n_mels=320, hidden_size=512, num_layers=3, device="cuda").eval()
+    model.load_state_dict(sd, strict=True)
+    dev_chunks = {i: torch.from_numpy(c).cuda() for i, c in enumerate(chunks)}
+    g = torch.Generator().manual_seed(5)
+    truth = {i: (torch.rand(88, len(c) * 938, generator=g) < 0.05).float() for i, c in enumerate(chunks)}
+    res = corpus.transcribe_shard(model, [0, 1], lambda i: dev_chunks[i], n_mels=320, device="cuda", batch=2, streams=2, threshold=0.5,
+                                  want_notes=True, reference_roll_of=lambda i, T_total: truth[i].cuda())
+    assert res["chunks"] == 5 and res["slabs"] == 3 and res["finite"] and res["chunks_per_recording"] == {0: 2, 1: 3}
+    fs, a, flips = 16000 / 512, 0, 0
+    for i, rec in enumerate(chunks):
+        n = len(rec)
+        lg = ref[a:a + n].permute(1, 0, 2).reshape(88, n * 938).numpy()
+        want = (lg > 0).astype(np.uint8)                                  # sigmoid(x) > 0.5
+        got = np.zeros_like(want)
+        for p, s, e in res["notes"][i]:
+            got[p - 21, int(round(s * fs)):int(round(e * fs))] = 1
+        bad = got != want
+        flips += int(bad.sum())
+        assert bad.mean() < 5e-3 and want.sum() > 1000, (i, bad.mean(), want.sum())
+        assert np.abs(lg[bad]).max(initial=0.0) < CORPUS_LOGIT_TOL, (i, np.abs(lg[bad]).max())     # only cells at the threshold may differ
+        assert res["notes"][i] == R.pianoroll_to_notes(got, fs) and len(res["notes"][i]) > 50                # the reference's run-length, note for note
+        if not bad.any():
+            assert res["notes"][i] == R.pianoroll_to_notes(want, fs)
+        assert abs(res["f1"][i] - R.f1_binary(truth[i].numpy(), got)) < 1e-9
+        a += n
+    print(f"\n[corpus full size] cells flipped against the fp32 oracle: {flips} of {88 * 5 * 938}")

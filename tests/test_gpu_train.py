@@ -130,6 +130,24 @@ def test_train_step_matches_reference_golden(mta, golden_dir):
             assert int(sd[k[len("bn0::"):]]) == int(g[k])
 
 
+# Adam's first steps are ~lr * sign(g) per element, so an element whose gradient is small against the 16-bit rounding of the
+# backward pass may step the other way: the per-tensor cosine of the UPDATE is lower than the gradient's.  0.0 = did not move.
+UPDATE_COS_ALL, UPDATE_COS_TENSOR = 0.95, 0.80
+
+
+def _update_cosines(post_ref, sd_got, sd_init):
+    """{tensor: cos(got - w0, want - w0)}, and the cosine over all tensors together."""
+    out, num, na, nb = {}, 0.0, 0.0, 0.0
+    for name, want in post_ref.items():
+        w0 = sd_init[name].double().numpy().ravel()
+        da = sd_got[name].detach().double().cpu().numpy().ravel() - w0
+        db = np.asarray(want, dtype=np.float64).ravel() - w0
+        d = float(np.linalg.norm(da) * np.linalg.norm(db))
+        out[name] = float(da @ db) / d if d > 0 else 0.0
+        num += float(da @ db); na += float(da @ da); nb += float(db @ db)
+    return out, (num / np.sqrt(na * nb) if na > 0 and nb > 0 else 0.0)
+
+
 def test_training_loop_matches_reference_losses(mta, golden_dir):
     """train_one_epoch of this package (NaN guards, clip 1.0, Adam) over the golden's 3 batches."""
     g = np.load(os.path.join(golden_dir, "train_step.npz"))
@@ -150,6 +168,13 @@ def test_training_loop_matches_reference_losses(mta, golden_dir):
         a, b = sd[name].float().cpu().numpy(), g[k]
         # 3 Adam steps of lr move a weight by <= 3 lr: agreement to a fraction of that
         assert np.abs(a - b).max() <= 3.2 * float(g["lr"]) + 2e-3 * np.abs(b).max(), name
+    # ... and the model MOVED the way the reference's did (the bound above alone would pass for weights that never changed): the
+    # update (post - initial) against the reference's own, per tensor and over all of them
+    sd0 = R.make_state_dict("cnn_rnn", nm, H, L, sw)
+    cos_t, cos_all = _update_cosines({k[len("post::"):]: g[k] for k in g.files if k.startswith("post::") and "num_batches" not in k and "running_" not in k
+                                      and k[len("post::model."):] not in ZERO_GRAD_KEYS}, sd, sd0)
+    print("\n[update direction, CNNRNNModel] all=%.4f worst: " % cos_all + ", ".join(f"{k.replace('model.', '')}={v:.3f}" for k, v in sorted(cos_t.items(), key=lambda kv: kv[1])[:5]))
+    assert cos_all >= UPDATE_COS_ALL and min(cos_t.values()) >= UPDATE_COS_TENSOR, (cos_all, {k: v for k, v in cos_t.items() if v < UPDATE_COS_TENSOR})
 
 
 def test_eval_after_training_uses_updated_weights(mta, golden_dir):
@@ -203,9 +228,41 @@ def test_train_cnn_script_two_epochs(mta, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     hist = json.load(open(os.path.join(run, "history.json")))
     assert len(hist) == 3 and hist[-1]["train_loss"] < hist[0]["train_loss"]
-    ck = torch.load(os.path.join(run, "checkpoints", "model_epoch_3.pth"))
+    # the reference's three checkpoint names (scripts/train_cnn.py:345-358), each a plain state_dict with the reference's keys
     man = R.make_state_dict("cnn_rnn", nm, 16, 2, 0)
-    assert set(ck) == set(man) and all(ck[k].shape == man[k].shape for k in man)
+    cks = {}
+    for name in ("model_epoch_3.pth", "model_best.pth", "model_final.pth"):
+        ck = cks[name] = torch.load(os.path.join(run, "checkpoints", name))
+        assert set(ck) == set(man) and all(ck[k].shape == man[k].shape and ck[k].device.type == "cpu" for k in man), name
+    assert all(torch.equal(cks["model_final.pth"][k], cks["model_epoch_3.pth"][k]) for k in man)      # final = the last epoch's weights
+    best_epoch = min(hist, key=lambda h: h["val_loss"])["epoch"]                                      # best = lowest validation loss
+    assert "New best model saved" in r.stdout and (best_epoch == 3) == all(torch.equal(cks["model_best.pth"][k], cks["model_final.pth"][k]) for k in man)
+    # scripts/evaluate.py --headless on that checkpoint: exactly one line, EVAL_MEAN_F1=<the oracle's mean framewise F1>
+    e = subprocess.run([sys.executable, os.path.join(root, "scripts", "evaluate.py"), "--model", os.path.join(run, "checkpoints", "model_best.pth"),
+                        "--cache_dir", cache, "--split", "validation", "--model_type", "cnn_rnn", "--hidden_size", "16", "--num_layers", "2",
+                        "--threshold", "0.3", "--headless"], capture_output=True, text=True, timeout=300)
+    assert e.returncode == 0, e.stderr[-2000:]
+    out = e.stdout.strip().splitlines()
+    assert len(out) == 1 and out[0].startswith("EVAL_MEAN_F1=") and len(out[0].split("=")[1].split(".")[1]) == 6, e.stdout
+    sd = cks["model_best.pth"]
+    ds = mta.CachedMaestroDataset(cache, "validation")
+    f1s, near = [], 0
+    for i in range(len(ds)):
+        mel, roll = ds[i]
+        with torch.no_grad():
+            lg = R.cnnrnn_forward(sd, mel[None])
+        near += int(((lg - float(np.log(0.3 / 0.7))).abs() < 3e-2).sum())
+        f1s.append(R.f1_binary(roll.numpy(), R.predict(lg, 0.3)[0].numpy()))
+    got = float(out[0].split("=")[1])
+    # (cells whose fp32 logit sits within the f16 path's tolerance of the threshold may fall on either side)
+    assert abs(got - float(np.mean(f1s))) <= (1e-6 if near == 0 else 0.02), (got, float(np.mean(f1s)), near)
+    from music_transcription_amd import evaluate as E                                               # the library call behind the script: same number
+    hm = mta.TranscriptionModel("cnn_rnn", n_mels=nm, hidden_size=16, num_layers=2, device="cuda").eval()
+    hm.load_state_dict(sd)
+    assert abs(E.evaluate_dataset(hm, ds, 0.3, "cuda")[0] - got) < 1e-6
+    e2 = subprocess.run([sys.executable, os.path.join(root, "scripts", "evaluate.py"), "--model", str(tmp_path / "missing.pth"), "--cache_dir", cache,
+                         "--headless"], capture_output=True, text=True, timeout=120)
+    assert e2.returncode == 1 and "not found" in e2.stdout
 
 
 @pytest.mark.parametrize("nm,H,L,B,T", [(40, 32, 3, 2, 33), (64, 48, 2, 5, 21), (32, 24, 1, 34, 12),

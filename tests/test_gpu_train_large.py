@@ -7,6 +7,7 @@ attention softmax backward with the clamp, LayerNorm backward) against torch aut
 Tolerances as tests/test_gpu_train.py: GEMM / conv operands are bf16 (f32 accumulate), so a gradient tensor is compared
 relative to its own largest entry and the whole flat gradient by its cosine to the reference."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -434,6 +435,14 @@ def test_large_training_loop_matches_reference_losses(mta, golden_dir):
             assert np.array_equal(got, want), name                          # ... and neither did the fused optimizer
         else:
             assert np.abs(got - want).max() <= 2.0 * nsteps * lr + 1e-7, (name, float(np.abs(got - want).max()))
+    # ... and every trained tensor MOVED the way the reference's did (the bound above alone passes for weights that never changed)
+    from test_gpu_train import _update_cosines, UPDATE_COS_ALL, UPDATE_COS_TENSOR
+    cos_t, cos_all = _update_cosines({k[len("post::"):]: g[k] for k in g.files if k.startswith("post::") and "running_" not in k and "num_batches" not in k
+                                      and "onset_head" not in k and "offset_head" not in k
+                                      # (convolution biases in front of a BatchNorm: analytically zero gradient, Adam turns rounding noise into steps)
+                                      and not re.search(r"(conv1\.0|freq_aware_conv\.0|res_block\d\.(conv1|conv2|skip\.0))\.bias$", k)}, sdm, sd0)
+    print("\n[update direction, CNNRNNModelLarge] all=%.4f worst: " % cos_all + ", ".join(f"{k.replace('model.', '')}={v:.3f}" for k, v in sorted(cos_t.items(), key=lambda kv: kv[1])[:6]))
+    assert cos_all >= UPDATE_COS_ALL and min(cos_t.values()) >= UPDATE_COS_TENSOR, (cos_all, {k: v for k, v in cos_t.items() if v < UPDATE_COS_TENSOR})
     # the packed inference weights follow the optimizer, and eval mode agrees with the oracle on the trained weights
     m.eval()
     with torch.no_grad():

@@ -345,7 +345,7 @@ def test_side_stream_tuner_keeps_the_fastest_candidate(mta, monkeypatch):
     made = []
 
     def fake_pair(dev):
-        key = str(dev)
+        key = train_step.device_key(dev)
         if key not in TL._SIDE2:
             made.append(("pair", len(made)))
             TL._SIDE2[key] = made[-1]
@@ -365,7 +365,7 @@ def test_side_stream_tuner_keeps_the_fastest_candidate(mta, monkeypatch):
         clock[0] += 100.0 if (not tuner.done and i % 3 == 0) else (cost[c] if c is not None else 1.0)   # first step of a candidate: warm-up, any length
         tuner.step_end()
     assert tuner.done and [round(t, 6) for t, _ in tuner.seen] == [5.0, 3.0, 4.0]
-    assert TL._SIDE2["cpu"] == ("pair", 1) and train_step._SIDE["cpu"] == ("single", 1)
+    assert TL._SIDE2["cpu:0"] == ("pair", 1) and train_step._SIDE["cpu:0"] == ("single", 1)
     n = len(made)
     tuner.step_begin(); tuner.step_end()               # quiet afterwards: no further candidates
     assert len(made) == n == 3
@@ -373,3 +373,84 @@ def test_side_stream_tuner_keeps_the_fastest_candidate(mta, monkeypatch):
     off = TL.SideStreamTuner("cpu")
     monkeypatch.setenv("MT_TRAIN_STREAM_AUTOTUNE", "0")
     assert TL.SideStreamTuner("cpu").done and not off.done
+
+
+def test_bench_compact_line_survives_a_bounded_tail():
+    """bench.py's LAST stdout line is the driver's record: round 3's full record (21.7 KB, kept as profiles/r03_bench_default_line.json)
+    must compact to <= 4 KB with the contract's fields, and must still parse when only the last 8 KB of stdout + stderr are kept."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_default_line.json")))
+    full["configs1_literal_b32"] = {"workload": "x", "value": 7568.05, "unit": "chunks/s", "ms_per_step": 4.228, "streams": 3, "one_in_flight": 4990.0}
+    full["configs4_corpus_from_pcm"] = dict(full["configs4_corpus"], value=1500.0, wall_s=1.66)
+    line = bench.compact_line(full)
+    assert len(line) <= bench.LINE_LIMIT == 4096 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["metric"] == full["metric"] and d["dtype"] == "f16" and set(d["config"]) >= {"workload", "batch_per_gpu"}
+    rf = d["roofline"]
+    assert {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "all"} <= set(rf) and rf["bound"] in ("hbm", "mfma")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and len(rf["all"]) >= 9
+    assert {"value", "unit", "cores", "kind"} <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    assert d["configs1_literal_b32"]["value"] == 7568.05 and d["configs1_literal_b32"]["streams"] == 3
+    assert set(d["sections"]) == {"configs2_large_b16", "configs3_train_b16", "train_large_b16", "configs4_corpus", "configs4_corpus_from_pcm"}
+    for o in d["sections"].values():
+        assert o["value"] > 0 and ("ms_per_step" in o or "wall_s" in o)
+    # the way the record's tail is cut: last 8 KB of everything the process wrote, the line is the last one that starts with '{'
+    noise = "".join(f"[bench] section {i}: 1.0 s\n" for i in range(400))
+    tail = (noise + line + "\n")[-8192:]
+    last = [l for l in tail.splitlines() if l.startswith("{")][-1]
+    assert json.loads(last) == d
+    # a pathological record (huge stage maps) still comes out under the limit, contract fields intact
+    full["roofline"]["all_large"] = {f"kernel_number_{i}": 0.123456 for i in range(400)}
+    line2 = bench.compact_line(full)
+    d2 = json.loads(line2)
+    assert len(line2) <= 4096 and d2["value"] == full["value"] and d2["roofline"]["frac"] == rf["frac"] and "cpu_baseline" in d2
+
+
+def test_side_stream_tables_use_one_key_per_device(mta):
+    """a tuner built with the caller's device='cuda' must forget / restore the streams the step created under
+    x.device = cuda:0 (the tables were keyed by str(device): 'cuda' != 'cuda:0' and the tuner measured one pair four times)."""
+    from music_transcription_amd import train_step, train_step_large as L
+    assert train_step.device_key("cuda") == train_step.device_key(torch.device("cuda")) == train_step.device_key("cuda:0") == "cuda:0"
+    assert train_step.device_key(torch.device("cuda", 3)) == "cuda:3"
+    tuner = L.SideStreamTuner("cuda", candidates=2, steps=1)
+    assert tuner.key == "cuda:0"
+    a, b = object(), object()
+    L._SIDE2["cuda:0"], train_step._SIDE["cuda:0"] = (a, a), b          # what a step on cuda:0 creates
+    try:
+        saved = L._current_side_streams(tuner.key)
+        assert saved == ((a, a), b)
+        L._forget_side_streams(tuner.key)
+        assert "cuda:0" not in L._SIDE2 and "cuda:0" not in train_step._SIDE
+        L._restore_side_streams(tuner.key, saved)
+        assert L._SIDE2["cuda:0"] == (a, a) and train_step._SIDE["cuda:0"] is b
+    finally:
+        L._SIDE2.pop("cuda:0", None); train_step._SIDE.pop("cuda:0", None)
+
+
+def test_params_without_grad_is_an_intersection_over_backward_passes(mta):
+    """two backward passes before one optimizer step (a frame-only pass, then a return_all_heads pass): the onset /
+    offset heads received a gradient in the second, so the fused step must NOT skip them (torch.optim.Adam would update them)."""
+    from music_transcription_amd.optim import FusedAdamClip, note_params_without_grad
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.body, self.onset_head = torch.nn.Linear(3, 2), torch.nn.Linear(2, 2)
+    net = Net()
+    opt = FusedAdamClip.__new__(FusedAdamClip)                         # (host logic only: no device buffers)
+    views, off = [], 0
+    for _, p in net.named_parameters():
+        views.append((p, off, p.numel())); off += p.numel()
+    opt._views, opt.net, opt.skip_untouched = views, net, True
+    net._params_without_grad = None
+    assert opt._keep_ranges() is None                                  # no backward yet: everything takes part
+    heads = {"onset_head.weight", "onset_head.bias"}
+    note_params_without_grad(net, heads)                               # frame-only backward
+    assert opt._keep_ranges() == [[0, 8]]                              # body only (6 + 2 values)
+    note_params_without_grad(net, set())                               # second backward reaches the heads
+    assert net._params_without_grad == set() and opt._keep_ranges() is None
+    net._params_without_grad = None
+    note_params_without_grad(net, heads); note_params_without_grad(net, heads)     # two frame-only passes: still skipped
+    assert opt._keep_ranges() == [[0, 8]]
