@@ -8,6 +8,7 @@
 // = 56 taps at 44.1 -> 16 kHz), the filter in LDS when it fits; 20 h of 44.1 kHz stereo is 64 GFLOP: the kernel is
 // bound by reading the PCM once (HBM), the point is that decode no longer costs host seconds per recording.
 #include "mt_common.h"
+#include <stdlib.h>
 
 namespace mt {
 
@@ -73,18 +74,98 @@ __global__ __launch_bounds__(256) void resample_polyphase_kernel(const void* __r
     }
 }
 
+// Round 4: the same sum, tiled.  Outputs j and j + up have the SAME filter phase and input windows exactly `down` frames apart, so a wave takes
+// 64 outputs j = j0 + up * m (m = lane): its taps are wave-uniform (scalar loads: no vector-memory traffic for the filter at all) and its inputs are
+// xs[off0 + down * lane - k] of an LDS image of the tile's input window -- channel mean and PCM scaling done ONCE per input frame while staging,
+// where the thread-per-output kernel redid them for each of a frame's ~180 uses, and (with `down` odd) bank-conflict free.  A 16-wave workgroup
+// takes P = min(up, 16) consecutive phases x MW = 1024 / P values of m: consecutive phases are consecutive output samples, so the tile's results
+// go back through LDS and leave as runs of P consecutive floats.  Per tap: one ds_read_b32 + one v_fmac with a scalar operand.
+// 44.1 -> 16 kHz: window (MW - 1) * 441 + 495 + 42 = 28.3 k frames = 113 KB of LDS, read once per 1024 outputs.
+constexpr int RT_THREADS = 1024;
+
+template <int FMT>
+__global__ __launch_bounds__(RT_THREADS) void resample_tiled_kernel(const void* __restrict__ src, long long n_in, int channels,
+                                                                    const float* __restrict__ hp, int L, int up, int down, long long n_pre_remove,
+                                                                    float* __restrict__ out, long long n_out, int P, int W, int n_mblk) {
+    extern __shared__ float xs[];                          // [W] input window, then [MW][P] results
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int MW = RT_THREADS / P;
+    const int qb = blockIdx.x / n_mblk, mb = blockIdx.x - qb * n_mblk;
+    const int q0 = qb * P;
+    const long long m0 = (long long)mb * MW;
+    // the tile's lowest input frame: output j_min = q0 + up * m0
+    const long long c_min = ((long long)q0 + n_pre_remove) * down;          // + up * down * m0, taken out so that the quotient stays exact
+    const long long base = c_min / up + (long long)down * m0 - (L - 1);
+    for (int idx = tid; idx < W; idx += RT_THREADS) {
+        const long long i = base + idx;
+        xs[idx] = (i >= 0 && i < n_in) ? load_mono<FMT>(src, i, channels) : 0.0f;
+    }
+    __syncthreads();
+    const int q = wv % P, ml = (wv / P) * 64 + lane;                        // this wave's phase, this lane's m
+    const bool q_ok = q0 + q < up;
+    const long long cq = ((long long)(q0 + q) + n_pre_remove) * down;
+    const long long iq = cq / up;
+    const int ph = __builtin_amdgcn_readfirstlane((int)(cq - iq * up));     // wave-uniform
+    const int off = (int)(iq + (long long)down * (m0 + ml) - base);         // xs index of x[i_hi]
+    const float* __restrict__ row = hp + (size_t)ph * L;
+    float acc = 0.0f;
+    if (q_ok) {
+        int k = 0;
+        for (; k + 8 <= L; k += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fmaf(xs[off - k - u], row[k + u], acc);
+        }
+        for (; k < L; ++k) acc = fmaf(xs[off - k], row[k], acc);
+    }
+    __syncthreads();                                                        // every wave is done with the window
+    xs[ml * P + q] = acc;
+    __syncthreads();
+    for (int idx = tid; idx < RT_THREADS; idx += RT_THREADS) {              // runs of P consecutive output samples
+        const int m = idx / P, qq = idx - m * P;
+        const long long j = (long long)q0 + qq + (long long)up * (m0 + m);
+        if (q0 + qq < up && j < n_out) out[j] = xs[idx];
+    }
+}
+
 }  // namespace mt
 
 using namespace mt;
+
+// tile geometry of resample_tiled_kernel for a rate pair; W = 0: does not fit (the thread-per-output kernel takes over)
+static void resample_tile_plan(int L, int up, int down, int* P, int* W) {
+    *P = up < 16 ? up : 16;
+    while (RT_THREADS % *P) --*P;                                           // MW = 1024 / P whole waves: P in {1, 2, 4, 8, 16}
+    const int MW = RT_THREADS / *P;
+    const long long w = (long long)(MW - 1) * down + ((long long)(*P - 1) * down) / up + 2 + L;
+    *W = (w <= 38 * 1024 && w >= RT_THREADS) ? (int)w : 0;
+}
 
 extern "C" int mt_resample_polyphase(const void* src, long long n_in, int channels, int fmt, const float* hp, int taps_per_phase, int up, int down,
                                      long long n_pre_remove, float* out, long long n_out, mt_stream_t stream) {
     MT_REQUIRE(src && hp && out && n_in > 0 && n_out > 0 && channels > 0 && channels <= 8 && taps_per_phase > 0 && up > 0 && down > 0 && n_pre_remove >= 0,
                MT_EINVAL, "mt_resample_polyphase: bad arguments");
     MT_REQUIRE(fmt >= 0 && fmt <= 2, MT_EINVAL, "mt_resample_polyphase: fmt must be 0 (int16), 1 (int32) or 2 (float32)");
+    hipStream_t st = (hipStream_t)stream;
+    int P = 0, W = 0;
+    resample_tile_plan(taps_per_phase, up, down, &P, &W);
+    static const bool no_tiles = getenv("MT_RESAMPLE_TILED") && atoi(getenv("MT_RESAMPLE_TILED")) == 0;
+    const long long n_m = (n_out + up - 1) / up, n_mblk = (n_m + RT_THREADS / P - 1) / (RT_THREADS / P), n_qblk = (up + P - 1) / P;
+    if (W && !no_tiles && n_out >= 4096 && n_mblk * n_qblk < (1ll << 31)) {
+        const size_t lds = (size_t)W * sizeof(float);
+        const dim3 grid((unsigned)(n_mblk * n_qblk));
+#define RT_LAUNCH(F)                                                                                                              \
+        do {                                                                                                                      \
+            MT_SET_MAX_LDS((resample_tiled_kernel<F>), 160 * 1024);                                                               \
+            hipLaunchKernelGGL(resample_tiled_kernel<F>, grid, dim3(RT_THREADS), lds, st, src, n_in, channels, hp, taps_per_phase, up, down, \
+                               n_pre_remove, out, n_out, P, W, (int)n_mblk);                                                      \
+        } while (0)
+        if (fmt == 0) RT_LAUNCH(0); else if (fmt == 1) RT_LAUNCH(1); else RT_LAUNCH(2);
+#undef RT_LAUNCH
+        MT_CHECK_LAUNCH();
+        return MT_OK;
+    }
     long long g = (n_out + 255) / 256;
     if (g > 16384) g = 16384;
-    hipStream_t st = (hipStream_t)stream;
     if (fmt == 0) hipLaunchKernelGGL(resample_polyphase_kernel<0>, dim3((unsigned)g), dim3(256), 0, st, src, n_in, channels, hp, taps_per_phase, up, down, n_pre_remove, out, n_out);
     else if (fmt == 1) hipLaunchKernelGGL(resample_polyphase_kernel<1>, dim3((unsigned)g), dim3(256), 0, st, src, n_in, channels, hp, taps_per_phase, up, down, n_pre_remove, out, n_out);
     else hipLaunchKernelGGL(resample_polyphase_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, src, n_in, channels, hp, taps_per_phase, up, down, n_pre_remove, out, n_out);

@@ -242,15 +242,22 @@ def test_large_canonical_vs_reference_golden(mta, golden_dir):
 
 
 # ------------------------------------------------------------------ BASELINE configs[4] at the model's full size
-CORPUS_LOGIT_TOL = 0.06      # 3 x the largest |dlogit| the f16 path shows against fp32 at this size and weight scale (0.020 of 15)
+CORPUS_LOGIT_TOL = 0.06        # full chunks vs fp32: 3 x the largest |dlogit| the f16 path shows at this size and weight scale (0.020 of 15)
+CORPUS_LOGIT_TOL_TAIL = 0.15   # zero-padded tail chunks vs fp32: the clamp floor (max - 80 dB, one constant over the silent part) rounds to f16 as ONE
+                               # systematic offset, not as noise: the oracle with the same f16 rounding points is itself 0.09 - 0.12 from fp32 there
+                               # (0.013 on full chunks), worst flipped cell 0.043 from the threshold
+CORPUS_LOGIT_TOL_EMU = 0.01    # every chunk vs the oracle with the HIP path's f16 rounding points (the mel differs by <= 5e-2 dB between the two)
 
 
 def test_corpus_shard_full_size_large_matches_oracle_pipeline(mta):
     """corpus.transcribe_shard -- slab assembly ACROSS recordings, three slabs on two streams, logits held per slab, notes and F1 on
     the device -- with CNNRNNModelLarge 320/512/3 (main.py:16-20's model) on two recordings / five 30 s chunks, against the oracle
-    pipeline of main.py:60-100 (chunking), :103-130 (mel per chunk), the fp32 model, :153-159 (threshold), :164-186 (concatenation),
-    :189-226 (notes): the rolls are equal except cells whose fp32 logit is within CORPUS_LOGIT_TOL of the threshold, and the notes
-    are the reference's run-length over that roll."""
+    pipeline of main.py:60-100 (chunking), :103-130 (mel per chunk), the model, :153-159 (threshold), :164-186 (concatenation),
+    :189-226 (notes): the rolls are equal except cells whose oracle logit is within the stated tolerance of the threshold -- against
+    the fp32 oracle and against the oracle with the f16 rounding points -- and the notes are the reference's run-length over that
+    roll.  Weights: trained-scale logits (N(-5, 3), ~5 % active cells) with the recurrence gain left at 1: with W_hh x 3 the silent
+    tail of a zero-padded chunk is a chaotic regime in which the f16-emulating ORACLE is 0.8 - 1.4 away from fp32 (measured), i.e. no
+    statement about the kernels could be made there."""
     from oracle import frontend_ref as FR
     from music_transcription_amd import corpus
     torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
@@ -264,9 +271,10 @@ def test_corpus_shard_full_size_large_matches_oracle_pipeline(mta):
     mel_ref = torch.from_numpy(np.concatenate([FR.audio_to_mel(c, 16000, 320, 512)[None] for rec in chunks for c in rec]))   # batch-1 clamp per chunk
     mel_ref = mel_ref.reshape(5, 1, 320, 938)
     sd0 = R.make_state_dict("cnn_rnn_large", 320, 512, 3, seed=11)
-    sd, _ = R.trained_scale_state_dict(sd0, "cnn_rnn_large", mel_ref[:1])
+    sd, _ = R.trained_scale_state_dict(sd0, "cnn_rnn_large", mel_ref[:1], w_hh_gain=1.0)
     with torch.no_grad():
         ref = R.forward(sd, mel_ref, "cnn_rnn_large", o=R.Opts(fast_lstm=True))     # fp32 (eval-mode BatchNorm: batch-independent)
+        emu = R.forward(sd, mel_ref, "cnn_rnn_large", o=R.Opts(gemm_f16=True))      # the HIP path's rounding points
     model = mta.TranscriptionModel("cnn_rnn_large", n_mels=320, hidden_size=512, num_layers=3, device="cuda").eval()
     model.load_state_dict(sd, strict=True)
     dev_chunks = {i: torch.from_numpy(c).cuda() for i, c in enumerate(chunks)}
@@ -275,21 +283,25 @@ def test_corpus_shard_full_size_large_matches_oracle_pipeline(mta):
     res = corpus.transcribe_shard(model, [0, 1], lambda i: dev_chunks[i], n_mels=320, device="cuda", batch=2, streams=2, threshold=0.5,
                                   want_notes=True, reference_roll_of=lambda i, T_total: truth[i].cuda())
     assert res["chunks"] == 5 and res["slabs"] == 3 and res["finite"] and res["chunks_per_recording"] == {0: 2, 1: 3}
-    fs, a, flips = 16000 / 512, 0, 0
+    fs, a, flips = 16000 / 512, 0, [0, 0]
     for i, rec in enumerate(chunks):
         n = len(rec)
-        lg = ref[a:a + n].permute(1, 0, 2).reshape(88, n * 938).numpy()
+        flat = lambda x: x[a:a + n].permute(1, 0, 2).reshape(88, n * 938).numpy()
+        lg, lge = flat(ref), flat(emu)
         want = (lg > 0).astype(np.uint8)                                  # sigmoid(x) > 0.5
         got = np.zeros_like(want)
         for p, s, e in res["notes"][i]:
             got[p - 21, int(round(s * fs)):int(round(e * fs))] = 1
-        bad = got != want
-        flips += int(bad.sum())
+        tol = np.full(n * 938, CORPUS_LOGIT_TOL, np.float32)
+        tol[(n - 1) * 938:] = CORPUS_LOGIT_TOL_TAIL                       # the recording's last chunk is the zero-padded one
+        bad, bad_e = got != want, got != (lge > 0)
+        flips[0] += int(bad.sum()); flips[1] += int(bad_e.sum())
         assert bad.mean() < 5e-3 and want.sum() > 1000, (i, bad.mean(), want.sum())
-        assert np.abs(lg[bad]).max(initial=0.0) < CORPUS_LOGIT_TOL, (i, np.abs(lg[bad]).max())     # only cells at the threshold may differ
+        assert not (bad & (np.abs(lg) >= tol[None, :])).any(), (i, float(np.abs(lg)[bad].max()))               # only cells at the threshold may differ
+        assert not (bad_e & (np.abs(lge) >= CORPUS_LOGIT_TOL_EMU)).any(), (i, float(np.abs(lge)[bad_e].max()))
         assert res["notes"][i] == R.pianoroll_to_notes(got, fs) and len(res["notes"][i]) > 50                # the reference's run-length, note for note
         if not bad.any():
             assert res["notes"][i] == R.pianoroll_to_notes(want, fs)
         assert abs(res["f1"][i] - R.f1_binary(truth[i].numpy(), got)) < 1e-9
         a += n
-    print(f"\n[corpus full size] cells flipped against the fp32 oracle: {flips} of {88 * 5 * 938}")
+    print(f"\n[corpus full size] cells flipped of {88 * 5 * 938}: {flips[0]} against the fp32 oracle, {flips[1]} against the f16-emulating oracle")
