@@ -436,7 +436,7 @@ def test_large_training_loop_matches_reference_losses(mta, golden_dir):
         else:
             assert np.abs(got - want).max() <= 2.0 * nsteps * lr + 1e-7, (name, float(np.abs(got - want).max()))
     # ... and every trained tensor MOVED the way the reference's did (the bound above alone passes for weights that never changed)
-    from test_gpu_train import _update_cosines, UPDATE_COS_ALL, UPDATE_COS_TENSOR
+    from test_gpu_train import _update_cosines, UPDATE_COS_ALL_LARGE as UPDATE_COS_ALL, UPDATE_COS_TENSOR_LARGE as UPDATE_COS_TENSOR
     cos_t, cos_all = _update_cosines({k[len("post::"):]: g[k] for k in g.files if k.startswith("post::") and "running_" not in k and "num_batches" not in k
                                       and "onset_head" not in k and "offset_head" not in k
                                       # (convolution biases in front of a BatchNorm: analytically zero gradient, Adam turns rounding noise into steps)

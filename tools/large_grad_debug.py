@@ -67,6 +67,29 @@ def wg_wrap(dz_hi, dz_lo, dz_pitch, x, x_pitch, B_, F_, T_, Cout, Cin, KH, KW, o
 
 
 TL._bn_act_bwd, TL._conv, TL.conv_wgrad_direct = bn_wrap, conv_wrap, wg_wrap
+
+# every library call goes check(lib.mt_x(ptr(a), ..., ptr(b)), "name"): ptr() sees the tensors, check() the name.  Snapshot the tensor
+# arguments of the calls of interest (after the call is queued: clone() is ordered behind it on the stream)
+from music_transcription_amd import train_step as TS  # noqa: E402
+WANT = ("mt_layernorm_residual_bwd", "mt_axpby_rows_f32", "mt_lstm_bidir_bwd", "mt_lstm_dg_unpack", "mt_gemm_lstm_dh", "mt_lstm_dh_relayout")
+calls, cur = [], []
+_ptr, _check = TL.ptr, TL.check
+
+
+def ptr_wrap(t):
+    if torch.is_tensor(t):
+        cur.append(t)
+    return _ptr(t)
+
+
+def check_wrap(rc, name=""):
+    _check(rc, name)
+    if in_bwd[0] and name in WANT:
+        calls.append((name, [t.detach().clone() for t in cur]))
+    cur.clear()
+
+
+TL.ptr, TL.check, TS.ptr, TS.check = ptr_wrap, check_wrap, ptr_wrap, check_wrap
 os.environ["MT_TRAIN_LARGE_STREAMS"] = "0"
 logits = m(mel.cuda())
 loss = m.compute_loss(logits, roll.cuda(), lengths)
@@ -118,11 +141,38 @@ for name, pre, pool in (("rb1", p + "res_block1", True), ("rb2", p + "res_block2
 zf = keep("zf", conv_raw(x, sdo[p + "freq_aware_conv.0.weight"], sdo[p + "freq_aware_conv.0.bias"], (3, 1)))
 hf = keep("hf", R.pool_f2(torch.relu(bnorm(zf, p + "freq_aware_conv.1"))))
 feats = hf.permute(0, 3, 1, 2).reshape(B, T, 256 * F3)
-main = R.bilstm(feats, sdo, p + "rnn_main", L, o)
-local = R.bilstm(feats, sdo, p + "rnn_local", 1, o)
-r = torch.cat([main, local], dim=-1)
-r = F.layer_norm(r + R.attention(r, sdo, p + "attention", 8, o), (r.shape[-1],), sdo[p + "attention_norm.weight"], sdo[p + "attention_norm.bias"], R.LN_EPS)
-shared = torch.relu(R._rq(r, o) @ R._rq(sdo[p + "shared_fc.weight"], o).t() + sdo[p + "shared_fc.bias"])
+
+
+def lstm_dir_nodes(x, pre, l, suf, reverse, tag):
+    """oracle.model_ref.lstm_dir with the gate pre-activation input (gx) kept as a node"""
+    w_ih, w_hh = sdo[f"{pre}.weight_ih_l{l}{suf}"], sdo[f"{pre}.weight_hh_l{l}{suf}"]
+    Hh = w_hh.shape[1]
+    gx = keep(tag + ".gx", R._rq(x, o) @ R._rq(w_ih, o).t() + (sdo[f"{pre}.bias_ih_l{l}{suf}"] + sdo[f"{pre}.bias_hh_l{l}{suf}"]))
+    q16 = lambda v: v + (v.half().float() - v).detach()
+    w_hh_t = q16(w_hh).t().contiguous()
+    h, c = x.new_zeros(B, Hh), x.new_zeros(B, Hh)
+    outs = [None] * T
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        gg = gx[:, t] + h @ w_hh_t
+        i_, f_, g_, o_ = gg.split(Hh, dim=1)
+        c = torch.sigmoid(f_) * c + torch.sigmoid(i_) * torch.tanh(g_)
+        h = q16(torch.sigmoid(o_) * torch.tanh(c))
+        outs[t] = h
+    return torch.stack(outs, 1)
+
+
+def bilstm_nodes(x, pre, layers, tag):
+    for l in range(layers):
+        x = keep(f"{tag}.out{l}", torch.cat([lstm_dir_nodes(x, pre, l, "", False, f"{tag}.l{l}.f"), lstm_dir_nodes(x, pre, l, "_reverse", True, f"{tag}.l{l}.r")], -1))
+    return x
+
+
+main = bilstm_nodes(feats, p + "rnn_main", L, "main")
+local = bilstm_nodes(feats, p + "rnn_local", 1, "local")
+r = keep("r", torch.cat([main, local], dim=-1))
+pre_ln = keep("pre_ln", r + R.attention(r, sdo, p + "attention", 8, o))
+feat = keep("feat", F.layer_norm(pre_ln, (r.shape[-1],), sdo[p + "attention_norm.weight"], sdo[p + "attention_norm.bias"], R.LN_EPS))
+shared = torch.relu(R._rq(feat, o) @ R._rq(sdo[p + "shared_fc.weight"], o).t() + sdo[p + "shared_fc.bias"])
 lo = (R._rq(shared, o) @ R._rq(sdo[p + "frame_head.weight"], o).t() + sdo[p + "frame_head.bias"]).transpose(1, 2)
 R.compute_loss(lo, roll, lengths).backward(retain_graph=True)
 print(f"logits HIP vs oracle: max|d| {float((logits.detach().cpu() - lo.detach()).abs().max()):.4g}")
@@ -146,6 +196,61 @@ def agrad(out_node, in_nodes, gout):
     return torch.autograd.grad(out_node, in_nodes, grad_outputs=gout.to(out_node.dtype), retain_graph=True, allow_unused=True)
 
 
+# ---------------------------------------------------------------------------------------------------- upper stack, in backward order
+Hl = H // 2
+comb = 2 * H + 2 * Hl
+rows = lambda t_: t_.float().cpu()[:T * B].reshape(T, B, -1).permute(1, 0, 2)          # [(t*B+b)][C] -> [B][T][C]
+
+
+def dh_layout(t_, Hp_, Hv):            # BPTT layout [g][t][d][Hp/8][8][32] f32 -> [B][T][2*Hv]
+    v = t_.float().cpu().reshape(-1, T, 2, Hp_ // 8, 8, 32)[0]                          # one batch group (B <= 32)
+    v = v.permute(4, 0, 1, 2, 3).reshape(32, T, 2, Hp_)[:B, :, :, :Hv]
+    return v.reshape(B, T, 2 * Hv)
+
+
+def dg_rows(t_, ld, col0, Hp_, Hv, d):  # dG [(t*B+b)][ld] bf16, column col0 + d*4Hp + p*Hp + j -> [B][T][4*Hv]
+    v = t_.float().cpu().reshape(-1, ld)[:T * B, col0 + d * 4 * Hp_: col0 + (d + 1) * 4 * Hp_].reshape(T, B, 4, Hp_)[..., :Hv]
+    return v.permute(1, 0, 2, 3).reshape(B, T, 4 * Hv)
+
+
+print("== upper stack (cumulative = against the oracle's end-to-end backward; isolated = the oracle's stage fed the HIP stage's input)")
+byname = {}
+for nm_, ts in calls:
+    byname.setdefault(nm_, []).append(ts)
+ln_c = byname["mt_layernorm_residual_bwd"][0]        # r32, proj, ln_g, ln_stats, dfeat, dxln, part
+dfeat_h, dxln_h = rows(ln_c[4])[..., :comb], rows(ln_c[5])[..., :comb]
+rep("dfeat (into LayerNorm) cumulative", dfeat_h, nodes["feat"].grad)
+rep("dxln cumulative", dxln_h, nodes["pre_ln"].grad)
+(gi,) = agrad(nodes["feat"], [nodes["pre_ln"]], dfeat_h)
+rep("dxln isolated", dxln_h, gi)
+dr_h = rows(byname["mt_axpby_rows_f32"][0][2])[..., :comb]
+rep("dr (into the LSTMs) cumulative", dr_h, nodes["r"].grad)
+(gi,) = agrad(nodes["pre_ln"], [nodes["r"]], dxln_h)
+rep("dr isolated (attention backward + residual)", dr_h, gi)
+Hp_m, Hp_l = ((H + 15) // 16) * 16, ((Hl + 15) // 16) * 16
+bw = byname["mt_lstm_bidir_bwd"]                      # args: gates, cx, dh, w_hh, dgx, part, sync
+un = byname["mt_lstm_dg_unpack"]                      # args: dgx, dG, dGT
+# call order with MT_TRAIN_LARGE_STREAMS=0: main layers L-1 .. 0, then the local layer
+order = [("main", l, Hp_m, H) for l in range(L - 1, -1, -1)] + [("local", 0, Hp_l, Hl)]
+for (tag, l, Hp_, Hv), b_args, u_args in zip(order, bw, un):
+    dh_h = dh_layout(b_args[2], Hp_, Hv)
+    out_node = nodes[f"{tag}.out{l}"]
+    rep(f"{tag} layer {l}: dh (into BPTT) cumulative", dh_h, out_node.grad)
+    dG = u_args[1]
+    if l == 0:        # layer 0 writes its columns of the shared dG0 (row pitch 8 Hp_main + 8 Hp_local): the captured view starts at its first column
+        ld = 8 * Hp_m + 8 * Hp_l
+        flat = dG.float().cpu().reshape(-1)
+        flat = flat[:(flat.numel() // ld) * ld] if flat.numel() >= T * B * ld else torch.cat([flat, flat.new_zeros(T * B * ld - flat.numel())])
+        dg_of = lambda d, flat=flat, ld=ld: dg_rows(flat, ld, 0, Hp_, Hv, d)
+    else:
+        dg_of = lambda d, dG=dG: dg_rows(dG, 8 * Hp_, 0, Hp_, Hv, d)
+    for d, sfx in ((0, "f"), (1, "r")):
+        gx_node = nodes[f"{tag}.l{l}.{sfx}.gx"]
+        dgh = dg_of(d)
+        rep(f"{tag} layer {l} dir {sfx}: dgates cumulative", dgh, gx_node.grad)
+        (gi,) = agrad(out_node, [gx_node], dh_h)
+        rep(f"{tag} layer {l} dir {sfx}: dgates isolated (BPTT alone)", dgh, gi)
+print("== convolution stack")
 it = iter(cap)
 
 

@@ -36,7 +36,7 @@ torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / 5
 tiled = os.environ.get("MT_RESAMPLE_TILED", "1") != "0"
 print(f"resample {secs:g} s of 44.1 kHz stereo int16 -> {y.numel()} samples, {'tiled' if tiled else 'thread-per-output'} kernel: {ms:.3f} ms "
-      f"({y.numel() * 495 * 2 / ms / 1e9:.1f} GFLOP/s of filter arithmetic; 20 h would take {ms * 72000 / secs:.0f} ms)")
+      f"({y.numel() * 495 * 2 / ms / 1e9:.2f} TFLOP/s of filter arithmetic; 20 h would take {ms * 72000 / secs:.0f} ms)")
 np.save(os.path.join(ROOT, "gpurun_out", f"pcm_probe_{'tiled' if tiled else 'plain'}.npy"), y[:2000000].cpu().numpy())
 other = os.path.join(ROOT, "gpurun_out", f"pcm_probe_{'plain' if tiled else 'tiled'}.npy")
 if os.path.exists(other):
