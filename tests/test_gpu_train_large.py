@@ -18,15 +18,21 @@ pytestmark = pytest.mark.gpu
 
 from oracle import model_ref as R
 
-# Against the oracle with the HIP path's bf16 rounding points.  The emulation cannot be exact: tests/tools/large_train_debug.py
-# shows every stage of the forward agreeing with it to ONE bf16 ulp (e.g. 0.0078 at |x| ~ 3), and a 1-ulp difference in front
-# of a ReLU / max-pool decision or under LayerNorm(48 features) moves single gradient entries by percents at these toy shapes;
-# the conv weight gradients are the heavily cancelling sums (BatchNorm forces sum dz = 0, sum dz*z = 0).  The pieces themselves
-# are held to tight bounds against torch autograd in the unit tests above.
+# Against the oracle with the HIP path's bf16 rounding points.  Which distance is a kernel error and which is the model's own
+# sensitivity?  MEASURED (round 4, tools/large_grad_debug.py + the oracle alone on the CPU):
+#   * every backward stage fed the HIP path's OWN input gradient agrees with f64 autograd on that stage: convolution weight
+#     gradients 0.2 - 0.4 %, input-gradient convolutions 0.3 %, attention + residual 0.04 %, LayerNorm 1 %, BPTT 0.4 - 0.7 % per layer;
+#   * the gradient entering the top of the backward pass (d feat, behind the heads) is already 7.6 % (L2) from the oracle's, and every
+#     stage below inherits that: it is ReLU / max-pool DECISIONS that differ where the two forward passes differ in a last bit, and
+#     BatchNorm's projections (sum dz = 0, sum dz xhat = 0) remove most of the upstream gradient's norm but none of that noise;
+#   * the oracle is that sensitive to ITSELF: perturbing its 16-bit roundings by 2^-20 relative -- the size of an f32 re-association --
+#     moves its train-mode logits by 0.03 and its conv weight gradients by 10 - 19 % of their largest entry (cosine 0.9977); at 2^-24 still
+#     7.5 - 10 % (cosine 0.9986 - 0.9992).  The HIP path sits at logits 0.04, conv weight gradients 9 - 11 %, cosine 0.9977 at that shape.
+# So the per-tensor bound is NOT a fixed table: it is the oracle's own noise floor at the test's shape (_oracle_noise_floor: three
+# perturbed runs of the oracle, per-tensor maximum), with GRAD_REL as the bound wherever the floor is below it.
 GRAD_REL = 6e-2        # per tensor: max |g - g_ref| / max |g_ref|
-GRAD_REL_BY_KEY = {"freq_aware_conv.0.weight": 0.25, "res_block2.conv2.weight": 0.2, "res_block2.conv1.weight": 0.15,
-                   "res_block1.conv2.weight": 0.15, "res_block1.conv1.weight": 0.15, "res_block2.skip.0.weight": 0.15,
-                   "res_block1.skip.0.weight": 0.15}
+FLOOR_AMP, FLOOR_SEEDS = 2.0 ** -20, (1, 2, 3)
+FLOOR_FACTOR, FLOOR_MARGIN = 1.5, 0.02     # HIP within 1.5 x the floor + 2 % (the floor itself is three random draws)
 GRAD_COS = 0.998
 # Against the fp32 reference golden the bar is set by bf16 itself, not by the kernels: at the golden's toy shapes (a few
 # hundred positions per BatchNorm channel, random labels) the CPU oracle with bf16-rounded activations and EXACT f32
@@ -331,6 +337,40 @@ def _oracle_grads(sd, mel, roll, lengths, emulate_bf16, all_heads=False):
     return lo, grads
 
 
+def _oracle_noise_floor(sd, mel, roll, lengths, ref, all_heads=False, amp=FLOOR_AMP, seeds=FLOOR_SEEDS):
+    """The emulating oracle's distance from ITSELF when every 16-bit rounding of an activation is preceded by a relative perturbation of
+    `amp` (2^-20: an f32 re-association; parameters are not perturbed): {tensor: max over the seeds of max |g' - g| / max |g|}, the smallest
+    cosine, the largest logit distance.  `ref` = the unperturbed oracle's gradients."""
+    floor, cos_min, dl_max = {}, 1.0, 0.0
+    orig = R._bf16_round
+    lo0 = None
+    for seed in (None,) + tuple(seeds):
+        gen = torch.Generator().manual_seed(seed or 0)
+
+        def dithered(x, gen=gen, on=seed is not None):
+            if on and not (x.is_leaf and x.requires_grad):
+                x = x + x.detach() * (amp * (2.0 * torch.rand(x.shape, generator=gen) - 1.0))
+            return orig(x)
+        R._bf16_round = dithered
+        try:
+            lo, g1 = _oracle_grads(sd, mel, roll, lengths, True, all_heads)
+        finally:
+            R._bf16_round = orig
+        lo = lo["frame"] if isinstance(lo, dict) else lo
+        if seed is None:
+            lo0 = lo.detach()
+            continue
+        w, c = _compare_grads({k: torch.from_numpy(v) for k, v in g1.items()}, ref)
+        for k, v in w.items():
+            floor[k] = max(floor.get(k, 0.0), v)
+        cos_min, dl_max = min(cos_min, c), max(dl_max, float((lo.detach() - lo0).abs().max()))
+    return floor, cos_min, dl_max
+
+
+def _bound(floor, k):
+    return max(GRAD_REL, FLOOR_FACTOR * floor.get(k, 0.0) + FLOOR_MARGIN)
+
+
 def _report(tag, worst, cos):
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:12]
     print(f"\n[{tag}] cos={cos:.6f} worst: " + ", ".join(f"{k.replace('model.', '')}={v:.3g}" for k, v in top))
@@ -361,12 +401,14 @@ def test_large_train_step_matches_reference_golden(mta, golden_dir):
     _report("large vs bf16-emulating oracle", worst, cos)
     we, ce = _compare_grads({k: torch.from_numpy(v) for k, v in ref_emu.items()}, ref)
     _report("(bf16-emulating oracle vs fp32 reference golden)", we, ce)
-    bad = {k: (v, we[k]) for k, v in worst32.items() if v > we[k] + GRAD_REL_BY_KEY.get(k[len("model."):], GRAD_REL)}
+    floor, cos_floor, dl_floor = _oracle_noise_floor(sd, mel, roll, lengths, ref_emu)
+    _report(f"(emulating oracle vs ITSELF under 2^-20 perturbations of its roundings: logits {dl_floor:.3f})", floor, cos_floor)
+    bad = {k: (v, we[k]) for k, v in worst32.items() if v > we[k] + _bound(floor, k)}
     assert not bad and cos32 > GRAD_COS_FP32 and cos32 > ce - 2e-3, (bad, cos32, ce)
     dd = (logits.detach().cpu() - lo_emu.detach()).abs()
     assert float(dd.mean()) < 4e-3 and float(dd.max()) < 2.5 * LOGIT_TOL_TRAIN_EMU
-    bad = {k: v for k, v in worst.items() if v > GRAD_REL_BY_KEY.get(k[len("model."):], GRAD_REL)}
-    assert not bad and cos > GRAD_COS, (bad, cos)
+    bad = {k: (v, floor.get(k)) for k, v in worst.items() if v > _bound(floor, k)}
+    assert not bad and cos > min(GRAD_COS, cos_floor - 1e-3), (bad, cos, cos_floor)
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters() if p.grad is not None)))
     # the frame-only loss leaves the onset / offset heads out of the graph (train_transcriber.py:119): .grad None, as in torch
     assert all(p.grad is None for k, p in m.named_parameters() if "onset_head" in k or "offset_head" in k)
@@ -381,12 +423,12 @@ def test_large_train_step_matches_reference_golden(mta, golden_dir):
 
 
 def test_large_gradients_at_a_realistic_position_count(mta):
-    """How much of the wide per-tensor bounds of GRAD_REL_BY_KEY belongs to the goldens' TOY shapes (a few hundred positions per
-    BatchNorm channel)?  At n_mels = 320, B = 2, T = 200 -- 64 000 positions per channel in the first block, 32 000 in the 7x3
-    conv -- against the oracle with the same bf16 rounding points: the conv weight gradients tighten from 15-25 % to 9-11 %
-    (freq_aware_conv 0.25 -> 0.11), cosine 0.9977; the BatchNorm affine gradients of the residual blocks sit at 10-18 %.  MEASURED,
-    NOT YET AT 6 %: the bound asserted here is what holds (conv weights <= 12 %, every tensor <= 20 %), and the gap to GRAD_REL
-    is recorded as open work: the remaining error is not a toy-shape artefact alone."""
+    """n_mels = 320, B = 2, T = 200 -- 64 000 positions per BatchNorm channel in the first block, 32 000 in the 7x3 conv -- against the
+    oracle with the same bf16 rounding points.  The per-tensor distance does not shrink to GRAD_REL with the position count: conv weight
+    gradients 9 - 11 %, BatchNorm affine gradients 10 - 18 %, cosine 0.9977.  Round 4 found why (header of this file): that IS the oracle's
+    distance from itself under 2^-20 perturbations of its roundings (10 - 19 %, cosine 0.9977), while every backward stage alone is within
+    0.2 - 1 % of autograd (tools/large_grad_debug.py, profiles/r04_large_grad_stage_errors.txt).  Asserted: the HIP path is within the
+    measured floor, tensor by tensor, at least as close in cosine, and its logits are no further away than the perturbed oracle's."""
     nm, H, L, B, T = 320, 64, 2, 2, 200
     m, sd = _hip_large(mta, nm, H, L, 21)
     m.train()
@@ -402,11 +444,15 @@ def test_large_gradients_at_a_realistic_position_count(mta):
     m.model.raise_on_train_handoff_timeout()
     grads = {k: p.grad for k, p in m.named_parameters()}
     lo_emu, ref_emu = _oracle_grads(sd, mel, roll, lengths, True)
-    assert float((logits.detach().cpu() - lo_emu.detach()).abs().max()) < 2.5 * LOGIT_TOL_TRAIN_EMU
+    dl = float((logits.detach().cpu() - lo_emu.detach()).abs().max())
     worst, cos = _compare_grads(grads, ref_emu)
-    _report("large 320/64/2, B = 2, T = 200 vs bf16-emulating oracle", worst, cos)
-    bad = {k: v for k, v in worst.items() if v > (0.12 if k.endswith("conv1.weight") or k.endswith("conv2.weight") or k.endswith(".0.weight") else 0.20)}
-    assert not bad and cos > 0.997, (bad, cos)
+    _report(f"large 320/64/2, B = 2, T = 200 vs bf16-emulating oracle (logits {dl:.3f})", worst, cos)
+    floor, cos_floor, dl_floor = _oracle_noise_floor(sd, mel, roll, lengths, ref_emu)
+    _report(f"(emulating oracle vs ITSELF under 2^-20 perturbations of its roundings: logits {dl_floor:.3f})", floor, cos_floor)
+    assert dl < 2.5 * LOGIT_TOL_TRAIN_EMU and dl < 2.0 * dl_floor + 0.01, (dl, dl_floor)
+    bad = {k: (v, floor.get(k)) for k, v in worst.items() if v > _bound(floor, k)}
+    assert not bad and cos > cos_floor - 1e-3 and cos > 0.997, (bad, cos, cos_floor)
+    assert max(worst.values()) < 0.25                      # (and an absolute cap, whatever the floor's draws say)
 
 
 def test_large_training_loop_matches_reference_losses(mta, golden_dir):
@@ -477,8 +523,9 @@ def test_large_variants_and_dict_loss_vs_oracle_autograd(mta, kw, all_heads):
         assert close(out, lo)
     worst, cos = _compare_grads(grads, ref)
     _report(f"variant {kw} all_heads={all_heads}", worst, cos)
-    bad = {k: v for k, v in worst.items() if v > max(GRAD_REL_BY_KEY.get(k[len("model."):], GRAD_REL), 0.15)}
-    assert not bad and cos > GRAD_COS, (bad, cos)
+    floor, cos_floor, _ = _oracle_noise_floor(sd, mel, roll, lengths, ref, all_heads)
+    bad = {k: (v, floor.get(k)) for k, v in worst.items() if v > _bound(floor, k)}
+    assert not bad and cos > min(GRAD_COS, cos_floor - 1e-3), (bad, cos, cos_floor)
 
 
 def test_large_train_with_dropout_runs_and_is_seeded(mta):
