@@ -154,11 +154,35 @@ class FusedAdamClip:
         # flat ranges of all the others (keep ranges).  `net` is attached by train.make_optimizer.
         self.net = None
         self.skip_untouched = True
+        self._touched = set()             # parameters whose flat-gradient view a backward pass wrote directly since zero_grad()
 
     def zero_grad(self):
         self.g.zero_()
+        self._touched = set()
         if self.net is not None:
             self.net._params_without_grad = None        # None = no backward pass since (the training step intersects)
+
+    def make_grad_target(self, named_params):
+        """-> target(name, shape): the flat-gradient view of parameter `name` for a training step's backward pass to WRITE its gradient
+        into (the step then hands autograd None for it), or None when the gradient must go through autograd's accumulation instead:
+        the parameter's .grad no longer is its view of the flat buffer (a caller detached it), or something was already written for
+        it since zero_grad() (a second backward pass before step(): gradients accumulate, as in torch).  A view is handed out once
+        per zero_grad()."""
+        off = {id(p): (o, k) for p, o, k in (self._views or [])}
+
+        def target(name, shape):
+            p = named_params.get(name)
+            if p is None or id(p) not in off or id(p) in self._touched:
+                return None
+            o, k = off[id(p)]
+            n = 1
+            for v in shape:
+                n *= int(v)
+            if n != k or p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:
+                return None
+            self._touched.add(id(p))
+            return self.g[o:o + k].view(*[int(v) for v in shape])
+        return target
 
     def _keep_ranges(self):
         """Ascending merged [lo, hi) ranges of the parameters that take part in this step: all of them, minus those the last

@@ -30,6 +30,9 @@ def make_optimizer(model, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-
     flat, grads = flatten_parameters(model.parameters())
     opt = FusedAdamClip(flat, grads, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_grad_norm)
     opt.net = getattr(model, "model", model)       # the training step records there which parameters got no gradient (optim._keep_ranges)
+    if _world_size() == 1 and os.environ.get("MT_DIRECT_GRADS", "1") != "0":
+        # single GPU: the step's backward pass writes gradients straight into the flat buffer (optim.FusedAdamClip.make_grad_target)
+        opt.net._grad_target = opt.make_grad_target(dict(opt.net.named_parameters()))
     if _world_size() > 1 and os.environ.get("MT_DP_EARLY_BUCKET", "1") != "0":
         # data parallel: the gradients of the upper LSTM layers and the fc are all-reduced under the rest of the backward pass
         net = getattr(model, "model", model)

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from typing import Dict, List
 
+import os
+
 import torch
 
 from . import _lib
@@ -121,10 +123,32 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
+def _split_k(M, N, K):
+    """K split of a weight-gradient GEMM: its output (M x N = a parameter) is small, its contraction (K = T B positions) long, so one
+    tile per workgroup fills a fraction of the chip (dW_hh at H = 512: 16 tiles of 256 x 256 for 256 CUs, each walking 236 K-tiles).
+    -> number of K slices (1 = no split): the largest of 8, 4, 2 that divides K into whole 64-wide K-tiles and keeps the launch under
+    ~2 workgroups per CU.  MT_GEMM_SPLITK=0 turns it off."""
+    if K < 4096 or K % 64 or os.environ.get("MT_GEMM_SPLITK", "1") == "0":
+        return 1
+    big = M >= 1024 and N >= 512 and N % 128 == 0                      # (gemm.hip launch_dt: the shapes that take the 256-tile kernel)
+    tiles = (-(-M // 256)) * (-(-N // 256)) if big else (-(-M // 128)) * (-(-N // 128))
+    for S in (8, 4, 2):
+        if (K // 64) % S == 0 and tiles * S <= 512 and tiles * (S // 2) < 256:
+            return S
+    return 1
+
+
 def _gemm(A, lda, W, ldw, C, ldc, M, N, K, bias=None):
     # the kernel reads whole 128-row tiles of both operands: the views handed in must cover them
     assert A.numel() >= (_ru(M, 128) - 1) * lda + K and W.numel() >= (_ru(N, 128) - 1) * ldw + K, "GEMM operand smaller than its tiles"
     assert C.numel() >= (M - 1) * ldc + N
+    S = _split_k(M, N, K) if bias is None else 1
+    if S > 1:       # K slices as a batch into partial products, summed in a fixed order (bitwise reproducible)
+        Kc = K // S
+        part = torch.empty(S * M * N, device=C.device, dtype=torch.float32)
+        check(lib.mt_gemm_batched_f32(ptr(A), lda, 0, Kc, ptr(W), ldw, 0, Kc, None, ptr(part), N, 0, M * N, M, N, Kc, S, S, _st()), "mt_gemm_batched_f32 (split K)")
+        check(lib.mt_sum_slices_f32(ptr(part), M * N, N, S, ptr(C), ldc, M, N, _st()), "mt_sum_slices_f32")
+        return
     check(lib.mt_gemm_bf16_f32acc(ptr(A), lda, ptr(W), ldw, ptr(bias), ptr(C), ldc, M, N, K, _st()), "mt_gemm_bf16_f32acc")
 
 

@@ -166,6 +166,49 @@ def _pack_upper(model, dev, t, d):
         t["fc_wT"] = fwT.to(bf)
 
 
+# ---------------------------------------------------------------------------------------------------------------- step workspace
+class _StepWorkspace:
+    """The training step's zero-padded scratch tensors, allocated (and zeroed) ONCE per (batch, frames): GEMM operands are read in whole
+    128-row / 64-column tiles, so their rows and columns beyond the live region must hold zeros -- and no kernel ever writes there, so
+    they still do in the next step.  Round 3 called torch.zeros for ~40 such tensors per step (2.3 GB of fills at B = 16, T = 937, most
+    of them alone on the GPU in front of the kernel that needed the buffer).  What IS accumulated into (f64 statistic sums, status
+    words) stays a per-step torch.zeros.  One step per workspace at a time: a second forward before the first one's backward gets
+    fresh tensors (_FreshZeros)."""
+
+    def __init__(self):
+        self.t, self.busy = {}, False
+
+    def zeros(self, name, *shape, **kw):
+        key = (name, tuple(int(v) for v in shape), kw.get("dtype"))
+        t = self.t.get(key)
+        if t is None:
+            t = self.t[key] = torch.zeros(*shape, **kw)
+        return t
+
+
+class _FreshZeros:
+    busy = False
+
+    def zeros(self, name, *shape, **kw):
+        return torch.zeros(*shape, **kw)
+
+
+def _workspace(model, B, T, dev):
+    if os.environ.get("MT_TRAIN_WS_CACHE", "1") == "0":
+        return _FreshZeros()
+    pool = model.__dict__.setdefault("_train_ws", {})
+    key = (int(B), int(T), str(dev))
+    ws = pool.get(key)
+    if ws is None:
+        for k_ in [k_ for k_, v_ in pool.items() if not v_.busy][:max(0, len(pool) - 1)]:     # keep at most two shapes (ragged batches: T varies)
+            del pool[k_]
+        ws = pool[key] = _StepWorkspace()
+    if ws.busy:
+        return _FreshZeros()
+    ws.busy = True
+    return ws
+
+
 # ---------------------------------------------------------------------------------------------------------------- small wrappers
 def _conv(A, S, W, bias, out, B, F, T, C1, C2, Cout, KH, relu=0, pool=0, out_mode=0, ldx=0, pitchA=None, pitchS=None, accum=0):
     check(lib.mt_conv_cl_ex(ptr(A), pitchA or C1, ptr(S), pitchS or C2, ptr(W), ptr(bias), ptr(out), B, F, T, C1, C2, Cout, KH, relu, pool,
@@ -301,7 +344,7 @@ def conv_wgrad_direct(dz_hi, dz_lo, dz_pitch, x, x_pitch, B, F, T, Cout, Cin, KH
 
 
 # ---------------------------------------------------------------------------------------------------------------- LSTM stack
-def _lstm_forward(X0, K0, w_ih, b_g, w_hh, L, Hp, Hv, K1, B, T, dropout, seed, layer_id0, dev, sync_slots):
+def _lstm_forward(X0, K0, w_ih, b_g, w_hh, L, Hp, Hv, K1, B, T, dropout, seed, layer_id0, dev, sync_slots, ws, tag):
     """Train-mode bidirectional LSTM stack on GEMM-row input X0 [Mpad][K0].  Returns saved state; the last layer's hx is
     left for the caller to re-lay out.  Inter-layer dropout p on the outputs of layers 0..L-2."""
     M, Mpad = T * B, _ru(T * B, 128)
@@ -318,9 +361,7 @@ def _lstm_forward(X0, K0, w_ih, b_g, w_hh, L, Hp, Hv, K1, B, T, dropout, seed, l
               "mt_lstm_bidir_fwd_train")
         gates.append(gx); cxs.append(cx); hxs.append(hx)
         if l < L - 1:
-            Xn = torch.zeros(Mpad, K1, **bf) if K1 != 2 * Hv else torch.empty(Mpad, K1, **bf)
-            if K1 == 2 * Hv:
-                Xn[M:].zero_()
+            Xn = ws.zeros(f"{tag}.Xn{l}", Mpad, K1, **bf)             # (rows >= M and columns >= 2 Hv stay zero: never written)
             check(lib.mt_lstm_relayout_train(ptr(hx), ptr(Xn), K1, B, T, Hp, Hv, float(dropout), seed, layer_id0 + l, _st()),
                   "mt_lstm_relayout_train")
             Xs.append(Xn)
@@ -328,7 +369,7 @@ def _lstm_forward(X0, K0, w_ih, b_g, w_hh, L, Hp, Hv, K1, B, T, dropout, seed, l
 
 
 def _lstm_backward(sv, dh, w_hh, w_ihT, L, Hp, Hv, K0, K1, B, T, dropout, seed, layer_id0, dev, sync_slots, dG0, ldg0, col0, names, g, rnn_prefix,
-                   k0_gather, wg_stream=None, parts=None):
+                   k0_gather, wg_stream=None, parts=None, zws=None, tag="", newg=None):
     """BPTT through the stack.  dh: gradient of the top layer's output in the backward recurrence's layout.  Layer 0's gate
     gradients go to dG0[:, col0 : col0 + 8 Hp] (row pitch ldg0): the caller turns them into the input gradient.  Parameter
     gradients land in g under rnn_prefix; k0_gather(gwi, di) produces layer 0's W_ih gradient in the reference layout."""
@@ -349,25 +390,26 @@ def _lstm_backward(sv, dh, w_hh, w_ihT, L, Hp, Hv, K0, K1, B, T, dropout, seed, 
             dG, ldg = dG0[:, col0:], ldg0
             dGv = dG0.reshape(-1)[col0:]
         else:
-            dGfull = torch.empty(Mpad, 8 * Hp, **bf)
-            dGfull[M:].zero_()
+            dGfull = zws.zeros(f"{tag}.dG{l}", Mpad, 8 * Hp, **bf)
             dGv, ldg = dGfull, 8 * Hp
-        dGT = torch.zeros(4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
+        dGT = zws.zeros(f"{tag}.dGT{l}", 4 * Hp + _ru(4 * Hp, 128), Mpad, **bf)
         check(lib.mt_lstm_dg_unpack(ptr(dgx), ptr(dGv), ldg, ptr(dGT), Mpad, B, T, Hp, _st()), "mt_lstm_dg_unpack")
         if l > 0:      # -> dh of layer l-1 (its output went through dropout in the forward pass)
-            dh = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
+            dh = zws.zeros(f"{tag}.dh{l}", lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
             check(lib.mt_gemm_lstm_dh(ptr(dGv), 8 * Hp, ptr(w_ihT[l]), 8 * Hp, ptr(dh), B, T, Hp, Hv, 8 * Hp, float(dropout), seed,
                                       layer_id0 + l - 1, _st()), "mt_gemm_lstm_dh")
         # ---- weight gradients: dW_ih = dG^T X_l, dW_hh = dG^T H_prev, db = sum dG.  They gate nothing below: on `wg_stream`
         #      (when given) they run beside the next layer's backward recurrence.  All buffers are allocated here, on the calling
         #      stream, and stay referenced in `keep` until the caller has joined the streams.
         XT = torch.empty(_ru(K, 128) * Mpad, **bf)
-        HT = torch.zeros(2 * Hr, Mpad, **bf)
+        HT = zws.zeros(f"{tag}.HT{l}", 2 * Hr, Mpad, **bf)
         gb, gwi, gwh = torch.empty(8 * Hp, **f32), torch.empty(8 * Hp, K, **f32), torch.empty(2, 4 * Hp, Hp, **f32)
         outs = []
-        for di in range(2):
-            wi = torch.empty(4 * Hv, 256 * (K0 // 256), **f32) if l == 0 else torch.empty(4 * Hv, 2 * Hv, **f32)
-            outs.append((wi, torch.empty(4 * Hv, Hv, **f32), torch.empty(4 * Hv, **f32), torch.empty(4 * Hv, **f32)))
+        mk = newg if newg is not None else (lambda name, *shape: torch.empty(*shape, **f32))
+        for di, suf in enumerate(("", "_reverse")):        # (the reference-shaped gradients: straight into the flat gradient buffer where allowed)
+            wi = mk(f"{rnn_prefix}.weight_ih_l{l}{suf}", 4 * Hv, 256 * (K0 // 256) if l == 0 else 2 * Hv)
+            outs.append((wi, mk(f"{rnn_prefix}.weight_hh_l{l}{suf}", 4 * Hv, Hv), mk(f"{rnn_prefix}.bias_ih_l{l}{suf}", 4 * Hv),
+                         mk(f"{rnn_prefix}.bias_hh_l{l}{suf}", 4 * Hv)))
         keep += [XT, HT, gb, gwi, gwh, dGT, dGv, outs]
         cur = torch.cuda.current_stream(dev)
         ws = wg_stream if wg_stream is not None else cur
@@ -411,7 +453,8 @@ def forward_train_large(model, x: torch.Tensor, p_drop: float, seed: int, p2d=DR
     x = x.contiguous().float()
     bf = dict(device=dev, dtype=torch.bfloat16)
     f32 = dict(device=dev, dtype=torch.float32)
-    sv: Dict[str, object] = dict(pk=pk, x=x, B=B, T=T, p=p_drop, seed=seed, p2d=p2d)
+    ws = _workspace(model, B, T, dev)
+    sv: Dict[str, object] = dict(pk=pk, x=x, B=B, T=T, p=p_drop, seed=seed, p2d=p2d, ws=ws)
     nsync = 2 * (L + 1)
     stride = _ru(max(lib.mt_lstm_sync_bytes(B, Hp), lib.mt_lstm_sync_bytes(B, Hlp)), 256)
     sync_all = torch.zeros(nsync * stride, device=dev, dtype=torch.uint8)       # one status slot per persistent launch of the step
@@ -489,18 +532,18 @@ def forward_train_large(model, x: torch.Tensor, p_drop: float, seed: int, p2d=DR
             with torch.cuda.stream(side_b):
                 side_b.wait_event(ev_x0)
                 sv["local"] = _lstm_forward(X0, K0, pk["l_wih"], pk["l_b"], pk["l_whh"], 1, Hlp, Hl, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
-                                            slots_local)
+                                            slots_local, ws, "local")
                 ev_loc = torch.cuda.Event()
                 ev_loc.record(side_b)
             for t_ in sv["local"]["gates"] + sv["local"]["cxs"] + sv["local"]["hxs"]:
                 t_.record_stream(main_st)              # allocated under the side stream, read by the backward pass on the calling one
-        sv["main"] = _lstm_forward(X0, K0, pk["m_wih"], pk["m_b"], pk["m_whh"], L, Hp, H, K1, B, T, pm, seed, 0, dev, slots)
+        sv["main"] = _lstm_forward(X0, K0, pk["m_wih"], pk["m_b"], pk["m_whh"], L, Hp, H, K1, B, T, pm, seed, 0, dev, slots, ws, "main")
         if use_side:
             main_st.wait_event(ev_loc)
         else:
             sv["local"] = _lstm_forward(X0, K0, pk["l_wih"], pk["l_b"], pk["l_whh"], 1, Hlp, Hl, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
-                                        slots_local)
-        rb = torch.zeros(Mpad, Cp, **bf)
+                                        slots_local, ws, "local")
+        rb = ws.zeros("rb", Mpad, Cp, **bf)
         r32 = torch.empty(M, comb, **f32)
         check(lib.mt_lstm_relayout_ex(ptr(sv["main"]["hxs"][-1]), ptr(rb), Cp, ptr(r32), comb, 0, B, T, Hp, H, _st()), "mt_lstm_relayout_ex")
         check(lib.mt_lstm_relayout_ex(ptr(sv["local"]["hxs"][-1]), ptr(rb), Cp, ptr(r32), comb, 2 * H, B, T, Hlp, Hl, _st()), "mt_lstm_relayout_ex")
@@ -511,23 +554,23 @@ def forward_train_large(model, x: torch.Tensor, p_drop: float, seed: int, p2d=DR
             heads, dp, Ca, ld3, scale = d["heads"], d["dp"], d["Ca"], d["ld3"], d["scale"]
             Tr, Tp = _ru(T, 128), _ru(T, 64)
             dpr = _ru(dp, 128)
-            qkv = torch.zeros(Tr * B, ld3, **bf)
+            qkv = ws.zeros("qkv", Tr * B, ld3, **bf)
             _gemm_bf16out(rb, Cp, pk["qkv_w"], Cp, pk["qkv_b"], qkv, ld3, M, ld3, Cp)
             S = torch.empty(B * heads, T, Tp, **f32)
             qk = qkv.reshape(-1)
             check(lib.mt_gemm_batched_f32(ptr(qk), B * ld3, ld3, dp, ptr(qk[Ca:]), B * ld3, ld3, dp, None, ptr(S), Tp, heads * T * Tp, T * Tp,
                                           T, T, dp, B * heads, heads, _st()), "mt_gemm_batched_f32 (QK^T)")
-            Pd = torch.zeros(B * heads * T * Tp + Tr * Tp, **bf)           # (a head's GEMM reads whole 128-row tiles: tail slack)
+            Pd = ws.zeros("Pd", B * heads * T * Tp + Tr * Tp, **bf)           # (a head's GEMM reads whole 128-row tiles: tail slack)
             check(lib.mt_attn_softmax_train(ptr(S), Tp, ptr(Pd), Tp, T, B * heads * T, scale, ATTN_CLIP, float(p_drop), seed, ATTN_LAYER_ID, _st()),
                   "mt_attn_softmax_train")
             VT = torch.empty(B * heads, dpr, Tp, **bf)
             check(lib.mt_attn_transpose_v(ptr(qkv), ld3, 2 * Ca, ptr(VT), B, T, Tp, heads, dp, _st()), "mt_attn_transpose_v")
-            ao = torch.zeros(Mpad, Ca, **bf)
+            ao = ws.zeros("ao", Mpad, Ca, **bf)
             check(lib.mt_gemm_batched_bf16out(ptr(Pd), Tp, heads * T * Tp, T * Tp, ptr(VT), Tp, heads * dpr * Tp, dpr * Tp, None, ptr(ao), B * Ca,
                                               Ca, dp, T, dp, Tp, B * heads, heads, 0, _st()), "mt_gemm_batched_bf16out (PV)")
             proj = torch.empty(M, comb, **f32)
             _gemm(ao, Ca, pk["proj_w"], Ca, proj, comb, M, comb, Ca, bias=pk["proj_b"])
-            ln = torch.zeros(Mpad, Cp, **bf)
+            ln = ws.zeros("ln", Mpad, Cp, **bf)
             stats = torch.empty(M, 2, **f32)
             check(lib.mt_layernorm_residual_train(ptr(r32), comb, ptr(proj), comb, ptr(pk["ln_g"]), ptr(pk["ln_b"]), ptr(ln), Cp, ptr(stats), M, comb,
                                                   LN_EPS, _st()), "mt_layernorm_residual_train")
@@ -538,7 +581,7 @@ def forward_train_large(model, x: torch.Tensor, p_drop: float, seed: int, p2d=DR
         ph = 1.5 * p_drop
         if model.use_onset_offset_heads:
             Hs = d["Hs"]
-            sh = torch.zeros(Mpad, Hs, **bf)
+            sh = ws.zeros("sh", Mpad, Hs, **bf)
             _gemm_bf16out(feat, Cp, pk["shared_w"], Cp, pk["shared_b"], sh, Hs, M, H, Cp, relu=1)
             check(lib.mt_dropout_bf16_rows(ptr(sh), Hs, M, H, float(ph), seed, HEADS_LAYER_ID, _st()), "mt_dropout_bf16_rows")
             logits = torch.empty(3, B, 88, T, **f32)
@@ -565,6 +608,20 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
     g: Dict[str, torch.Tensor] = {}
     dlogits = dlogits.contiguous().float()
     slots = sv["sync_free"]
+    ws = sv["ws"]
+    # Gradient tensors: where the optimizer allows it (optim.FusedAdamClip.grad_target: single GPU, the parameter's .grad still is its
+    # view of the flat gradient buffer and nothing was accumulated into it since zero_grad()), the kernel that produces a parameter's
+    # gradient writes it STRAIGHT into that view -- autograd is handed None for it -- instead of into a temporary that autograd then
+    # adds to the view with one elementwise kernel per parameter (82 of them per step, 1 GB of traffic at 89 M parameters).
+    tgt = getattr(model, "_grad_target", None)
+    direct = sv["direct_grads"] = set()
+
+    def newg(name, *shape):
+        t = tgt(name, shape) if tgt is not None else None
+        if t is None:
+            return torch.empty(*shape, **f32)
+        direct.add(name)
+        return t
     feat = sv["feat"]
     ph = 1.5 * p_drop
     with torch.cuda.device(dev):
@@ -593,7 +650,7 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         # ---- heads
         if model.use_onset_offset_heads:
             Hs = d["Hs"]
-            dL, dLT = torch.zeros(Mpad, 384, **bf), torch.zeros(384, Mpad, **bf)
+            dL, dLT = ws.zeros("dL", Mpad, 384, **bf), ws.zeros("dLT", 384, Mpad, **bf)
             check(lib.mt_dlogits_pack_heads(ptr(dlogits), ptr(dL), 384, ptr(dLT), Mpad, 3, B, 88, T, _st()), "mt_dlogits_pack_heads")
             sh = sv["sh"]
             shT = torch.empty(_ru(Hs, 128) * Mpad, **bf)
@@ -608,13 +665,13 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
                 g[f"{n}_head.weight"], g[f"{n}_head.bias"] = w, ghb[i * 88:(i + 1) * 88].clone()
             dsh = torch.empty(M, Hs, **f32)
             _gemm(dL, 384, pk["heads_wT"], 384, dsh, Hs, M, Hs, 384)
-            dzs = torch.zeros(Mpad, Hs, **bf)
+            dzs = ws.zeros("dzs", Mpad, Hs, **bf)
             check(lib.mt_heads_relu_dropout_bwd(ptr(dsh), Hs, ptr(sh), Hs, ptr(dzs), Hs, M, H, float(ph), _st()), "mt_heads_relu_dropout_bwd")
             dzsT = torch.empty(_ru(Hs, 128) * Mpad, **bf)
             check(lib.mt_transpose_bf16(ptr(dzs), Hs, M, Hs, ptr(dzsT), Mpad, Hs, _st()), "mt_transpose_bf16")
             gs = torch.empty(_ru(H, 128), Cp, **f32)
             _gemm(dzsT, Mpad, featT, Mpad, gs, Cp, H, Cp, Mpad)
-            g["shared_fc.weight"], g["shared_fc.bias"] = torch.empty(H, comb, **f32), torch.empty(H, **f32)
+            g["shared_fc.weight"], g["shared_fc.bias"] = newg("shared_fc.weight", H, comb), newg("shared_fc.bias", H)
             _gather4(gs, 0, g["shared_fc.weight"], (1, 1, H, comb), (0, 0, Cp, 1))
             check(lib.mt_rowsum_bf16(ptr(dzsT), Mpad, M, ptr(g["shared_fc.bias"]), H, _st()), "mt_rowsum_bf16")
             _gemm(dzs, Hs, pk["shared_wT"], Hs, dfeat, comb, M, comb, Hs)
@@ -622,11 +679,11 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             if ph > 0.0:        # the dropout on the logits (cnn_rnn_model.py:346): same mask
                 dlogits = dlogits.clone()
                 check(lib.mt_dropout_f32(ptr(dlogits), dlogits.numel(), float(ph), seed, HEADS_LAYER_ID, _st()), "mt_dropout_f32")
-            dL, dLT = torch.zeros(Mpad, 128, **bf), torch.zeros(128, Mpad, **bf)
+            dL, dLT = ws.zeros("dL", Mpad, 128, **bf), ws.zeros("dLT", 128, Mpad, **bf)
             check(lib.mt_dlogits_pack(ptr(dlogits), ptr(dL), ptr(dLT), Mpad, B, 88, T, _st()), "mt_dlogits_pack")
             gf = torch.empty(128, Cp, **f32)
             _gemm(dLT, Mpad, featT, Mpad, gf, Cp, 88, Cp, Mpad)
-            g["fc.weight"], g["fc.bias"] = torch.empty(88, comb, **f32), torch.empty(88, **f32)
+            g["fc.weight"], g["fc.bias"] = newg("fc.weight", 88, comb), newg("fc.bias", 88)
             _gather4(gf, 0, g["fc.weight"], (1, 1, 88, comb), (0, 0, Cp, 1))
             check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(g["fc.bias"]), 88, _st()), "mt_rowsum_bf16")
             _gemm(dL, 128, pk["fc_wT"], 128, dfeat, comb, M, comb, 128)
@@ -644,7 +701,7 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             check(lib.mt_sum_slices_f32(ptr(part), 2 * comb, comb, nsl, ptr(lng), comb, 2, comb, _st()), "mt_sum_slices_f32")
             g["attention_norm.weight"], g["attention_norm.bias"] = lng[0].clone(), lng[1].clone()
             # proj
-            dpb = torch.zeros(Mpad, Cp, **bf)
+            dpb = ws.zeros("dpb", Mpad, Cp, **bf)
             check(lib.mt_f32_to_bf16_rows(ptr(dxln), comb, ptr(dpb), Cp, M, comb, 1.0, _st()), "mt_f32_to_bf16_rows")
             dpT = torch.empty(_ru(Cp, 128) * Mpad, **bf)
             check(lib.mt_transpose_bf16(ptr(dpb), Cp, M, Cp, ptr(dpT), Mpad, Cp, _st()), "mt_transpose_bf16")
@@ -652,10 +709,10 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             check(lib.mt_transpose_bf16(ptr(sv["ao"]), Ca, M, Ca, ptr(aoT), Mpad, Ca, _st()), "mt_transpose_bf16")
             gp = torch.empty(_ru(comb, 128), Ca, **f32)
             _gemm(dpT, Mpad, aoT, Mpad, gp, Ca, comb, Ca, Mpad)
-            g["attention.proj.weight"], g["attention.proj.bias"] = torch.empty(comb, comb, **f32), torch.empty(comb, **f32)
+            g["attention.proj.weight"], g["attention.proj.bias"] = newg("attention.proj.weight", comb, comb), newg("attention.proj.bias", comb)
             _gather4(gp, 0, g["attention.proj.weight"], (1, comb, heads, dh_), (0, Ca, dp, 1))
             check(lib.mt_rowsum_bf16(ptr(dpT), Mpad, M, ptr(g["attention.proj.bias"]), comb, _st()), "mt_rowsum_bf16")
-            dO = torch.zeros(Tr * B, Ca, **bf)
+            dO = ws.zeros("dO", Tr * B, Ca, **bf)
             _gemm_bf16out(dpb, Cp, pk["proj_wT"], Cp, None, dO, Ca, M, Ca, Cp)
             # dPd = dO V^T per (chunk, head)
             qkv = sv["qkv"]
@@ -664,10 +721,10 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             dPd = torch.empty(B * heads, T, Tp, **f32)
             check(lib.mt_gemm_batched_f32(ptr(dOf), B * Ca, Ca, dp, ptr(qk[2 * Ca:]), B * ld3, ld3, dp, None, ptr(dPd), Tp, heads * T * Tp, T * Tp,
                                           T, T, dp, B * heads, heads, _st()), "mt_gemm_batched_f32 (dO V^T)")
-            dS = torch.zeros(B * heads * T * Tp + Tr * Tp, **bf)
+            dS = ws.zeros("dS", B * heads * T * Tp + Tr * Tp, **bf)
             check(lib.mt_attn_clamped_bwd(ptr(sv["S"]), Tp, ptr(dPd), Tp, ptr(dS), Tp, T, B * heads * T, scale, ATTN_CLIP, float(p_drop), seed,
                                           ATTN_LAYER_ID, _st()), "mt_attn_clamped_bwd")
-            dqkv = torch.zeros(Mpad, ld3, **bf)
+            dqkv = ws.zeros("dqkv", Mpad, ld3, **bf)
             dq = dqkv.reshape(-1)
             # dV = Pd^T dO:  A = Pd^T [t'][t] per (chunk, head), W = dO^T [d][t]
             PdT = torch.empty(B * heads, Tr, Tp, **bf)
@@ -695,12 +752,12 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             check(lib.mt_transpose_bf16(ptr(sv["rb"]), Cp, M, Cp, ptr(rbT), Mpad, Cp, _st()), "mt_transpose_bf16")
             gq = torch.empty(_ru(ld3, 128), Cp, **f32)
             _gemm(dqT, Mpad, rbT, Mpad, gq, Cp, ld3, Cp, Mpad)
-            g["attention.qkv.weight"] = torch.empty(3 * comb, comb, **f32)
+            g["attention.qkv.weight"] = newg("attention.qkv.weight", 3 * comb, comb)
             for w3 in range(3):
                 _gather4(gq, w3 * Ca * Cp, g["attention.qkv.weight"][w3 * comb:(w3 + 1) * comb], (1, heads, dh_, comb), (0, dp * Cp, Cp, 1))
             gqb = torch.empty(ld3, **f32)
             check(lib.mt_rowsum_bf16(ptr(dqT), Mpad, M, ptr(gqb), ld3, _st()), "mt_rowsum_bf16")
-            g["attention.qkv.bias"] = torch.empty(3 * comb, **f32)
+            g["attention.qkv.bias"] = newg("attention.qkv.bias", 3 * comb)
             _gather4(gqb, 0, g["attention.qkv.bias"], (1, 3, heads, dh_), (0, Ca, dp, 1))
             dra = torch.empty(M, comb, **f32)
             _gemm(dqkv, ld3, pk["qkv_wT"], ld3, dra, comb, M, comb, ld3)
@@ -710,11 +767,11 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             dr = dfeat
         # ---- LSTMs: main stack and the local layer; layer 0's gate gradients side by side -> one input-gradient GEMM
         ldg = 8 * Hp + 8 * Hlp
-        dG0 = torch.zeros(Mpad, ldg, **bf)
+        dG0 = ws.zeros("dG0", Mpad, ldg, **bf)
         drf = dr.reshape(-1)
-        dh_m = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
+        dh_m = ws.zeros("dh_m", lib.mt_lstm_cx_bytes(B, T, Hp) // 4, **f32)
         check(lib.mt_lstm_dh_relayout(ptr(drf), comb, ptr(dh_m), B, T, Hp, H, 0.0, seed, 0, _st()), "mt_lstm_dh_relayout")
-        dh_l = torch.zeros(lib.mt_lstm_cx_bytes(B, T, Hlp) // 4, **f32)
+        dh_l = ws.zeros("dh_l", lib.mt_lstm_cx_bytes(B, T, Hlp) // 4, **f32)
         check(lib.mt_lstm_dh_relayout(ptr(drf[2 * H:]), comb, ptr(dh_l), B, T, Hlp, Hl, 0.0, seed, 0, _st()), "mt_lstm_dh_relayout")
 
         def k0_gather(Hx, Hxp):
@@ -736,12 +793,12 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             with torch.cuda.stream(side_b):
                 side_b.wait_event(ev_in)
                 keep_all += _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
-                                           slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp), parts=parts_local)
+                                           slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp), parts=parts_local, zws=ws, tag="local", newg=newg)
         keep_all += _lstm_backward(sv["main"], dh_m, pk["m_whh"], pk["m_wihT"], L, Hp, H, K0, K1, B, T, pm, seed, 0, dev, slots, dG0, ldg, 0, None, g,
-                                   "rnn_main", k0_gather(H, Hp), wg_stream=side_a, parts=parts_main)
+                                   "rnn_main", k0_gather(H, Hp), wg_stream=side_a, parts=parts_main, zws=ws, tag="main", newg=newg)
         if not use_side:
             keep_all += _lstm_backward(sv["local"], dh_l, pk["l_whh"], [None], 1, Hlp, Hl, K0, _ru(2 * Hl, 64), B, T, 0.0, seed, LOCAL_LAYER_ID, dev,
-                                       slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp))
+                                       slots_local, dG0, ldg, 8 * Hp, None, g, "rnn_local", k0_gather(Hl, Hlp), zws=ws, tag="local", newg=newg)
         else:
             for st_ in (side_a, side_b):                # join: dG0 is complete, every LSTM gradient is final
                 evj = torch.cuda.Event()
@@ -770,13 +827,13 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         #      convolutions on the calling stream; joined at the end.
         def wgrad(key, dz_hi, dz_lo, dzp, xt, xp, Fx, co, ci, KH, KW):
             if not use_side:
-                g[key] = conv_wgrad_direct(dz_hi, dz_lo, dzp, xt, xp, B, Fx, T, co, ci, KH, KW, torch.empty(co, ci, KH, KW, **f32))
+                g[key] = conv_wgrad_direct(dz_hi, dz_lo, dzp, xt, xp, B, Fx, T, co, ci, KH, KW, newg(key, co, ci, KH, KW))
                 return
             ev = torch.cuda.Event()
             ev.record(main_st)
             with torch.cuda.stream(side_a):
                 side_a.wait_event(ev)
-                g[key] = conv_wgrad_direct(dz_hi, dz_lo, dzp, xt, xp, B, Fx, T, co, ci, KH, KW, torch.empty(co, ci, KH, KW, **f32))
+                g[key] = conv_wgrad_direct(dz_hi, dz_lo, dzp, xt, xp, B, Fx, T, co, ci, KH, KW, newg(key, co, ci, KH, KW))
                 g[key].record_stream(main_st)
                 for t_ in (dz_hi, dz_lo, xt):           # allocated on the calling stream, read here: not to be reused before this is done
                     t_.record_stream(side_a)
@@ -847,7 +904,9 @@ class CnnRnnLargeTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         g = backward_train_large(ctx.model, ctx.sv, dlogits)
-        ctx.sv = None
+        direct = ctx.sv.get("direct_grads", set())
+        ctx.sv["ws"].busy = False                       # the step's workspace may serve the next forward (stream order: the backward
+        ctx.sv = None                                   # pass joined its side streams into the calling stream before it returned)
         if ctx.frame_only:
             # model(mel) of the reference's loop returns the frame logits only (cnn_rnn_model.py:343-349,
             # train_transcriber.py:119): the onset / offset heads are not part of the graph, their .grad stays None and
@@ -866,6 +925,8 @@ class CnnRnnLargeTrainFn(torch.autograd.Function):
         # passes before one step: a frame-only pass and a return_all_heads pass -> the heads DO have a gradient): intersection
         from .optim import note_params_without_grad
         note_params_without_grad(ctx.model, no_grad)
+        for n in direct:                                # already in the flat gradient buffer (see newg in backward_train_large)
+            g[n] = None
         return (None, None, None, None, None, None, None) + tuple(g[n] for n in ctx.names)
 
 
@@ -880,6 +941,7 @@ def train_forward_large(model, x: torch.Tensor, return_all_heads: bool = False):
         out = CnnRnnLargeTrainFn.apply(model, x, p, seed, p2d, names, frame_only, *params)
     else:
         out, sv = forward_train_large(model, x, p, seed, p2d)
+        sv["ws"].busy = False                           # no backward pass will follow
         model._train_sync = (sv["sync_all"], sv["sync_stride"])
     if model.use_onset_offset_heads and return_all_heads:
         return {"frame": out[0], "onset": out[1], "offset": out[2]}

@@ -454,3 +454,27 @@ def test_params_without_grad_is_an_intersection_over_backward_passes(mta):
     net._params_without_grad = None
     note_params_without_grad(net, heads); note_params_without_grad(net, heads)     # two frame-only passes: still skipped
     assert opt._keep_ranges() == [[0, 8]]
+
+
+def test_direct_gradient_targets_follow_torch_accumulation_semantics(mta):
+    """optim.FusedAdamClip.make_grad_target: a backward pass may write a parameter's gradient straight into its view of the flat gradient
+    buffer ONCE per zero_grad(); a second backward pass before step() gets None (its gradient goes through autograd and is added, as torch
+    accumulates), and so does a parameter whose .grad a caller detached (zero_grad(set_to_none=True)) or whose shape does not match."""
+    from music_transcription_amd.optim import FusedAdamClip
+    a, b = torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))
+    g = torch.zeros(17)
+    a.grad, b.grad = g[0:12].view(3, 4), g[12:17].view(5)
+    opt = FusedAdamClip.__new__(FusedAdamClip)
+    opt.g, opt._views, opt._touched, opt.net = g, [(a, 0, 12), (b, 12, 5)], set(), None
+    target = opt.make_grad_target({"a": a, "b": b})
+    t = target("a", (3, 4))
+    assert t is not None and t.data_ptr() == g.data_ptr() and t.shape == (3, 4)
+    t.fill_(2.0)
+    assert float(a.grad.sum()) == 24.0                              # the view IS the parameter's gradient
+    assert target("a", (3, 4)) is None                               # second backward before step(): accumulate through autograd
+    assert target("b", (4,)) is None and target("c", (1,)) is None   # wrong size / unknown parameter
+    b.grad = None                                                    # a caller's zero_grad(set_to_none=True)
+    assert target("b", (5,)) is None
+    b.grad = g[12:17].view(5)
+    opt.g.zero_(); opt._touched = set()                              # = zero_grad()
+    assert target("a", (12,)) is not None and target("b", (5,)) is not None
