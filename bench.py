@@ -211,13 +211,20 @@ def bench_train(args):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    segs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
+    host = []
     for j in range(K):
+        th = time.perf_counter()
         loss = step(j)
+        host.append(time.perf_counter() - th)
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    log(f"train: host enqueue {1e3 * t_host / K:.2f} ms per step ({', '.join(f'{1e3 * v:.1f}' for v in host)}), device allocations inside the timed region: "
+        f"{torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - segs0}, reserved {torch.cuda.memory_reserved(dev) / 2 ** 30:.1f} GiB")
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)

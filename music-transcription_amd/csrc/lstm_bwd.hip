@@ -47,7 +47,7 @@ struct LstmBwdArgs {
     const float* dh;      // [NG][T][2][NKB][8][32]
     const float* w_hh;    // [2][4H][H]
     bf16_t* dgx;          // [NG][T][2][NW][8][64][8]
-    void* part;           // [NG][T][2][NW consumer][NW producer][8][32][4] bf16 partial products, poisoned before every launch
+    void* part;           // [NG][T][2][NW consumer][NW producer][8][32 (16 when B <= 16)][4] bf16 partial products, poisoned before every launch
     unsigned* flags;      // (unused by the flagless hand-off)
     unsigned* status;     // abort word, zeroed before every launch
     int B, T, H;
@@ -132,7 +132,10 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
     const float* cx_g = a.cx + g * g_blocks * 256;
     const float* dh_g = a.dh + g * g_blocks * 256;
     char* dgx_g = (char*)a.dgx + g * ((size_t)T * 2 * NW * 8 * 1024);
-    const size_t part_bytes = (size_t)T * 2 * NW * NW * 2048;
+    // a slice = one producer's partial products for one consumer: 32 units x 32 batch columns of bf16 = 2 KB; ONE (B <= 16) keeps the 16 live
+    // batch columns only -- 1 KB slices: half the workspace, half the poison fill in front of every launch (0.5 GB instead of 1 GB at H = 512)
+    constexpr int SL = ONE ? 1024 : 2048, SLB = ONE ? 16 : 32;
+    const size_t part_bytes = (size_t)T * 2 * NW * NW * SL;
     char* part_g = (char*)a.part + g * part_bytes;
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(part_g, 0, (int)part_bytes, 0x00020000);
     if (tid == 0) abort_s = 0;
@@ -197,13 +200,13 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
             //      loads poll the poison pattern (as lstm.hip); the short sleep keeps the certain-to-fail first attempt,
             //      issued right behind this workgroup's own publish, off the fabric.
             // (ONE: the 4-byte half of the word that holds this thread's unit; the other unit of the half is dropped below)
-            const int gbase = (((tn * 2 + d) * NW + w) * NW) * 2048 + (wv * 32 + cb) * 8 + (ONE ? ((lane >> 5) & 1) : hh) * 4;
+            const int gbase = (((tn * 2 + d) * NW + w) * NW) * SL + (wv * SLB + cb) * 8 + (ONE ? ((lane >> 5) & 1) : hh) * 4;
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
                 unsigned raw[TPW * 8];
 #pragma unroll
                 for (int i = 0; i < TPW * 8; ++i)
-                    raw[i] = (i < NW) ? __builtin_amdgcn_raw_buffer_load_b32(prsrc, gbase + i * 2048, 0, 16 /*sc1*/) : 0u;
+                    raw[i] = (i < NW) ? __builtin_amdgcn_raw_buffer_load_b32(prsrc, gbase + i * SL, 0, 16 /*sc1*/) : 0u;
                 unsigned worst = 0;
                 float sum[2] = {0.0f, 0.0f};
 #pragma unroll
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
 #pragma unroll
                     for (int ks2 = 0; ks2 < 4; ++ks2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[mt][ks2], bfr[ks2], acc, 0, 0, 0);
                     // lane (batch bb, kg): results = units 16 (mt & 1) + 4 kg + (0..3) of consumer wc: word (unit/4 = 4 (mt & 1) + kg, batch bb)
-                    const int obase = (((t * 2 + d) * NW + wc) * NW + w) * 2048 + ((4 * (mt & 1) + kg) * 32 + bb) * 8;
+                    const int obase = (((t * 2 + d) * NW + wc) * NW + w) * SL + ((4 * (mt & 1) + kg) * SLB + bb) * 8;
                     const u32x2 v = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3])};
                     __builtin_amdgcn_raw_buffer_store_b64(v, prsrc, obase, 0, 16 /*sc1: write-through*/);
                 }
@@ -465,7 +468,7 @@ extern "C" size_t mt_lstm_cx_bytes(int B, int T, int H) { return (size_t)((B + 3
 // sync_ws: >= mt_lstm_sync_bytes(B, H) bytes (word 0 = status, flags from byte 256)
 extern "C" size_t mt_lstm_bwd_part_bytes(int B, int T, int H) {
     const size_t NW = (H + 31) / 32;
-    return (size_t)((B + 31) / 32) * T * 2 * NW * NW * 2048;
+    return (size_t)((B + 31) / 32) * T * 2 * NW * NW * (B <= 16 ? 1024 : 2048);      // (B <= 16: 16-column slices, see lstm_bptt_kernel)
 }
 
 // Fill a partial-product workspace with the poison pattern the hand-off polls (mt_lstm_bidir_bwd does it itself unless told
@@ -483,7 +486,7 @@ extern "C" int mt_lstm_bidir_bwd_ex(const float* gates, const float* cx, const f
     MT_REQUIRE(gates && cx && dh && w_hh && dgx && part_ws && sync_ws, MT_EINVAL, "mt_lstm_bidir_bwd: null pointer");
     MT_REQUIRE(B > 0 && T > 0 && H >= 16 && H % 16 == 0 && H <= 512, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: H=%d unsupported (16..512, multiple of 16)", H);
     const int NG = (B + 31) / 32, NW = (H + 31) / 32;
-    MT_REQUIRE((size_t)T * 2 * NW * NW * 2048 < (size_t)1 << 31, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: T=%d too long for one buffer descriptor", T);
+    MT_REQUIRE((size_t)T * 2 * NW * NW * (B <= 16 ? 1024 : 2048) < (size_t)1 << 31, MT_EUNSUPPORTED, "mt_lstm_bidir_bwd: T=%d too long for one buffer descriptor", T);
     MT_REQUIRE(part_bytes >= mt_lstm_bwd_part_bytes(B, T, H), MT_EWORKSPACE, "mt_lstm_bidir_bwd: partial-product workspace %zu < %zu", part_bytes,
                mt_lstm_bwd_part_bytes(B, T, H));
     MT_REQUIRE(sync_bytes >= 256, MT_EWORKSPACE, "mt_lstm_bidir_bwd: sync workspace too small");
