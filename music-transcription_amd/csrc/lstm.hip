@@ -452,6 +452,182 @@ __global__ __launch_bounds__(XP ? 256 : 320, XP ? 1 : (NKSW > 8 ? 2 : 4)) void l
 #endif
 }
 
+// ---- B <= 16: one batch group with at most 16 live columns (round 4: the training step's shape, BASELINE configs[3] = 16 chunks per GPU; short
+// recordings at inference).  lstm_rec_kernel's 32x32x16 tiles are then half padding: half of the gathered h bytes, of the MFMA passes and of the
+// cell lanes work on columns nobody reads.  Same decomposition, hand-off, loader wave and hx / gx / gates / cx layouts, but on v_mfma_f32_16x16x32_f16:
+//   * gate rows in the order row = 16 mt + 4 rg + p  <->  unit 4 mt + rg, gate p (two 16-row tiles), so that lane (column n = lane & 15, rg = lane >> 4)
+//     of the accumulator holds the four gates of ONE unit: the cell update is lane-local in waves 0 and 1 (tile mt = wave);
+//   * K is split over the four waves in 32-wide k-steps (NK = ceil(H / 32 / 4) per wave): 2 NK MFMAs of 8 passes where the 32-column kernel runs
+//     2 NK of 16 passes, and NK 16-byte gather loads per lane instead of 2 NK: a B fragment is (k group kg = lane >> 4, column n) = 16 bytes of the
+//     SAME published image -- 16-wide k-step 2 ks2 + (kg >> 1), lane (kg & 1) * 32 + n;
+//   * the cross-wave sum moves 2 x 16 bytes per lane into LDS and 4 x 16 bytes out (was 4 and 4);
+//   * the published block keeps all 32 batch rows (rows >= 16 are zeros from an LDS image that is cleared once), so every reader of hx sees
+//     what the 32-column kernel would have written.
+template <int NK, bool TRAIN, bool G16>
+__global__ __launch_bounds__(320, 4) void lstm_rec16_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[4][2][64][4];     // [k-slice wave][tile][lane][4 rows]
+    __shared__ __attribute__((aligned(16))) f16_t hs[32][8];            // [batch][unit]
+    constexpr int GX_RING = 6;
+    constexpr int GX_DMA = G16 ? 2 : 4;
+    __shared__ __attribute__((aligned(16))) float gring[GX_RING][G16 ? 512 : 1024];
+    __shared__ int abort_s;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int H = a.H, T = a.T, nkb = H >> 3, nks = H >> 4;
+    const int kb = blockIdx.x, d = blockIdx.y, g = blockIdx.z + a.g0;
+    const int Bg = min(16, a.B - g * 32);
+    const size_t gd_blocks = (size_t)T * 2 * nkb;
+
+    if (wv == 4) {          // ---- the loader wave (as in lstm_rec_kernel, one batch group): slot n = step n lives in gring[n % GX_RING]
+        typedef __attribute__((address_space(1))) void gvoid_t;
+        typedef __attribute__((address_space(3))) void lvoid_t;
+        int is = 0;
+        auto request = [&](int n) {
+            const int tn = d ? (T - 1 - is) : is;
+            const size_t blk = (size_t)g * gd_blocks + ((size_t)tn * 2 + d) * nkb + kb;
+            const char* src = (const char*)a.gx + blk * (G16 ? 2048 : 4096) + lane * 16;
+            char* dst = (char*)&gring[n % GX_RING][0];
+#pragma unroll
+            for (int qq = 0; qq < GX_DMA; ++qq) __builtin_amdgcn_global_load_lds((gvoid_t*)(src + qq * 1024), (lvoid_t*)(dst + qq * 1024), 16, 0, 0);
+            ++is;
+        };
+        for (int n = 0; n < GX_RING - 1 && n < T; ++n) request(n);
+        if (GX_RING - 1 <= T) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GX_DMA * (GX_RING - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int n = 0; n < T; ++n) {
+            if (n + GX_RING - 1 < T) {
+                request(n + GX_RING - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(GX_DMA * (GX_RING - 2)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();                             // the step's reduce barrier
+            int ab;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ab) : "v"((unsigned)(size_t)(lvoid_t*)&abort_s) : "memory");
+            if (ab) return;
+            __builtin_amdgcn_s_barrier();                             // the step's publish barrier
+        }
+        return;
+    }
+
+    // ---- W_hh slice as 16x16x32 A operands: lane (row rr = lane & 15, k group kg = lane >> 4) holds W[row][32 ks2 + 8 kg + j], j = 0..7;
+    //      tile mt, row rr <-> unit 4 mt + (rr >> 2), gate rr & 3
+    const int rr = lane & 15, kg = lane >> 4;
+    f16x8 w16[2][NK];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int wrow = (rr & 3) * H + kb * 8 + 4 * mt + (rr >> 2);
+        const float* wsrc = a.w_hh + ((size_t)d * 4 * H + wrow) * H;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int k0 = (wv * NK + i) * 32 + 8 * kg, k0c = min(k0, H - 8);     // (clamped address + select: the loads pipeline)
+            const f32x4 w0 = *(const f32x4*)(wsrc + k0c), w1 = *(const f32x4*)(wsrc + k0c + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w16[mt][i][j] = (k0 < H) ? (f16_t)w0[j] : (f16_t)0.0f;
+                w16[mt][i][4 + j] = (k0 < H) ? (f16_t)w1[j] : (f16_t)0.0f;
+            }
+        }
+    }
+    // this thread's cell (waves 0 and 1): unit jl = 4 wv + rg of the workgroup, batch column n
+    const int n = lane & 15, rg = lane >> 4, jl = 4 * (wv & 1) + rg;
+    const bool owner = wv < 2;
+    float c = 0.0f;
+    char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
+    if (tid == 0) abort_s = 0;
+    if (tid < 128) ((unsigned*)&hs[0][0])[tid] = 0u;                      // (rows >= 16 stay zero)
+    __syncthreads();
+
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+    int ring = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = d ? (T - 1 - s) : s;
+        const int tprev = d ? (t + 1) : (t - 1);
+        float gxv[4];
+        if (G16) {
+            unsigned short raw[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) raw[pp] = ((const unsigned short*)gring[ring])[pp * 256 + jl * 32 + n];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) gxv[pp] = (float)__builtin_bit_cast(f16_t, raw[pp]);
+        } else {
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) gxv[pp] = gring[ring][pp * 256 + jl * 32 + n];
+        }
+        ring = ring + 1 == GX_RING ? 0 : ring + 1;
+        f32x4 acc[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        if (s > 0) {
+            sleep64(a.sleep_first);
+            // B fragment of k32-step ks2: 16-wide k-step 2 ks2 + (kg >> 1), image lane (kg & 1) * 32 + n
+            const int hbase = ((tprev * 2 + d) * nkb) * 512 + ((kg & 1) * 32 + n) * 16 + (kg >> 1) * 1024;
+            long long t1 = 0;
+            for (unsigned it = 0;; ++it) {
+                u32x4 hq[NK];
+#pragma unroll
+                for (int i = 0; i < NK; ++i) {
+                    const int ks = 2 * (wv * NK + i) + (kg >> 1);
+                    hq[i] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, (ks < nks) ? hbase + (wv * NK + i) * 2048 : OOB_OFF, 0, 16 /*sc1*/);
+                }
+                unsigned worst = 0;
+#pragma unroll
+                for (int i = 0; i < NK; ++i) {
+                    worst = max(max(worst, max(hq[i][0], hq[i][1])), max(hq[i][2], hq[i][3]));
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w16[0][i], __builtin_bit_cast(f16x8, hq[i]), acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w16[1][i], __builtin_bit_cast(f16x8, hq[i]), acc[1], 0, 0, 0);
+                }
+                if (!__any(worst == H_POISON)) break;
+                acc[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                sleep64(a.sleep_retry);
+                if ((it & 63u) == 63u && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    if (lane == 0) abort_s = 1;
+                    break;
+                }
+                if ((it & 255u) == 255u) {
+                    const long long now = __builtin_amdgcn_s_memrealtime();
+                    if (t1 == 0) t1 = now;
+                    else if (now - t1 > LSTM_SPIN_LIMIT_TICKS) {
+                        if (lane == 0) {
+                            __hip_atomic_store(a.status, 0x40000000u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            abort_s = 1;
+                        }
+                        break;
+                    }
+                }
+            }
+        }
+        // ---- sum the four K slices through LDS
+        *(f32x4*)(&red[wv][0][lane][0]) = acc[0];
+        *(f32x4*)(&red[wv][1][lane][0]) = acc[1];
+        __syncthreads();
+        if (abort_s) return;
+        if (owner) {
+            const int mt = wv;
+            const f32x4 r0 = *(const f32x4*)(&red[0][mt][lane][0]), r1 = *(const f32x4*)(&red[1][mt][lane][0]);
+            const f32x4 r2 = *(const f32x4*)(&red[2][mt][lane][0]), r3 = *(const f32x4*)(&red[3][mt][lane][0]);
+            float pre[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + (n < Bg ? gxv[pp] : 0.0f);
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
+            c = fmaf(fg, c, ig * gg);
+            const float hval = og * tanhf_(c);
+            if (TRAIN && n < Bg) {
+                float* go = a.gates_out + (size_t)g * gd_blocks * 1024 + (((size_t)t * 2 + d) * nkb + kb) * 1024 + jl * 32 + n;
+                go[0] = ig; go[256] = fg; go[512] = gg; go[768] = og;
+                a.cx[(size_t)g * gd_blocks * 256 + (((size_t)t * 2 + d) * nkb + kb) * 256 + jl * 32 + n] = c;
+            }
+            hs[n][jl] = (f16_t)hval;
+        }
+        __syncthreads();                                          // the 512-B piece is assembled; every wave is done with `red`
+        if (wv == 0) {
+            const u32x4 piece = *(const u32x4*)(&hs[lane & 31][0]);
+            const int hoff = ((t * 2 + d) * nkb) * 512 + (kb >> 1) * 1024 + ((kb & 1) * 32 + (lane & 31)) * 16;
+            __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, lane < 32 ? hoff : OOB_OFF, 0, 16 /*sc1: write-through*/);
+        }
+    }
+}
+
 // Layer output for (g, t, d): nks blocks of 1 KB: [lane = (k half)*32 + batch][8 f16], k = 16 ks + 8 half + j.
 // hx -> X[(t*B + b)][d*H + k] bf16 (next layer's GEMM A matrix), round-to-nearest.
 // H = layout hidden size (multiple of 16), Hv <= H = real hidden size (units >= Hv are zero padding and are
@@ -527,6 +703,15 @@ int persistent_cancel(hipStream_t st);
 
 template <int NKSW>
 static int launch_rec(const LstmArgs& a, int ngroups, bool g16, hipStream_t st) {
+    // B <= 16 (one batch group, at most 16 live columns): the 16-column kernel (MT_LSTM_C16=0 keeps the 32-column one)
+    static const bool c16 = !(getenv("MT_LSTM_C16") && atoi(getenv("MT_LSTM_C16")) == 0);
+    constexpr int NK16 = (NKSW + 1) / 2;                       // 32-wide k-steps per wave
+    if (c16 && !a.w_ihx && a.B <= 16 && ngroups == 1 && NKSW <= 8) {
+        if (a.cx) MT_PERSISTENT_LAUNCH_N((lstm_rec16_kernel<NK16, true, false>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd_train");
+        else if (g16) MT_PERSISTENT_LAUNCH_N((lstm_rec16_kernel<NK16, false, true>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd");
+        else MT_PERSISTENT_LAUNCH_N((lstm_rec16_kernel<NK16, false, false>), dim3(a.H >> 3, 2, 1), 320, "mt_lstm_bidir_fwd");
+        return MT_OK;
+    }
     if (a.w_ihx) MT_PERSISTENT_LAUNCH((lstm_rec_kernel<NKSW, false, true>), dim3(a.H >> 3, 2, ngroups), "mt_lstm_bidir_fwd_xproj");
     else if (a.cx) MT_PERSISTENT_LAUNCH_N((lstm_rec_kernel<NKSW, true, false>), dim3(a.H >> 3, 2, ngroups), 320, "mt_lstm_bidir_fwd_train");
     // (H > 512: a workgroup's W_hh slice takes 64 registers per lane and the interleaved variants would spill: one group per workgroup)
