@@ -62,7 +62,9 @@ template <int RB> __device__ __forceinline__ int cw_tr_addr(int lane, int row0, 
 }
 
 // CO_W: 64-channel tiles of dz per workgroup (1, 2); CI_W: 32-channel tiles of x per workgroup (1, 2, 4); TAPS: kernel columns (3, 1)
-template <int CO_W, int CI_W, int TAPS>
+// LO: dz comes as two bf16 pieces (value + rounding remainder: two DMA images, two MFMAs per fragment pair).  Round 4 measured that the
+// second piece buys nothing the gradient can use (train_step_large.py: MT_TRAIN_DZ_LO): LO = false skips its image, reads and MFMAs.
+template <int CO_W, int CI_W, int TAPS, bool LO>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(CwArgs a) {
     constexpr int KS = 8 / (CO_W * CI_W);                  // waves per (co, ci) wave tile: they split the 16-position steps
     constexpr int DR = 128 * CO_W;                         // bytes per dz image row (one image per piece)
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(CwArgs a) {
             const int j = j0 * 8 + wv;                      // wave-uniform
             if (j < 2 * D_NI) {
                 const int piece = j / D_NI, jj = j % D_NI;
+                if (!LO && piece == 1) continue;            // (no second image: its LDS slot stays unused)
                 const int row = jj * D_RPI + d_rl;
                 const bool ok = t0 + row < a.T && (piece == 0 || has_lo);
                 const int voff = ok ? d_voff + d_base + jj * D_RPI * a.dz_pitch * 2 : 0x7fffffff;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(CwArgs a) {
             if (KS > 1 && (((it << 2) | s) & (KS - 1)) != ks) continue;
             bf16x8 fa[2][2], fb[TAPS];
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc)
+            for (int pc = 0; pc < (LO ? 2 : 1); ++pc)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const char* p = st + pc * D_BYTES + a_addr[m] + s * 16 * DR;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(CwArgs a) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     acc[kw][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][m], fb[kw], acc[kw][m], 0, 0, 0);
-                    acc[kw][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[kw], acc[kw][m], 0, 0, 0);
+                    if (LO) acc[kw][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][m], fb[kw], acc[kw][m], 0, 0, 0);
                 }
         }
         cur ^= 1;
@@ -260,18 +263,17 @@ extern "C" int mt_conv_wgrad(const void* dz_hi, const void* dz_lo, int dz_pitch,
     CwArgs a{(const bf16_t*)dz_hi, (const bf16_t*)dz_lo, (const bf16_t*)x, (float*)ws, dz_pitch, x_pitch, B, F, T, Cout, Cin, KH, p.S, cdiv(T, 64)};
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(p.nc * p.S);
-#define CW_LAUNCH(CO_W, CI_W, TAPS)                                                                                          \
+#define CW_LAUNCH_LO(CO_W, CI_W, TAPS, LO_)                                                                                  \
     do {                                                                                                                     \
         constexpr int DR_ = 128 * CO_W, XR_ = 64 * CI_W, XROWS_ = TAPS == 3 ? 66 : 64;                                       \
         constexpr int LDS_ = 2 * (2 * (64 / (1024 / DR_)) * 1024 + ((XROWS_ + 1024 / XR_ - 1) / (1024 / XR_)) * 1024);       \
-        static bool attr_set[16] = {};                                                                                       \
-        int dev_ = 0;                                                                                                        \
-        MT_CHECK_HIP(hipGetDevice(&dev_));                                                                                   \
-        if (dev_ >= 0 && dev_ < 16 && !attr_set[dev_]) {                                                                     \
-            MT_CHECK_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<CO_W, CI_W, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_)); \
-            attr_set[dev_] = true;                                                                                           \
-        }                                                                                                                    \
-        hipLaunchKernelGGL((conv_wgrad_kernel<CO_W, CI_W, TAPS>), grid, dim3(512), LDS_, st, a);                             \
+        MT_SET_MAX_LDS((conv_wgrad_kernel<CO_W, CI_W, TAPS, LO_>), LDS_);                                                    \
+        hipLaunchKernelGGL((conv_wgrad_kernel<CO_W, CI_W, TAPS, LO_>), grid, dim3(512), LDS_, st, a);                        \
+    } while (0)
+#define CW_LAUNCH(CO_W, CI_W, TAPS)                                                                                          \
+    do {                                                                                                                     \
+        if (dz_lo) CW_LAUNCH_LO(CO_W, CI_W, TAPS, true);                                                                     \
+        else CW_LAUNCH_LO(CO_W, CI_W, TAPS, false);                                                                          \
     } while (0)
 #define CW_DISPATCH(TAPS)                                                  \
     do {                                                                   \
@@ -286,6 +288,7 @@ extern "C" int mt_conv_wgrad(const void* dz_hi, const void* dz_lo, int dz_pitch,
     else CW_DISPATCH(1);
 #undef CW_DISPATCH
 #undef CW_LAUNCH
+#undef CW_LAUNCH_LO
     MT_CHECK_LAUNCH();
     const size_t n = (size_t)KH * KW * Cout * Cin;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const float*)ws, p.S * p.ks, KH, KW, Cout, Cin, out);

@@ -825,6 +825,14 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         # ---- convolution stack.  Weight gradients (csrc/conv_wgrad.hip: matrix-pipe bound, at most one workgroup per CU) go to side
         #      stream A as soon as their dz exists, beside the chain of BatchNorm backward passes (HBM bound) and input-gradient
         #      convolutions on the calling stream; joined at the end.
+        # Second bf16 piece of every dz (round 2: dz = hi + lo through the weight-gradient sums)?  Round 4: no.  Rounding dz to ONE bf16 adds
+        # zero-mean noise of 2^-9 per term to sums over 10^5 - 10^6 positions: ~1e-4 of a gradient entry by the estimate in DESIGN.md 2, four
+        # orders of magnitude under the gradient's own sensitivity to last-bit forward differences (profiles/r04_oracle_noise_floor.txt) -- and
+        # it cost 2.5 GB of writes in the BatchNorm backward kernels, the same in reads and HALF of the 5.3 TFLOP of the seven weight-gradient
+        # launches.  MT_TRAIN_DZ_LO=1 brings the second piece back (A/B).
+        use_lo = os.environ.get("MT_TRAIN_DZ_LO", "0") == "1"
+        lo_like = (lambda t_: torch.empty_like(t_)) if use_lo else (lambda t_: None)
+
         def wgrad(key, dz_hi, dz_lo, dzp, xt, xp, Fx, co, ci, KH, KW):
             if not use_side:
                 g[key] = conv_wgrad_direct(dz_hi, dz_lo, dzp, xt, xp, B, Fx, T, co, ci, KH, KW, newg(key, co, ci, KH, KW))
@@ -836,11 +844,13 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
                 g[key] = conv_wgrad_direct(dz_hi, dz_lo, dzp, xt, xp, B, Fx, T, co, ci, KH, KW, newg(key, co, ci, KH, KW))
                 g[key].record_stream(main_st)
                 for t_ in (dz_hi, dz_lo, xt):           # allocated on the calling stream, read here: not to be reused before this is done
-                    t_.record_stream(side_a)
+                    if t_ is not None:
+                        t_.record_stream(side_a)
         # ---- freq_aware_conv
         masks = sv["masks"]
         z256 = pk["zeros256"]
-        dzf, dzf_lo = torch.empty(B * F2 * T, 256, **bf), torch.empty(B * F2 * T, 256, **bf)
+        dzf = torch.empty(B * F2 * T, 256, **bf)
+        dzf_lo = lo_like(dzf)
         g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"] = torch.empty(256, **f32), torch.empty(256, **f32)
         _bn_act_bwd(None, 0, dX0, K0, sv["zf"], sv["sf"], None, None, masks[2], dzf, None,
                     (g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"], None, None), B, F2, T, 256, 1, 1, dev, dza_lo=dzf_lo)
@@ -855,7 +865,8 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             st = sv[name]
             cin, cout, pool, Fin, xin = st["cin"], st["cout"], st["pool"], st["Fin"], st["xin"]
             N = B * Fin * T
-            dz2, dzs, dz2_lo, dzs_lo = (torch.empty(N, cout, **bf) for _ in range(4))
+            dz2, dzs = torch.empty(N, cout, **bf), torch.empty(N, cout, **bf)
+            dz2_lo, dzs_lo = lo_like(dz2), lo_like(dzs)
             gr = {k: torch.empty(cout, **f32) for k in ("bn2.weight", "bn2.bias", "skip.1.weight", "skip.1.bias", "bn1.weight", "bn1.bias")}
             _bn_act_bwd(dout, cout, None, 0, st["z2"], st["s2"], st["zs"], st["ss"], st["mask"], dz2, dzs,
                         (gr["bn2.weight"], gr["bn2.bias"], gr["skip.1.weight"], gr["skip.1.bias"]), B, Fin, T, cout, 1, pool, dev,
@@ -865,7 +876,8 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             wgrad(pfx + ".skip.0.weight", dzs, dzs_lo, cout, xin, cin, Fin, cout, cin, 1, 1)
             dy1 = torch.empty(N, cout, **bf)
             _conv(dz2, None, pk[name + "c2_wd"], z256, dy1, B, Fin, T, cout, 0, cout, 3)
-            dz1, dz1_lo = torch.empty(N, cout, **bf), torch.empty(N, cout, **bf)
+            dz1 = torch.empty(N, cout, **bf)
+            dz1_lo = lo_like(dz1)
             _bn_act_bwd(dy1, cout, None, 0, st["z1"], st["s1"], None, None, None, dz1, None, (gr["bn1.weight"], gr["bn1.bias"], None, None),
                         B, Fin, T, cout, 1, 0, dev, dza_lo=dz1_lo)
             cin_p = max(cin, 64)
