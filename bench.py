@@ -583,7 +583,7 @@ def section_train_large(mta, dev, cores, do_cpu):
     backward + fused clip/Adam, with the step's stream plan (LSTM weight gradients beside the next backward recurrence, the local
     layer's chain beside the main stack).  The roofline object is the WHOLE step against the bf16 matrix peak (3 x forward FLOPs)."""
     import torch
-    B, K, W, T = 16, 4, 2, 937
+    B, K, W, T = 16, 8, 2, 937
     g = torch.Generator().manual_seed(1234)
     model = seeded_model(mta, "cnn_rnn_large", str(dev), dropout=0.2)
     opt = mta.make_optimizer(model, lr=1e-4)
@@ -610,11 +610,19 @@ def section_train_large(mta, dev, cores, do_cpu):
     from music_transcription_amd.train_step_large import autotune_side_streams
     tuned = autotune_side_streams(step, dev, candidates=4, steps=1)
     torch.cuda.synchronize()
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
+    marks = []
     for _ in range(K):
         loss = step()
+        e_ = torch.cuda.Event(enable_timing=True)
+        e_.record()
+        marks.append(e_)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    per_step = [round(marks[i].elapsed_time(marks[i + 1]), 2) for i in range(K - 1)]
+    log(f"train_large_b16: steps (ms, event to event) {per_step}, device allocations in the timed region "
+        f"{torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - allocs0}")
     model.model.raise_on_train_handoff_timeout()
     tf = 3.0 * 326.47e9 * B * T / 938.0 * K / el / 1e12
     sec = {"workload": "CNNRNNModelLarge training step (example.sh:22's model), batch=16 cached-format chunks, 1 GPU",
@@ -623,7 +631,7 @@ def section_train_large(mta, dev, cores, do_cpu):
            "roofline": {"kernel": "whole training step (3 x forward FLOPs)", "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
                         "per_kernel": "profiles/r04_train_large_b16_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --mode train --model cnn_rnn_large`)"},
-           "final_loss": round(float(loss.item()), 5),
+           "final_loss": round(float(loss.item()), 5), "steps_ms_event_to_event": per_step,
            "side_stream_autotune_ms_per_step": [round(1e3 * t, 2) for t in tuned]}
     if do_cpu:
         from oracle import model_ref

@@ -425,6 +425,12 @@ int    mt_bn_pool_bwd_tie(const float* dX, int ldd, const void* z, const float* 
 int    mt_conv2_wgrad_workgroups(void);
 int    mt_conv2_wgrad(const void* a1, const void* dz_hi, const void* dz_lo, float* P, float* Pb, int n_wg,
                       int B, int F, int T, mt_stream_t stream);
+/* Layer-0 W_ih of one direction of an nn.LSTM (f32 [4H][C*F], reference feature order c*F + f: models/cnn_rnn_model.py:60-62,
+ * :292-294) -> rows row0 + p*Hp + j of the projection GEMM's 16-bit operand `out` (row pitch ldo elements) in the kernels' feature
+ * order f*C + c; rows j in [H, Hp) are written as zeros.  dt = MT_DT_BF16 | MT_DT_F16.  C*(F|1)*4 bytes of LDS (<= 64 KB).
+ * What _pack_bilstm (music-transcription_amd/model.py) did with an index gather + cast per direction.                     */
+int    mt_pack_wih_cf(const float* w, void* out, long long ldo, int row0, int H, int Hp, int C, int F, int dt,
+                      mt_stream_t stream);
 /* dst[c*ldd + r] = src[r*lds + c] (bf16), r < R, c < C; every dst element with c < Cd, r < ldd is written
  * (zero outside the source).                                                                               */
 int    mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd,

@@ -733,6 +733,45 @@ extern "C" int mt_conv2_wgrad(const void* a1, const void* dz_hi, const void* dz_
     return MT_OK;
 }
 
+// Layer-0 W_ih of one direction of an nn.LSTM (f32 [4H][K], reference feature order k = c * F + f: channel-major, cnn_rnn_model.py:60-62 /
+// :292-294) -> rows of the projection GEMM's 16-bit operand in the kernels' feature order f * C + c (what conv2 / freq_aware_conv write):
+//   out[(row0 + p * Hp + j) * ldo + f * C + c] = h16(w[(p * H + j) * K + c * F + f]),  rows j in [H, Hp) zero.
+// One workgroup per output row: the source row is read contiguously, turned around in LDS ([c][F + 1]: conflict-free for the odd pitch), written
+// contiguously.  Replaces torch's index gather + cast (4 launches of 138 us per training step of CNNRNNModelLarge: the optimizer moves the f32
+// weights every step, so the operands are re-packed every step).
+template <int DT>
+__global__ __launch_bounds__(256) void pack_wih_cf_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, long long ldo, int row0,
+                                                          int H, int Hp, int C, int F) {
+    extern __shared__ float rowbuf[];
+    const int r = blockIdx.x, p = r / Hp, j = r - p * Hp, K = C * F, FP = F | 1;
+    bf16_t* o = out + (size_t)(row0 + r) * ldo;
+    if (j >= H) {
+        for (int i = threadIdx.x; i < K; i += 256) o[i] = 0;
+        return;
+    }
+    const float* src = w + ((size_t)p * H + j) * K;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        const int c = i / F, f = i - c * F;
+        rowbuf[c * FP + f] = src[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256) {
+        const int f = i / C, c = i - f * C;
+        o[i] = f32_to_h16<DT>(rowbuf[c * FP + f]);
+    }
+}
+
+extern "C" int mt_pack_wih_cf(const float* w, void* out, long long ldo, int row0, int H, int Hp, int C, int F, int dt, mt_stream_t stream) {
+    MT_REQUIRE(w && out && H > 0 && Hp >= H && C > 0 && F > 0 && row0 >= 0 && ldo >= (long long)C * F, MT_EINVAL, "mt_pack_wih_cf: bad arguments");
+    MT_REQUIRE_DT(dt, "mt_pack_wih_cf");
+    const size_t lds = (size_t)C * (F | 1) * sizeof(float);
+    MT_REQUIRE(lds <= 64 * 1024, MT_EUNSUPPORTED, "mt_pack_wih_cf: a row of %d x %d features does not fit 64 KB of LDS", C, F);
+    if (dt == MT_DT_F16) hipLaunchKernelGGL(pack_wih_cf_kernel<MT_DT_F16>, dim3(4 * Hp), dim3(256), lds, ST(stream), w, (bf16_t*)out, ldo, row0, H, Hp, C, F);
+    else hipLaunchKernelGGL(pack_wih_cf_kernel<MT_DT_BF16>, dim3(4 * Hp), dim3(256), lds, ST(stream), w, (bf16_t*)out, ldo, row0, H, Hp, C, F);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
 extern "C" int mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd, mt_stream_t stream) {
     MT_REQUIRE(src && dst && R > 0 && C > 0 && lds >= C && ldd >= R && Cd >= C, MT_EINVAL, "mt_transpose_bf16: bad arguments");
     if (lds % 8 == 0 && ldd % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0)

@@ -65,13 +65,16 @@ def _pad2(t, rows, cols):
     return out
 
 
-def _pack_bilstm(rnn: nn.LSTM, layers: int, H: int, k0_cols, dev, dt: int = _lib.DT_BF16):
+def _pack_bilstm(rnn: nn.LSTM, layers: int, H: int, k0_cols, dev, dt: int = _lib.DT_BF16, k0_cf=None, wih0_out=None):
     """Pack a bidirectional nn.LSTM for mt_gemm_lstm_gx + mt_lstm_bidir_fwd (computed on `dev`: the training
     step re-packs after every optimizer step).  The hidden size is laid out padded to Hp = roundup(H, 16): a
     padded unit has zero weights and bias, so its gates are 0 and its c, h stay 0.  Gate row p*Hp + j;
     directions stacked [fwd; reverse]; layer 0's columns are re-ordered by `k0_cols` (index tensor: kernel
     column -> reference column); deeper layers take the compact [fwd H | reverse H] rows padded to
-    roundup(2H, 64) columns.  Returns (w_ih[], b_gates[], w_hh[])."""
+    roundup(2H, 64) columns.  Returns (w_ih[], b_gates[], w_hh[]).
+    k0_cf = (C, F): the re-ordering is kernel column f*C + c <- reference column c*F + f and layer 0's W_ih is packed by
+    mt_pack_wih_cf (one launch per direction instead of an index gather, a copy and a cast); wih0_out: a 16-bit tensor
+    [>= roundup(8 Hp, 128) rows][K] to pack it into (the caller owns the rows beyond 8 Hp)."""
     Hp = _round_up(H, 16)
     K1 = _round_up(2 * H, 64)
     k0 = k0_cols.to(dev)
@@ -79,17 +82,31 @@ def _pack_bilstm(rnn: nn.LSTM, layers: int, H: int, k0_cols, dev, dt: int = _lib
     for l in range(layers):
         K = k0.numel() if l == 0 else 2 * H
         Kp = K if l == 0 else K1
-        wcat = torch.zeros(_round_up(8 * Hp, 128), Kp, dtype=torch.float32, device=dev)
+        fast0 = l == 0 and k0_cf is not None and torch.device(dev).type == "cuda" and k0_cf[0] * (k0_cf[1] | 1) * 4 <= 64 * 1024
+        if fast0:
+            C_, F_ = k0_cf
+            assert C_ * F_ == K
+            w16 = wih0_out
+            if w16 is None:
+                w16 = torch.empty(_round_up(8 * Hp, 128), K, dtype=torch.float16 if dt == _lib.DT_F16 else torch.bfloat16, device=dev)
+                w16[8 * Hp:].zero_()
+            with torch.cuda.device(dev):
+                for di, suf in enumerate(("", "_reverse")):
+                    w = getattr(rnn, f"weight_ih_l0{suf}").detach()
+                    w = w if (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()) else w.to(dev, torch.float32).contiguous()
+                    _lib.check(_lib.lib.mt_pack_wih_cf(_lib.ptr(w), _lib.ptr(w16), K, di * 4 * Hp, H, Hp, C_, F_, dt, _lib.stream_ptr()), "mt_pack_wih_cf")
+        wcat = None if fast0 else torch.zeros(_round_up(8 * Hp, 128), Kp, dtype=torch.float32, device=dev)
         bcat = torch.zeros(2, 4, Hp, dtype=torch.float32, device=dev)
         hcat = torch.zeros(2, 4, Hp, Hp, dtype=torch.float32, device=dev)
         for di, suf in enumerate(("", "_reverse")):
-            w = getattr(rnn, f"weight_ih_l{l}{suf}").detach().to(dev, torch.float32)
-            w = w[:, k0] if l == 0 else w
-            wcat[di * 4 * Hp:(di + 1) * 4 * Hp].view(4, Hp, Kp)[:, :H, :K] = w.reshape(4, H, K)
+            if not fast0:
+                w = getattr(rnn, f"weight_ih_l{l}{suf}").detach().to(dev, torch.float32)
+                w = w[:, k0] if l == 0 else w
+                wcat[di * 4 * Hp:(di + 1) * 4 * Hp].view(4, Hp, Kp)[:, :H, :K] = w.reshape(4, H, K)
             b = (getattr(rnn, f"bias_ih_l{l}{suf}") + getattr(rnn, f"bias_hh_l{l}{suf}")).detach().to(dev, torch.float32)
             bcat[di, :, :H] = b.reshape(4, H)
             hcat[di, :, :H, :H] = getattr(rnn, f"weight_hh_l{l}{suf}").detach().to(dev, torch.float32).reshape(4, H, H)
-        w_ih.append(_h16(wcat, dt))
+        w_ih.append(w16 if fast0 else _h16(wcat, dt))
         b_g.append(bcat.reshape(-1).contiguous())
         w_hh.append(hcat.reshape(2, 4 * Hp, Hp).contiguous())
     return w_ih, b_g, w_hh
@@ -210,7 +227,7 @@ class CNNRNNModel(nn.Module, _HipForward):
         K1 = _round_up(2 * H, 64)
         # reference feature index c*Fo2+f (cnn_rnn_model.py:60-62) -> kernel column f*64+c
         cols = (torch.arange(64)[None, :] * Fo2 + torch.arange(Fo2)[:, None]).reshape(-1)
-        wi, bg, wh = _pack_bilstm(self.rnn, L, H, cols, device, dt)
+        wi, bg, wh = _pack_bilstm(self.rnn, L, H, cols, device, dt, k0_cf=(64, Fo2))
         for l in range(L):
             t[f"w_ih{l}"], t[f"b_g{l}"], t[f"w_hh{l}"] = wi[l], bg[l], wh[l]
         # layers > 0: W_ih in the layout of the fused input projection (mt_lstm_bidir_fwd_xproj): f32 [2][4Hp][2Hp],
@@ -383,7 +400,7 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
         w.fa_w, w.fa_b = put("fa_w", _h16(conv_cl(wf), dt)), put("fa_b", bf_)
         # reference feature index c*F3+f (cnn_rnn_model.py:292-294) -> kernel column f*256+c
         cols = (torch.arange(256)[None, :] * F3 + torch.arange(F3)[:, None]).reshape(-1)
-        wi, bg, wh = _pack_bilstm(self.rnn_main, L, H, cols, device, dt)
+        wi, bg, wh = _pack_bilstm(self.rnn_main, L, H, cols, device, dt, k0_cf=(256, F3))
         Hp = _round_up(H, 16)
         for l in range(L):
             t[f"m_wi{l}"], t[f"m_b{l}"], t[f"m_wh{l}"] = wi[l], bg[l], wh[l]
@@ -394,7 +411,7 @@ class CNNRNNModelLarge(nn.Module, _HipForward):
                 for di, suf in enumerate(("", "_reverse")):
                     wx[di, :, :H, :, :H] = getattr(self.rnn_main, f"weight_ih_l{l}{suf}").detach().to(device, torch.float32).reshape(4, H, 2, H)
                 t[f"m_wix{l}"] = wx.reshape(2, 4 * Hp, 2 * Hp).contiguous()
-        wi, bg, wh = _pack_bilstm(self.rnn_local, 1, Hl, cols, device, dt)
+        wi, bg, wh = _pack_bilstm(self.rnn_local, 1, Hl, cols, device, dt, k0_cf=(256, F3))
         t["l_wi"], t["l_b"], t["l_wh"] = wi[0], bg[0], wh[0]
         w.local_w_ih, w.local_b, w.local_w_hh = ptr(wi[0]), ptr(bg[0]), ptr(wh[0])
         if self.use_attention:

@@ -60,7 +60,7 @@ def pack_train(model, dev, part: str = "all") -> Dict[str, object]:
             t[f"be{i}"] = bn.bias.detach().to(**f32).contiguous()
     if part in ("all", "rnn"):
         cols = (torch.arange(64)[None, :] * Fo2 + torch.arange(Fo2)[:, None]).reshape(-1)             # kernel col f*64+c -> ref col c*Fo2+f
-        t["w_ih"], t["b_g"], t["w_hh"] = _pack_bilstm(model.rnn, L, H, cols, dev)
+        t["w_ih"], t["b_g"], t["w_hh"] = _pack_bilstm(model.rnn, L, H, cols, dev, k0_cf=(64, K0 // 64))
         t["w_ihT"] = []
         for l in range(L):
             K = K0 if l == 0 else K1

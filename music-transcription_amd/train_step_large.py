@@ -117,16 +117,23 @@ def _pack_upper(model, dev, t, d):
     g = lambda p: p.detach().to(**f32)
     # LSTMs (layer-0 columns re-ordered: reference feature c*F3+f -> kernel column f*256+c)
     cols = (torch.arange(256)[None, :] * F3 + torch.arange(F3)[:, None]).reshape(-1)
-    t["m_wih"], t["m_b"], t["m_whh"] = _pack_bilstm(model.rnn_main, L, H, cols, dev)
-    t["l_wih"], t["l_b"], t["l_whh"] = _pack_bilstm(model.rnn_local, 1, Hl, cols, dev)
+    # layer 0 of BOTH LSTMs into one 16-bit tensor [main 8 Hp rows; local 8 Hlp rows (+ tile slack)][K0]: the two forward projections read
+    # their own rows, and ONE transpose of the whole gives [W_ih_main; W_ih_local]^T for the input-gradient GEMM (was: two index gathers
+    # and casts per LSTM, a zero fill of the 126-MB transposed operand and two strided copies into it, every step)
+    R0, R1 = 8 * Hp, 8 * Hlp
+    wboth = torch.empty(R0 + _ru(R1, 128) + 128, K0, device=dev, dtype=bf)
+    wboth[R0 + R1:].zero_()
+    t["m_wih"], t["m_b"], t["m_whh"] = _pack_bilstm(model.rnn_main, L, H, cols, dev, k0_cf=(256, F3), wih0_out=wboth)
+    t["l_wih"], t["l_b"], t["l_whh"] = _pack_bilstm(model.rnn_local, 1, Hl, cols, dev, k0_cf=(256, F3), wih0_out=wboth[R0:])
     t["m_wihT"] = [None]
     for l in range(1, L):
         wT = torch.zeros(_ru(K1, 128), 8 * Hp, device=dev, dtype=bf)
         wT[:K1] = t["m_wih"][l][:8 * Hp].t()
         t["m_wihT"].append(wT)
-    wcat = torch.zeros(_ru(K0, 128), 8 * Hp + 8 * Hlp, device=dev, dtype=bf)   # dX0 = [dG_main | dG_local] . [W_ih_main; W_ih_local]
-    wcat[:K0, :8 * Hp] = t["m_wih"][0][:8 * Hp].t()
-    wcat[:K0, 8 * Hp:] = t["l_wih"][0][:8 * Hlp].t()
+    wcat = torch.empty(_ru(K0, 128), R0 + R1, device=dev, dtype=bf)             # dX0 = [dG_main | dG_local] . [W_ih_main; W_ih_local]
+    if _ru(K0, 128) > K0:
+        wcat[K0:].zero_()
+    check(lib.mt_transpose_bf16(ptr(wboth), K0, R0 + R1, K0, ptr(wcat), R0 + R1, K0, _st()), "mt_transpose_bf16")
     t["ml_wihT"] = wcat
     if model.use_attention:
         heads, dh = model.attention.num_heads, model.attention.head_dim
