@@ -193,11 +193,25 @@ class _StepWorkspace:
         return t
 
 
+    def buffer(self, name, nbytes, device):
+        """Persistent UNINITIALISED scratch (the backward recurrences' hand-off workspaces, re-poisoned before every use on a side stream:
+        as per-step allocations recorded on two streams they came back to the allocator late, and every now and then a step had to
+        hipMalloc a fresh 0.5 GB block -- 80 ms on this stack, the 'one step in a few hundred takes three' of round 3)."""
+        key = (name, int(nbytes), "u8")
+        t = self.t.get(key)
+        if t is None:
+            t = self.t[key] = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+        return t
+
+
 class _FreshZeros:
     busy = False
 
     def zeros(self, name, *shape, **kw):
         return torch.zeros(*shape, **kw)
+
+    def buffer(self, name, nbytes, device):
+        return torch.empty(int(nbytes), device=device, dtype=torch.uint8)
 
 
 def _workspace(model, B, T, dev):
@@ -639,8 +653,8 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         # stream A now, beside the heads' and the attention's backward, instead of in front of every recurrence
         parts_main = parts_local = ev_poison = None
         if use_side:
-            parts_main = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp), device=dev, dtype=torch.uint8) for _ in range(L)]
-            parts_local = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hlp), device=dev, dtype=torch.uint8)]
+            parts_main = [ws.buffer(f"part.main{l_}", lib.mt_lstm_bwd_part_bytes(B, T, Hp), dev) for l_ in range(L)]
+            parts_local = [ws.buffer("part.local", lib.mt_lstm_bwd_part_bytes(B, T, Hlp), dev)]
             ev0 = torch.cuda.Event()
             ev0.record(main_st)
             with torch.cuda.stream(side_a):

@@ -3,7 +3,9 @@ more dummy stream is taken from the pool and the step's side streams are re-crea
 49.4 - 49.8 ms for most mappings, 51 - 52 for some, 55.5 - 56 (the single-stream time) for about one in eight -- and pairwise concurrency
 probes (a tiny kernel beside eight 256-MB fills, or beside one 3-ms matrix product, every pair of {calling stream, side A, side B} in both
 directions) report "runs beside" for ALL of them, the slow ones included; running the recurrences on high-priority streams does not help
-(51 - 56 ms).  The mechanism is not understood; `bench.py --mode train --model cnn_rnn_large` in a fresh process gets a good mapping."""
+(51 - 56 ms).  Round 4: the mechanism is the caching allocator, not the queues -- its pools are per stream, a fresh side stream starts with an
+empty one, and a device allocation inside the timed steps costs up to 80 ms (0.5 - 1 GB blocks).  This version prints the device allocations
+of the timed steps and the event-to-event step times beside the wall clock."""
 import os
 import sys
 import time
@@ -35,14 +37,20 @@ def step():
 dummies = []
 for trial in range(10):
     TL._SIDE2.clear()
-    for _ in range(2):
+    for _ in range(3):
         step()
     torch.cuda.synchronize()
+    a0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    marks = []
     t0 = time.perf_counter()
-    for _ in range(4):
+    for _ in range(5):
         step()
+        e = torch.cuda.Event(enable_timing=True); e.record(); marks.append(e)
     torch.cuda.synchronize()
-    sa, sb = TL._SIDE2[str(dev)]
-    print(f"dummy streams created before the side streams: {len(dummies)}: {1e3 * (time.perf_counter() - t0) / 4:.2f} ms per step "
+    wall = 1e3 * (time.perf_counter() - t0) / 5
+    ev = [marks[i].elapsed_time(marks[i + 1]) for i in range(4)]
+    sa, sb = TL._SIDE2[TL.device_key(dev)]
+    print(f"dummy streams created before the side streams: {len(dummies)}: wall {wall:.2f} ms per step, event to event {min(ev):.2f} .. {max(ev):.2f} ms, "
+          f"device allocations in the timed steps {torch.cuda.memory_stats(dev).get('num_device_alloc', 0) - a0} "
           f"(side streams {sa.cuda_stream:#x} {sb.cuda_stream:#x})", flush=True)
     dummies.append(torch.cuda.Stream(device=dev))
