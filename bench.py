@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 # on one queue run their kernels one after the other.  The default schedule keeps 4 forwards in flight on 4 streams next to
 # torch's own stream, so the bench asks for 8 queues (must be in the environment before the runtime initialises).  Measured:
 # 8 600 chunks/s with 4 queues, 10 500 with 8, same kernels.
+_USER_SET_QUEUES = "GPU_MAX_HW_QUEUES" in os.environ
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # chip peaks from /opt/skills/guides/MI355X_MICROARCH.md (dense; spec)
@@ -840,6 +841,11 @@ def main():
                     help="infer = the bench line; train = informational run of configs[3] (use --batch 16 --steps 5)")
     args = ap.parse_args()
     if args.mode == "train":
+        # a training-only process: 32 hardware queues, so that the step's side streams never share one with the calling stream (a shared
+        # queue serialises them: 46 instead of 42 ms per CNNRNNModelLarge step; tools/train_large_queue_probe.py, profiles/r04_train_large_stream_mapping.txt).
+        # Inference keeps 8 (9 996 / 9 430 chunks/s at 400 / 20 steps against 9 925 - 9 956 / 9 207 - 9 393 with 32).
+        if not _USER_SET_QUEUES:
+            os.environ["GPU_MAX_HW_QUEUES"] = "32"
         return bench_train(args)
     if args.model == "cnn_rnn_large":
         return bench_large(args)

@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# The training step overlaps its weight-gradient work on two side streams; streams that share a hardware queue run one after the other.  With 32
+# queues (the runtime's default is 4) no two of a training process's streams share one (profiles/r04_train_large_stream_mapping.txt).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 
 def main():
