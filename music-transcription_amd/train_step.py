@@ -173,7 +173,15 @@ def forward_train(model, x: torch.Tensor, dropout: float, seed: int):
         pk = pack_train(model, dev, "conv")
         d = pk["dims"]
         Hp_, L_ = d["Hp"], d["L"]
-        parts = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp_), device=dev, dtype=torch.uint8) for _ in range(min(2, L_))]
+        # (persistent per (B, T): as per-step allocations used on two streams they came back to the allocator late, and a step that has to
+        #  hipMalloc a fresh 0.5 GB block waits ~80 ms for it -- see train_step_large._StepWorkspace)
+        pool = model.__dict__.setdefault("_bptt_parts", {})
+        pkey = (int(B), int(T), Hp_, str(dev))
+        if pkey not in pool:
+            if len(pool) >= 2:
+                pool.pop(next(iter(pool)))
+            pool[pkey] = [torch.empty(lib.mt_lstm_bwd_part_bytes(B, T, Hp_), device=dev, dtype=torch.uint8) for _ in range(min(2, L_))]
+        parts = pool[pkey]
     H, Hp, L, F1, K0, K1 = d["H"], d["Hp"], d["L"], d["F1"], d["K0"], d["K1"]
     M, Mpad = T * B, _ru(T * B, 128)
     x = x.contiguous().float()

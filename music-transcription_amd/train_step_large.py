@@ -283,10 +283,13 @@ def _side_streams(dev):
 
 def autotune_side_streams(step, dev, candidates: int = 4, steps: int = 2):
     """Picks, by measurement, the pair of side streams the training step runs fastest with, and keeps it for the process.
-    `step()` runs one full training step (they are real steps: nothing is thrown away).  Why: which streams of torch's pool the two
-    side streams happen to be decides whether their work overlaps the calling stream's at all -- 49.6 ms per step for most pairs,
-    51 - 52 for some, 55.7 (the single-stream time) for about one in eight, and no pairwise concurrency probe tells them apart
-    (tools/train_large_queue_probe.py, profiles/r03_train_large_stream_mapping.txt).  Returns the seconds per step of every candidate."""
+    `step()` runs one full training step (they are real steps: nothing is thrown away).  Why (round 4, profiles/r04_train_large_stream_mapping.txt):
+    the HIP runtime folds a process's streams onto GPU_MAX_HW_QUEUES hardware queues, and a side stream that lands on the calling stream's
+    queue runs behind it instead of beside it -- 46 ms per CNNRNNModelLarge step (the single-stream time) instead of 42; with 32 queues no two
+    streams share one and 42.1 against 43.6 ms by the parity of the streams' pool slots is what is left.  A process that also serves inference
+    keeps 8 queues (the headline is 0.5 % faster there), so it chooses its pair by timing the step itself.  (Round 3's larger spread, 49.6 against
+    55.7 ms, was mostly something else: a device allocation inside the timed steps -- the allocator's pools are per stream, a new side stream
+    starts with an empty one -- which the persistent step workspace removed.)  Returns the seconds per step of every candidate."""
     import time
     dev = torch.device(dev)
     key = device_key(dev)

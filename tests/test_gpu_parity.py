@@ -488,7 +488,9 @@ def test_full_size_batch_independence_and_determinism(mta):
 
 # ------------------------------------------------------------------ audio decode (row f3): GPU resampler vs scipy
 @pytest.mark.parametrize("rate,ch,dtype,n", [(44100, 2, "int16", 200000), (48000, 1, "float32", 150001), (16000, 2, "int16", 50000),
-                                             (44100, 2, "int32", 44100), (22050, 1, "int16", 33333)])
+                                             (44100, 2, "int32", 44100), (22050, 1, "int16", 33333),
+                                             # up-sampling (P = 2 phases per tile) / fewer than 4096 outputs (the thread-per-output kernel)
+                                             (8000, 1, "int16", 30000), (44100, 2, "int16", 5000)])
 def test_load_audio_device_matches_scipy_resample_poly(mta, tmp_path, rate, ch, dtype, n):
     from math import gcd
     from scipy.io import wavfile

@@ -636,3 +636,23 @@ def test_sum_slices_helper(mta, S, rows, cols, ldp, ldo):
     want = P[:, :, :cols].double().sum(0)
     assert (out[:, :cols].double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
     assert torch.all(out[:, cols:] == 9.0) and torch.equal(out, out2)
+
+
+def test_pack_wih_cf_matches_index_gather(mta):
+    """mt_pack_wih_cf (layer 0's W_ih -> the projection GEMM's 16-bit operand rows in the kernels' feature order) against the torch index
+    gather + cast it replaces (model._pack_bilstm): bit-exact for bf16 and f16, zero rows for padded hidden units, both directions, row offset."""
+    from music_transcription_amd import _lib
+    from music_transcription_amd.model import _pack_bilstm, _h16
+    for H, C, F, dt in ((24, 64, 10, _lib.DT_BF16), (16, 256, 5, _lib.DT_F16), (512, 256, 40, _lib.DT_BF16)):
+        Hp = (H + 15) // 16 * 16
+        K = C * F
+        rnn = torch.nn.LSTM(K, H, 1, bidirectional=True).cuda()
+        with torch.no_grad():
+            rnn.weight_ih_l0[3, 5] = 1e6                       # (f16 saturates at 65504 instead of overflowing)
+        cols = (torch.arange(C)[None, :] * F + torch.arange(F)[:, None]).reshape(-1)
+        slow, _, _ = _pack_bilstm(rnn, 1, H, cols, "cuda", dt)
+        fast, _, _ = _pack_bilstm(rnn, 1, H, cols, "cuda", dt, k0_cf=(C, F))
+        assert fast[0].dtype == slow[0].dtype and fast[0].shape == slow[0].shape and torch.equal(fast[0].view(torch.int16), slow[0].view(torch.int16)), (H, C, F)
+        out = torch.full((8 * Hp + 256, K), 7.0, device="cuda", dtype=fast[0].dtype)
+        _pack_bilstm(rnn, 1, H, cols, "cuda", dt, k0_cf=(C, F), wih0_out=out[64:])
+        assert torch.equal(out[64:64 + 8 * Hp].view(torch.int16), slow[0][:8 * Hp].view(torch.int16)) and bool((out[:64] == 7.0).all()) and bool((out[64 + 8 * Hp:] == 7.0).all())
