@@ -208,8 +208,9 @@ def bench_train(args):
     # the side streams the step runs fastest with (every rank the same number of steps)
     from music_transcription_amd.train_step_large import autotune_side_streams
     autotune_side_streams(lambda: step(0), dev, candidates=4, steps=1)
-    step(0)                                            # (allocator pools of the chosen side streams settle: a device allocation is ~80 ms)
-    torch.cuda.synchronize()
+    for _ in range(2):                                 # (allocator pools of the chosen side streams settle: a device allocation is ~80 ms)
+        step(0)
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -534,8 +535,9 @@ def section_train(mta, dev, cores, do_cpu):
         step()
     from music_transcription_amd.train_step_large import autotune_side_streams
     tuned = autotune_side_streams(step, dev, candidates=4, steps=2)     # (see section_train_large)
-    step()
-    torch.cuda.synchronize()
+    for _ in range(2):
+        step()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
         loss = step()
@@ -612,8 +614,9 @@ def section_train_large(mta, dev, cores, do_cpu):
     # they are decides whether their work overlaps the calling stream's; by now this process has used a dozen streams)
     from music_transcription_amd.train_step_large import autotune_side_streams
     tuned = autotune_side_streams(step, dev, candidates=4, steps=1)
-    step()                                             # (one more untimed step on the chosen streams: their allocator pools settle)
-    torch.cuda.synchronize()
+    for _ in range(2):                                 # (untimed steps on the chosen streams, each behind a device synchronisation as the timed region
+        step()                                         #  is: the allocator's per-stream pools settle -- a device allocation costs up to 80 ms)
+        torch.cuda.synchronize()
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     marks = []
