@@ -597,3 +597,31 @@ def test_large_full_size_training_step(mta):
         assert st[1] == 1.0 and np.isfinite(st[0])
         losses.append(float(ls.item()))
     assert losses[-1] < losses[0], losses
+
+
+def test_train_cnn_script_trains_the_large_model(mta, tmp_path):
+    """scripts/train_cnn.py --model cnn_rnn_large (what the reference's example.sh:22 trains) on a tiny cache: one epoch runs through the HIP
+    training step, the three checkpoint names hold the reference's CNNRNNModelLarge keys, --no_onset_offset_heads drops the head keys."""
+    import json
+    import subprocess
+    import sys
+    nm, T = 32, 40
+    cache = str(tmp_path / "cache")
+    for split, n in (("train", 4), ("validation", 2)):
+        for i in range(n):
+            mel = _mel_in(1, nm, T - (i % 2) * 6, 400 + i)[0]
+            mta.write_cache_chunk(cache, split, i, mel, _roll_in(1, mel.shape[-1], 500 + i, 0.1)[0])
+        mta.write_cache_metadata(cache, split, [{} for _ in range(n)], n_mels=nm)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra, heads in (([], True), (["--no_onset_offset_heads"], False)):
+        run = str(tmp_path / ("run_h" if heads else "run_nh"))
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "train_cnn.py"), "--cached_dir", cache, "--model", "cnn_rnn_large", "--batch_size", "2",
+                            "--epochs", "1", "--lr", "1e-3", "--n_mels", str(nm), "--hidden_size", "16", "--num_layers", "2", "--dropout", "0.1",
+                            "--run_dir", run, "--num_workers", "0"] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hist = json.load(open(os.path.join(run, "history.json")))
+        assert len(hist) == 1 and np.isfinite(hist[0]["train_loss"]) and np.isfinite(hist[0]["val_loss"]) and hist[0]["steps"] == 2
+        man = R.make_state_dict("cnn_rnn_large", nm, 16, 2, 0, use_heads=heads)
+        for name in ("model_epoch_1.pth", "model_best.pth", "model_final.pth"):
+            ck = torch.load(os.path.join(run, "checkpoints", name))
+            assert set(ck) == set(man) and all(ck[k].shape == man[k].shape for k in man), (name, set(ck) ^ set(man))
