@@ -61,6 +61,28 @@ int         mt_version(void);
 const char* mt_last_error(void);
 /* Number of HIP devices visible, or negative error.  Does not create a context. */
 int         mt_device_count(void);
+/* Makes `device` current for the calling thread and checks that it is a gfx950 part (the only code object in the library).  No global
+ * tables are built (plans and packed weights are caller-owned buffers), so calling it is optional; idempotent.  (mt_init.) */
+int         mt_init(int device);
+/* One size query for the path's scratch / intermediate buffers (mt_workspace_bytes(kind, dims...)): forwards to the per-buffer
+ * queries below.  kind = MT_WS_*; MT_WS_MEL_PLAN takes n_mels in B; unknown kind -> 0 and mt_last_error().                          */
+#define MT_WS_LSTM_GX        1
+#define MT_WS_LSTM_HX        2
+#define MT_WS_LSTM_CX        3
+#define MT_WS_LSTM_SYNC      4
+#define MT_WS_LSTM_BWD_PART  5
+#define MT_WS_LSTM_DGX       6
+#define MT_WS_MEL_PLAN       7
+#define MT_WS_ADAM           8
+size_t      mt_workspace_bytes(int kind, int B, int T, int H);
+/* In-place SUM all-reduce of `count` elements over the ranks of the caller's RCCL communicator (`comm` = ncclComm_t), queued on `stream`:
+ * the gradient step of data-parallel training (train/train_transcriber.py has none: single GPU; BASELINE configs[3]) for a host that is
+ * not Python -- the flat gradient buffer, then mt_adam_clip_step_ex with grad_scale = 1 / world.  RCCL is opened on first use
+ * (librccl.so.1), not linked.  The Python host uses torch.distributed instead.                          */
+#define MT_AR_F32   0
+#define MT_AR_BF16  1
+#define MT_AR_F16   2
+int         mt_allreduce(void* buf, size_t count, int dtype, void* comm, mt_stream_t stream);
 
 /* ------------------------------------------------------------------ frontend
  * Replaces librosa.feature.melspectrogram + librosa.power_to_db as called at

@@ -74,6 +74,9 @@ _SIGS = {
     "mt_version": (i32, []),
     "mt_last_error": (C.c_char_p, []),
     "mt_device_count": (i32, []),
+    "mt_init": (i32, [i32]),
+    "mt_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "mt_allreduce": (i32, [vp, sz, i32, vp, vp]),
     "mt_mel_filterbank_host": (i32, [vp, i32, i32]),
     "mt_mel_num_frames": (i32, [i32, i32]),
     "mt_mel_plan_bytes": (sz, [i32]),

@@ -656,3 +656,41 @@ def test_pack_wih_cf_matches_index_gather(mta):
         out = torch.full((8 * Hp + 256, K), 7.0, device="cuda", dtype=fast[0].dtype)
         _pack_bilstm(rnn, 1, H, cols, "cuda", dt, k0_cf=(C, F), wih0_out=out[64:])
         assert torch.equal(out[64:64 + 8 * Hp].view(torch.int16), slow[0][:8 * Hp].view(torch.int16)) and bool((out[:64] == 7.0).all()) and bool((out[64 + 8 * Hp:] == 7.0).all())
+
+
+def test_mt_allreduce_with_a_single_rank_rccl_communicator(mta):
+    """mt_allreduce (the C ABI's gradient all-reduce for a host that is not Python) drives RCCL's ncclAllReduce with the CALLER's
+    communicator: here a one-rank communicator made through RCCL's own C API (ncclGetUniqueId / ncclCommInitRank), so the sum over ranks is the
+    identity -- in place, on the caller's stream, f32 and bf16; bad arguments are refused without touching RCCL."""
+    import ctypes as C
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr, last_error
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl.so.1 is not on the loader path of this box")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    torch.cuda.set_device(0)
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0 and comm.value
+    try:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        x = torch.randn(1 << 20, device="cuda", generator=g)
+        want = x.clone()
+        check(lib.mt_allreduce(ptr(x), x.numel(), 0, comm, stream_ptr()), "mt_allreduce")
+        xb = want.bfloat16()
+        wantb = xb.clone()
+        check(lib.mt_allreduce(ptr(xb), xb.numel(), 1, comm, stream_ptr()), "mt_allreduce")
+        torch.cuda.synchronize()
+        assert torch.equal(x, want) and torch.equal(xb, wantb)
+        assert lib.mt_allreduce(ptr(x), x.numel(), 7, comm, stream_ptr()) < 0 and "dtype" in last_error()
+        assert lib.mt_allreduce(ptr(x), 0, 0, comm, stream_ptr()) < 0 and lib.mt_allreduce(ptr(x), 4, 0, None, stream_ptr()) < 0
+    finally:
+        rccl.ncclCommDestroy(comm)
+    assert lib.mt_init(0) == 0 and lib.mt_init(99) < 0
+    assert lib.mt_workspace_bytes(5, 16, 937, 512) == lib.mt_lstm_bwd_part_bytes(16, 937, 512) == 937 * 2 * 16 * 16 * 1024

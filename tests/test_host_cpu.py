@@ -478,3 +478,16 @@ def test_direct_gradient_targets_follow_torch_accumulation_semantics(mta):
     b.grad = g[12:17].view(5)
     opt.g.zero_(); opt._touched = set()                              # = zero_grad()
     assert target("a", (12,)) is not None and target("b", (5,)) is not None
+
+
+def test_workspace_query_and_allreduce_argument_checks(mta):
+    """SURVEY 8(b)'s mt_workspace_bytes(kind, dims...) forwards to the per-buffer queries; mt_allreduce refuses bad arguments before it
+    looks for RCCL (no GPU here)."""
+    from music_transcription_amd import _lib
+    lib = _lib.lib
+    assert lib.mt_workspace_bytes(1, 32, 938, 512) == lib.mt_lstm_gx_bytes(32, 938, 512)
+    assert lib.mt_workspace_bytes(2, 33, 10, 256) == lib.mt_lstm_hx_bytes(33, 10, 256)
+    assert lib.mt_workspace_bytes(5, 16, 937, 512) * 2 == lib.mt_workspace_bytes(5, 17, 937, 512)       # 16-column hand-off slices for B <= 16
+    assert lib.mt_workspace_bytes(7, 320, 0, 0) == lib.mt_mel_plan_bytes(320) and lib.mt_workspace_bytes(8, 0, 0, 0) == lib.mt_adam_workspace_bytes()
+    assert lib.mt_workspace_bytes(99, 1, 1, 1) == 0 and "unknown kind" in _lib.last_error()
+    assert lib.mt_allreduce(None, 4, 0, None, None) == _lib_code("MT_EINVAL")
