@@ -133,7 +133,7 @@ def test_train_step_matches_reference_golden(mta, golden_dir):
 # Adam's first steps are ~lr * sign(g) per element, so an element whose gradient is small against the 16-bit rounding of the
 # backward pass may step the other way: the per-tensor cosine of the UPDATE is lower than the gradient's.  0.0 = did not move.
 # Measured (round 4): CNNRNNModel 0.9992 over all tensors, worst tensor 0.993; CNNRNNModelLarge 0.979 / 0.922 (its conv-stack
-# gradients carry the LSTM input gradient's noise through the BatchNorm projections: tools/large_grad_debug.py).
+# gradients carry the LSTM input gradient's noise through the BatchNorm projections: tests/tools/large_grad_debug.py).
 UPDATE_COS_ALL, UPDATE_COS_TENSOR = 0.995, 0.98
 UPDATE_COS_ALL_LARGE, UPDATE_COS_TENSOR_LARGE = 0.97, 0.90
 

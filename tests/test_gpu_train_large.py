@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 from oracle import model_ref as R
 
 # Against the oracle with the HIP path's bf16 rounding points.  Which distance is a kernel error and which is the model's own
-# sensitivity?  MEASURED (round 4, tools/large_grad_debug.py + the oracle alone on the CPU):
+# sensitivity?  MEASURED (round 4, tests/tools/large_grad_debug.py + the oracle alone on the CPU):
 #   * every backward stage fed the HIP path's OWN input gradient agrees with f64 autograd on that stage: convolution weight
 #     gradients 0.2 - 0.4 %, input-gradient convolutions 0.3 %, attention + residual 0.04 %, LayerNorm 1 %, BPTT 0.4 - 0.7 % per layer;
 #   * the gradient entering the top of the backward pass (d feat, behind the heads) is already 7.6 % (L2) from the oracle's, and every
@@ -427,7 +427,7 @@ def test_large_gradients_at_a_realistic_position_count(mta):
     oracle with the same bf16 rounding points.  The per-tensor distance does not shrink to GRAD_REL with the position count: conv weight
     gradients 9 - 11 %, BatchNorm affine gradients 10 - 18 %, cosine 0.9977.  Round 4 found why (header of this file): that IS the oracle's
     distance from itself under 2^-20 perturbations of its roundings (10 - 19 %, cosine 0.9977), while every backward stage alone is within
-    0.2 - 1 % of autograd (tools/large_grad_debug.py, profiles/r04_large_grad_stage_errors.txt).  Asserted: the HIP path is within the
+    0.2 - 1 % of autograd (tests/tools/large_grad_debug.py, profiles/r04_large_grad_stage_errors.txt).  Asserted: the HIP path is within the
     measured floor, tensor by tensor, at least as close in cosine, and its logits are no further away than the perturbed oracle's."""
     nm, H, L, B, T = 320, 64, 2, 2, 200
     m, sd = _hip_large(mta, nm, H, L, 21)

@@ -5,7 +5,7 @@ gradients) is captured and compared twice against torch autograd on the CPU orac
   isolated   -- the oracle's stage is fed the HIP stage's own INPUT gradient (f64 autograd): the stage's own error;
   cumulative -- against the oracle's end-to-end backward (what the parity tests see).
 
-Usage: python tools/large_grad_debug.py [n_mels H L B T]      (default 320 64 2 2 200: the realistic-count test's shape)"""
+Usage: python tests/tools/large_grad_debug.py [n_mels H L B T]      (default 320 64 2 2 200: the realistic-count test's shape)"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import model_ref as R  # noqa: E402
 import music_transcription_amd as mta  # noqa: E402

@@ -1,14 +1,14 @@
 """CPU only: how far does the bf16-emulating ORACLE move from itself when its 16-bit roundings of activations are preceded by a relative
 perturbation of 2^-e?  (Answers ADVICE r3 / VERDICT r3 item 3: is the 9-11 % per-tensor distance of the CNNRNNModelLarge conv weight gradients
 a precision loss of the HIP backward pass?  No: it is this floor -- an f32 re-association, 2^-20..2^-24, already moves the oracle that far.)
-Usage: python tools/oracle_noise_floor.py        (n_mels 320, hidden 64, 2 layers, B = 2, T = 200: the realistic-count test's shape)"""
+Usage: python tests/tools/oracle_noise_floor.py        (n_mels 320, hidden 64, 2 layers, B = 2, T = 200: the realistic-count test's shape)"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import model_ref as R  # noqa: E402
 
