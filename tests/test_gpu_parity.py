@@ -141,6 +141,46 @@ def test_lstm_layer_matches_oracle(mta, B, T, H, K):
     assert torch.equal(X1[:M, :2 * H], want.bfloat16())
 
 
+@pytest.mark.parametrize("H,T", [(512, 40), (256, 33), (48, 21), (16, 9), (64, 50)])
+def test_lstm_16_column_kernel_equals_the_32_column_kernel(mta, H, T):
+    """B <= 16 runs lstm_rec16_kernel (16x16x32 MFMAs, K split in 32-wide steps, cells in two waves), B = 17 .. 32 lstm_rec_kernel: the SAME 16
+    sequences, alone (B = 16) and with a 17th beside them, must give the same h for every step up to the f32 summation order of the K split
+    (the 17th chunk cannot influence the others) -- inference and train mode (activated gates and cell states saved for the backward pass)."""
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(7 * H + T)
+    nkb = H // 8
+    whh = ((torch.rand(2, 4 * H, H, generator=g) * 2 - 1) / np.sqrt(H)).cuda()
+    gx17 = torch.randn(T, 2, nkb, 4, 8, 32, generator=g) * 1.5                 # [t][dir][unit block][gate][unit][batch slot]
+    gx17[..., 17:] = 0.0
+    gx16 = gx17.clone(); gx16[..., 16:] = 0.0
+    s = stream_ptr()
+    outs = {}
+    for B, gx0 in ((16, gx16), (17, gx17)):
+        for train in (False, True):
+            gx = gx0.clone().reshape(-1).cuda()
+            hx = torch.empty(lib.mt_lstm_hx_bytes(B, T, H) // 4, device="cuda")
+            cx = torch.zeros(lib.mt_lstm_cx_bytes(B, T, H) // 4, device="cuda")
+            sync = torch.empty(lib.mt_lstm_sync_bytes(B, H), dtype=torch.uint8, device="cuda")
+            y = torch.empty(B, T, 2 * H, device="cuda")
+            if train:
+                check(lib.mt_lstm_bidir_fwd_train(ptr(gx), ptr(whh), ptr(hx), ptr(cx), ptr(sync), sync.numel(), B, T, H, s))
+            else:
+                check(lib.mt_lstm_bidir_fwd(ptr(gx), ptr(whh), ptr(hx), ptr(sync), sync.numel(), B, T, H, s))
+            check(lib.mt_lstm_unpack_f32(ptr(hx), ptr(y), B, T, H, s))
+            torch.cuda.synchronize()
+            assert int(sync[:4].view(torch.int32).item()) == 0, "hand-off timeout"
+            outs[(B, train)] = (y[:16].cpu(), gx.reshape(T, 2, nkb, 4, 8, 32)[..., :16].cpu(), cx.reshape(T, 2, nkb, 8, 32)[..., :16].cpu())
+    for train in (False, True):
+        a, b = outs[(16, train)], outs[(17, train)]
+        assert torch.isfinite(a[0]).all() and float(a[0].abs().max()) > 0.05
+        assert float((a[0] - b[0]).abs().max()) < 1.5e-3                       # h is published as f16: an ulp (2^-11 at |h| < 1) where a rounding flips
+        assert float((a[0] - b[0]).abs().mean()) < 2e-5
+    assert torch.equal(outs[(16, False)][0], outs[(16, True)][0])                 # train mode changes what is SAVED, not h
+    ga, gb = outs[(16, True)][1], outs[(17, True)][1]                             # activated gates i, f, g, o overwrite gx in place
+    assert float((ga - gb).abs().max()) < 2e-3 and float(ga.min()) >= -1.0 and float(ga.max()) <= 1.0
+    assert float((outs[(16, True)][2] - outs[(17, True)][2]).abs().max()) < 5e-3  # cell states
+
+
 @pytest.mark.parametrize("B,T,H,K", [(3, 20, 16, 64), (32, 40, 512, 1024), (96, 24, 512, 1024), (70, 11, 32, 64), (150, 9, 64, 64), (64, 36, 256, 512)])
 def test_f16_gate_preactivations_equal_the_rounded_f32_ones(mta, B, T, H, K):
     """MT_GX_F16 (include/mt_hip.h): the projection GEMM stores W_ih x + b as f16 -- bit for bit the round-to-nearest-even of what
