@@ -50,14 +50,19 @@ PEAK_F32_MATRIX_TFLOPS = 157.3
 N_SAMPLES, SR, HOP, N_MELS, HIDDEN, LAYERS = 480000, 16000, 512, 320, 512, 3
 
 
-def stage_table(B, T, n_mels, H, L, fused=False):
+def stage_table(B, T, n_mels, H, L, fused=False, conv_fused=None):
     """(name, bound, work per launch, unit of work) for each timed stage, in launch order.
     Algorithmic figures: SURVEY 8(d) / DESIGN.md 'Kernels'."""
     F1, Fo2 = n_mels // 2, n_mels // 4
     M = B * T
+    if conv_fused is None:
+        from music_transcription_amd._lib import lib
+        conv_fused = bool(lib.mt_cnnrnn_conv_fused())
     st = [("mel_kernel", "hbm", B * (4 * N_SAMPLES + 4 * n_mels * T), "B"),
-          ("conv1_kernel", "hbm", B * (4 * n_mels * T + 2 * 32 * F1 * T), "B"),
-          ("conv2_kernel", "mfma", 2.0 * B * (2 * Fo2) * T * 64 * 288, "FLOP")]        # "mfma": f16 operands (inference)
+          # conv1 + conv2 as one kernel (conv12_kernel: act1 never exists in HBM): the conv1 stage is empty, the fused kernel is charged
+          # conv2's matrix-pipe work (conv1's 576 multiply-adds per position run on the vector ALU beside it)
+          ("conv1_kernel", "hbm", 0 if conv_fused else B * (4 * n_mels * T + 2 * 32 * F1 * T), "B"),
+          ("conv12_kernel" if conv_fused else "conv2_kernel", "mfma", 2.0 * B * (2 * Fo2) * T * 64 * 288, "FLOP")]        # "mfma": f16 operands (inference)
     for l in range(L):
         K = Fo2 * 64 if l == 0 else 2 * H
         proj = 2.0 * M * 8 * H * K

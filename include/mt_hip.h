@@ -127,6 +127,11 @@ int    mt_conv2_bn_relu_pool(const void* act1, const void* w2, const float* bias
 /* The same with the 16-bit operand type chosen by the caller (dt = MT_DT_BF16 | MT_DT_F16). */
 int    mt_conv1_bn_relu_pool_dt(const float* mel, const float* chunk_max_power, const float* w, const float* bias,
                                 void* act1, int B, int n_mels, int T, int dt, mt_stream_t stream);
+/* conv1 + conv2 in one kernel (models/cnn_rnn_model.py:29-39): X0 bit-identical to mt_conv1_bn_relu_pool_dt followed by
+ * mt_conv2_bn_relu_pool_dt on the same operands; act1 is computed per tile in LDS and never exists in HBM.                */
+int    mt_conv12_bn_relu_pool_dt(const float* mel, const float* chunk_max_power, const float* w1, const float* b1,
+                                 const void* w2, const float* b2, void* X0, int ldx, int B, int n_mels, int T, int dt,
+                                 mt_stream_t stream);
 int    mt_conv2_bn_relu_pool_dt(const void* act1, const void* w2, const float* bias, void* X0, int ldx,
                                 int B, int F1, int T, int dt, mt_stream_t stream);
 
@@ -236,6 +241,9 @@ typedef struct {
 } mt_cnnrnn_weights;
 
 size_t mt_cnnrnn_workspace_bytes(const mt_cnnrnn_weights* w, int B, int T);
+/* 1 when mt_cnnrnn_forward* runs conv1 + conv2 as one kernel (default; MT_CONV_FUSED=0 in the environment keeps the two launches):
+ * the conv1 stage of mt_cnnrnn_forward_ex's event list is then empty.                                                    */
+int    mt_cnnrnn_conv_fused(void);
 size_t mt_cnnrnn_status_offset(const mt_cnnrnn_weights* w, int B, int T, int layer);
 /* mel[B][n_mels][T] f32 (dB; chunk_max_power may be NULL when mel is already clamped)
  * -> logits[B][88][T] f32.                                                                */

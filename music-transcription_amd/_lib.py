@@ -86,6 +86,8 @@ _SIGS = {
     "mt_conv2_bn_relu_pool": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mt_conv1_bn_relu_pool_dt": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mt_conv2_bn_relu_pool_dt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "mt_cnnrnn_conv_fused": (i32, []),
+    "mt_conv12_bn_relu_pool_dt": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mt_gemm_f32acc_dt": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mt_gemm_lstm_gx_dt": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "mt_gemm_logits_dt": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),

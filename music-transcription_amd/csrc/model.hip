@@ -3,10 +3,12 @@
 //       -> GEMM (fc, transposed store) -> logits (B, 88, T)
 // All intermediates live in the caller's workspace; nothing is allocated or synchronised here.
 #include "mt_common.h"
+#include <stdlib.h>
 
 extern "C" {
 int mt_conv1_bn_relu_pool_dt(const float*, const float*, const float*, const float*, void*, int, int, int, int, mt_stream_t);
 int mt_conv2_bn_relu_pool_dt(const void*, const void*, const float*, void*, int, int, int, int, int, mt_stream_t);
+int mt_conv12_bn_relu_pool_dt(const float*, const float*, const float*, const float*, const void*, const float*, void*, int, int, int, int, int, mt_stream_t);
 int mt_gemm_lstm_gx_dt(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
 int mt_gemm_logits_dt(const void*, int, const void*, int, const float*, float*, int, int, int, int, int, mt_stream_t);
 int mt_lstm_bidir_fwd_ex(const float*, const float*, float*, void*, size_t, int, int, int, int, mt_stream_t);
@@ -84,6 +86,12 @@ static inline int rec(void* const* events, int n_events, int& idx, hipStream_t s
 }
 
 extern "C" int mt_cnnrnn_num_stages(int layers) { return 3 + 3 * layers; }   // conv1, conv2, (gemm, rec, relayout) x L, fc
+// 1: mt_cnnrnn_forward* runs conv1 + conv2 as one kernel (the default; the conv1 stage of the event list is then empty); MT_CONV_FUSED=0
+// in the environment (read once) keeps the two launches.  Same X0 either way, bit for bit.
+extern "C" int mt_cnnrnn_conv_fused(void) {
+    static const int on = !(getenv("MT_CONV_FUSED") && atoi(getenv("MT_CONV_FUSED")) == 0);
+    return on;
+}
 
 extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel, const float* chunk_max_power, int B, int T,
                                     float* logits, void* workspace, size_t workspace_bytes,
@@ -99,9 +107,16 @@ extern "C" int mt_cnnrnn_forward_ex(const mt_cnnrnn_weights* w, const float* mel
     hipStream_t st = (hipStream_t)stream;
     int ei = 0;
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;                      // event 0: start
-    if ((rc = mt_conv1_bn_relu_pool_dt(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, dt, stream)) != MT_OK) return rc;
-    if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
-    if ((rc = mt_conv2_bn_relu_pool_dt(ws + p.act1, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, p.F1, T, dt, stream)) != MT_OK) return rc;
+    if (mt_cnnrnn_conv_fused()) {
+        // conv1 + conv2 as ONE kernel (csrc/conv.hip, conv12_kernel): act1 never exists in HBM; the conv1 stage is empty
+        if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
+        if ((rc = mt_conv12_bn_relu_pool_dt(mel, chunk_max_power, w->conv1_w, w->conv1_b, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, w->n_mels, T, dt,
+                                            stream)) != MT_OK) return rc;
+    } else {
+        if ((rc = mt_conv1_bn_relu_pool_dt(mel, chunk_max_power, w->conv1_w, w->conv1_b, ws + p.act1, B, w->n_mels, T, dt, stream)) != MT_OK) return rc;
+        if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
+        if ((rc = mt_conv2_bn_relu_pool_dt(ws + p.act1, w->conv2_w, w->conv2_b, ws + p.x0, p.K0, B, p.F1, T, dt, stream)) != MT_OK) return rc;
+    }
     if ((rc = rec(events, n_events, ei, st)) != MT_OK) return rc;
     if (p.K1 != 2 * Hv) MT_CHECK_HIP(hipMemsetAsync(ws + p.x1, 0, (size_t)p.Mpad * p.K1 * 2, (hipStream_t)stream));
     char* hcur = ws + p.hx;                  // the previous layer's output images

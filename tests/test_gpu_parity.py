@@ -526,6 +526,55 @@ def test_full_size_batch_independence_and_determinism(mta):
     model.model.raise_on_handoff_timeout(32, 938)
 
 
+@pytest.mark.parametrize("B,n_mels,T,dt", [(2, 320, 937, "f16"), (3, 229, 100, "f16"), (1, 64, 50, "bf16"), (2, 38, 33, "f16"), (5, 32, 17, "bf16")])
+def test_fused_conv1_conv2_is_bit_identical_to_the_two_kernels(mta, B, n_mels, T, dt):
+    """conv12_kernel (act1 computed per tile in LDS from the mel tile, never written to HBM) against mt_conv1_bn_relu_pool_dt followed by
+    mt_conv2_bn_relu_pool_dt on the same operands: the same X0, bit for bit -- with the 80-dB clamp floor taken from the chunk maxima,
+    image borders, an odd number of pooled rows (n_mels = 38: F1 = 19), tiles that overhang T and F."""
+    from music_transcription_amd import _lib
+    from music_transcription_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(B * 1000 + n_mels + T)
+    d = _lib.DT_F16 if dt == "f16" else _lib.DT_BF16
+    t16 = torch.float16 if dt == "f16" else torch.bfloat16
+    mel = (torch.rand(B, n_mels, T, generator=g) * 90.0 - 100.0).cuda()
+    cmax = (10.0 ** ((torch.rand(B, generator=g) * 20.0 - 10.0) / 10.0)).cuda()          # floors between -90 and -70 dB: part of the mel is clamped
+    w1, b1 = (torch.randn(32, 9, generator=g) * 0.05).cuda(), (torch.randn(32, generator=g) * 0.5 + 1.0).cuda()
+    w2 = (torch.randn(64, 288, generator=g) * 0.05).to(t16).cuda()
+    b2 = (torch.randn(64, generator=g) * 0.3).cuda()
+    F1, Fo2 = n_mels // 2, n_mels // 4
+    ldx, Mp = Fo2 * 64 + 64, (T * B + 127) // 128 * 128
+    s = stream_ptr()
+    outs = []
+    for fused in (False, True):
+        X0 = torch.full((Mp, ldx), 7.0, dtype=t16, device="cuda")
+        if fused:
+            check(lib.mt_conv12_bn_relu_pool_dt(ptr(mel), ptr(cmax), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(X0), ldx, B, n_mels, T, d, s), "conv12")
+        else:
+            act1 = torch.empty(B, F1, T, 32, dtype=t16, device="cuda")
+            check(lib.mt_conv1_bn_relu_pool_dt(ptr(mel), ptr(cmax), ptr(w1), ptr(b1), ptr(act1), B, n_mels, T, d, s), "conv1")
+            check(lib.mt_conv2_bn_relu_pool_dt(ptr(act1), ptr(w2), ptr(b2), ptr(X0), ldx, B, F1, T, d, s), "conv2")
+        torch.cuda.synchronize()
+        outs.append(X0)
+    a, b = outs
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    live = a[:T * B, :Fo2 * 64].float()
+    assert torch.isfinite(live).all() and float(live.abs().max()) > 0.1 and bool((a[:, Fo2 * 64:] == 7.0).all())     # and nothing written beside the tile
+    # without chunk maxima (no clamp) as well
+    outs = []
+    for fused in (False, True):
+        X0 = torch.zeros(Mp, ldx, dtype=t16, device="cuda")
+        if fused:
+            check(lib.mt_conv12_bn_relu_pool_dt(ptr(mel), None, ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(X0), ldx, B, n_mels, T, d, s), "conv12")
+        else:
+            act1 = torch.empty(B, F1, T, 32, dtype=t16, device="cuda")
+            check(lib.mt_conv1_bn_relu_pool_dt(ptr(mel), None, ptr(w1), ptr(b1), ptr(act1), B, n_mels, T, d, s), "conv1")
+            check(lib.mt_conv2_bn_relu_pool_dt(ptr(act1), ptr(w2), ptr(b2), ptr(X0), ldx, B, F1, T, d, s), "conv2")
+        outs.append(X0)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert lib.mt_cnnrnn_conv_fused() == 1                                          # what the whole-model forward uses
+
+
 # ------------------------------------------------------------------ audio decode (row f3): GPU resampler vs scipy
 @pytest.mark.parametrize("rate,ch,dtype,n", [(44100, 2, "int16", 200000), (48000, 1, "float32", 150001), (16000, 2, "int16", 50000),
                                              (44100, 2, "int32", 44100), (22050, 1, "int16", 33333),
