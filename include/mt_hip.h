@@ -241,8 +241,8 @@ typedef struct {
 } mt_cnnrnn_weights;
 
 size_t mt_cnnrnn_workspace_bytes(const mt_cnnrnn_weights* w, int B, int T);
-/* 1 when mt_cnnrnn_forward* runs conv1 + conv2 as one kernel (default; MT_CONV_FUSED=0 in the environment keeps the two launches):
- * the conv1 stage of mt_cnnrnn_forward_ex's event list is then empty.                                                    */
+/* 1 when mt_cnnrnn_forward* runs conv1 + conv2 as one kernel (opt-in: MT_CONV_FUSED=1 in the environment; same X0 bit for bit, act1
+ * never in HBM, not faster): the conv1 stage of mt_cnnrnn_forward_ex's event list is then empty.                          */
 int    mt_cnnrnn_conv_fused(void);
 size_t mt_cnnrnn_status_offset(const mt_cnnrnn_weights* w, int B, int T, int layer);
 /* mel[B][n_mels][T] f32 (dB; chunk_max_power may be NULL when mel is already clamped)

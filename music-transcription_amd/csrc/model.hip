@@ -86,10 +86,13 @@ static inline int rec(void* const* events, int n_events, int& idx, hipStream_t s
 }
 
 extern "C" int mt_cnnrnn_num_stages(int layers) { return 3 + 3 * layers; }   // conv1, conv2, (gemm, rec, relayout) x L, fc
-// 1: mt_cnnrnn_forward* runs conv1 + conv2 as one kernel (the default; the conv1 stage of the event list is then empty); MT_CONV_FUSED=0
-// in the environment (read once) keeps the two launches.  Same X0 either way, bit for bit.
+// 1: mt_cnnrnn_forward* runs conv1 + conv2 as one kernel (conv12_kernel; the conv1 stage of the event list is then empty).  OPT-IN
+// (MT_CONV_FUSED=1 in the environment, read once): same X0 bit for bit and 2.4 GB less HBM traffic per forward of 128 chunks, but not
+// faster -- measured 1.38 ms against 0.55 + 0.86 for the two kernels, headline 9 955 - 10 021 against 9 718 - 9 987 chunks/s at 400 steps and
+// 9 082 - 9 273 against 9 364 - 9 454 at 20: conv1 is bound by vector-ALU issue (576 multiply-adds per position) and its phase does not
+// hide under the other resident workgroup's MFMAs as hoped.
 extern "C" int mt_cnnrnn_conv_fused(void) {
-    static const int on = !(getenv("MT_CONV_FUSED") && atoi(getenv("MT_CONV_FUSED")) == 0);
+    static const int on = getenv("MT_CONV_FUSED") && atoi(getenv("MT_CONV_FUSED")) == 1;
     return on;
 }
 
