@@ -11,7 +11,6 @@
 //                                    reference's feature order c*F+f (cnn_rnn_model.py:60-62)
 //                                    is absorbed by permuting W_ih's columns at pack time.
 #include "mt_common.h"
-#include <stdlib.h>
 
 namespace mt {
 
@@ -89,18 +88,11 @@ constexpr int C2_ROWS = 2 * C2_TF + 2, C2_PITCH = 20; // input tile rows, positi
 constexpr int C2_DMA_INSTRS = (C2_ROWS * C2_PITCH * 4 + 63) / 64;          // 64 x 16-B pieces per wave instruction
 constexpr int C2_LDS_BYTES = C2_DMA_INSTRS * 1024;
 
-// STAGE (round 4): the epilogue goes through LDS.  Straight from the accumulators a lane owns one channel of 8 frames: 64 two-byte-per-lane store
-// instructions per wave and tile, 512 per workgroup, each touching two 64-byte pieces.  But for ONE frame the tile's output -- 16 pooled rows x 64
-// channels -- is a contiguous 2-KB run of X0 (column fo * 64 + co), so the pooled tile is assembled in LDS as [frame][row][channel] and leaves as
-// 16-byte-per-lane stores of whole runs: 32 store instructions per workgroup and tile.  (csrc/convg.hip got the same treatment in round 3.)
-constexpr int C2_OUT_BYTES = C2_TT * C2_TF * 64 * 2;                        // 32 KB: [16 frames][16 pooled rows][64 channels] 16-bit
-
-template <int DT, bool STAGE>
+template <int DT>
 __global__ __launch_bounds__(256, 2) void conv2_kernel(const bf16_t* __restrict__ act1, const bf16_t* __restrict__ w2 /*[64][9][32]*/,
                                                        const float* __restrict__ bias /*[64]*/, bf16_t* __restrict__ X0,
                                                        int B, int F1, int T, int Fo2, int ldx, int tiles_f, int tiles_t) {
     extern __shared__ __attribute__((aligned(16))) char in_s[];
-    bf16_t* out_s = (bf16_t*)(in_s + C2_LDS_BYTES);   // (STAGE) the pooled output tile
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int ntile = wv & 1, mgrp = wv >> 1;         // wave: 32 channels x 8 pooled rows
     const int r = lane & 31, h = lane >> 5;
@@ -171,29 +163,17 @@ __global__ __launch_bounds__(256, 2) void conv2_kernel(const bf16_t* __restrict_
             // ---- epilogue: + folded bias, MaxPool over the f pair, ReLU, bf16, X0[(t*B+b)][fo*64+co]
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int fo_l = mgrp * 8 + half * 4 + mi, fo = fo0 + fo_l;
-                if (!STAGE && fo >= Fo2) continue;
+                const int fo = fo0 + mgrp * 8 + half * 4 + mi;
+                if (fo >= Fo2) continue;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const int tl = p + 8 * q + 4 * h, t = t0 + tl;
                         const float v = fmaxf(fmaxf(acc[mi][4 * q + p], acc[mi][4 * (q + 2) + p]) + bv, 0.0f);
-                        if (STAGE) out_s[(tl * C2_TF + fo_l) * 64 + co] = f32_to_h16<DT>(v);
-                        else if (t < T) X0[((size_t)t * B + b) * ldx + fo * 64 + co] = f32_to_h16<DT>(v);
+                        if (t < T) X0[((size_t)t * B + b) * ldx + fo * 64 + co] = f32_to_h16<DT>(v);
                     }
             }
-        }
-        if (STAGE) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                      // the pooled tile is assembled
-            const int nfo = min(C2_TF, Fo2 - fo0);             // pooled rows of this tile inside the image: nfo * 128 bytes per frame
-            for (int i = tid; i < C2_TT * C2_TF * 8; i += 256) {        // 16-byte pieces: frame = i / 128, piece = i % 128 = row * 8 + channel octet
-                const int tl = i >> 7, pc = i & 127, t = t0 + tl;
-                if (t < T && (pc >> 3) < nfo)
-                    *(uint4*)(X0 + ((size_t)t * B + b) * ldx + fo0 * 64 + pc * 8) = *(const uint4*)(out_s + tl * (C2_TF * 64) + pc * 8);
-            }
-            // (the next tile's first out_s write sits behind its own tile barrier, which every wave reaches after these reads)
         }
     }
 #undef C2_ISSUE_DMA
@@ -370,19 +350,11 @@ extern "C" int mt_conv1_bn_relu_pool(const float* mel, const float* chunk_max_po
 template <int DT>
 static int conv2_launch(const void* act1, const void* w2, const float* bias, void* X0, int ldx, int B, int F1, int T, hipStream_t st) {
     const int Fo2 = F1 / 2;
+    MT_SET_MAX_LDS((conv2_kernel<DT>), C2_LDS_BYTES);
     const int tiles_t = cdiv(T, C2_TT), tiles_f = cdiv(Fo2, C2_TF), n_tiles = B * tiles_f * tiles_t;
     dim3 grid(n_tiles < 512 ? n_tiles : 512);          // persistent: two workgroups per CU walk the tiles
-    // the staged epilogue needs 16-byte aligned rows of X0 (MT_CONV2_STAGE=0: stores straight from the accumulators)
-    static const bool stage_env = !(getenv("MT_CONV2_STAGE") && atoi(getenv("MT_CONV2_STAGE")) == 0);
-    if (stage_env && ldx % 8 == 0 && ((uintptr_t)X0 & 15) == 0) {
-        MT_SET_MAX_LDS((conv2_kernel<DT, true>), C2_LDS_BYTES + C2_OUT_BYTES);
-        hipLaunchKernelGGL((conv2_kernel<DT, true>), grid, dim3(256), C2_LDS_BYTES + C2_OUT_BYTES, st, (const bf16_t*)act1,
-                           (const bf16_t*)w2, bias, (bf16_t*)X0, B, F1, T, Fo2, ldx, tiles_f, tiles_t);
-    } else {
-        MT_SET_MAX_LDS((conv2_kernel<DT, false>), C2_LDS_BYTES);
-        hipLaunchKernelGGL((conv2_kernel<DT, false>), grid, dim3(256), C2_LDS_BYTES, st, (const bf16_t*)act1,
-                           (const bf16_t*)w2, bias, (bf16_t*)X0, B, F1, T, Fo2, ldx, tiles_f, tiles_t);
-    }
+    hipLaunchKernelGGL(conv2_kernel<DT>, grid, dim3(256), C2_LDS_BYTES, st, (const bf16_t*)act1,
+                       (const bf16_t*)w2, bias, (bf16_t*)X0, B, F1, T, Fo2, ldx, tiles_f, tiles_t);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
