@@ -199,25 +199,42 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
             //      for this workgroup; this thread's 2 units x 1 batch row are half an 8-B word of each slice.  No flag: the
             //      loads poll the poison pattern (as lstm.hip); the short sleep keeps the certain-to-fail first attempt,
             //      issued right behind this workgroup's own publish, off the fabric.
-            // (ONE: the 4-byte half of the word that holds this thread's unit; the other unit of the half is dropped below)
-            const int gbase = (((tn * 2 + d) * NW + w) * NW) * SL + (wv * SLB + cb) * 8 + (ONE ? ((lane >> 5) & 1) : hh) * 4;
+            // A poll's lanes read their row of a slice CONSECUTIVELY (round 4; tools/handoff_bench.hip): the cell-shaped pattern -- 8-byte stride,
+            // lanes 16 apart on the same word -- made every uncached request of the poll several times as expensive; the same 16 slices polled
+            // by consecutive lanes took 1.0 us off a 3.9-us step of the stand-alone hand-off.  ONE: a row is 128 B, so lanes 0..31 poll the
+            // lower half of the producers and lanes 32..63 the upper half (half the requests); the two half sums meet through a lane swap and
+            // two ds_bpermutes hand every cell its unit.
+            constexpr int NPL = ONE ? TPW * 4 : TPW * 8;                 // loads of a poll
+            const int gbase = (((tn * 2 + d) * NW + w) * NW) * SL + wv * (SLB * 8) + (ONE ? (lane & 31) : lane) * 4;
+            const int pofs = ONE ? NPL * (lane >> 5) : 0;              // first producer of this lane
             long long t1 = 0;
             for (unsigned it = 0;; ++it) {
-                unsigned raw[TPW * 8];
+                unsigned raw[NPL];
 #pragma unroll
-                for (int i = 0; i < TPW * 8; ++i)
-                    raw[i] = (i < NW) ? __builtin_amdgcn_raw_buffer_load_b32(prsrc, gbase + i * SL, 0, 16 /*sc1*/) : 0u;
+                for (int i = 0; i < NPL; ++i)
+                    raw[i] = (i + pofs < NW) ? __builtin_amdgcn_raw_buffer_load_b32(prsrc, gbase + (i + pofs) * SL, 0, 16 /*sc1*/) : 0u;
                 unsigned worst = 0;
                 float sum[2] = {0.0f, 0.0f};
 #pragma unroll
-                for (int i = 0; i < TPW * 8; ++i) {
+                for (int i = 0; i < NPL; ++i) {
                     worst = max(worst, raw[i]);
                     sum[0] += __uint_as_float(raw[i] << 16);
                     sum[1] += __uint_as_float(raw[i] & 0xFFFF0000u);
                 }
                 if (!__any(worst == DG_POISON)) {
-                    if (ONE) rec[0] = ((lane >> 4) & 1) ? sum[1] : sum[0];
-                    else { rec[0] = sum[0]; rec[1] = sum[1]; }
+                    if (ONE) {
+                        // word l of the row = batch l >> 1, units 2 (l & 1) + (0, 1); this cell = batch lane & 15, unit lane >> 4
+                        sum[0] += __shfl_xor(sum[0], 32);
+                        sum[1] += __shfl_xor(sum[1], 32);
+                        const int src = (lane & 15) * 2 + (lane >> 5);
+                        const float v0 = __shfl(sum[0], src), v1 = __shfl(sum[1], src);
+                        rec[0] = ((lane >> 4) & 1) ? v1 : v0;
+                    } else {
+                        // word l of the 256-B row = batch l >> 1, units 2 (l & 1) + (0, 1); this thread = batch b, units 2 hh + (0, 1)
+                        const int src = 2 * b + hh;
+                        rec[0] = __shfl(sum[0], src);
+                        rec[1] = __shfl(sum[1], src);
+                    }
                     break;
                 }
 #ifdef MT_BPTT_DIAG
