@@ -243,8 +243,8 @@ def bench_train(args):
                           "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1e3 * el / K, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16 MFMA operands, f32 accumulate / LSTM state / master weights", "data": "synthetic",
-                          "config": {"workload": ("CNNRNNModel training, batch=16/GPU cached-format chunks, data-parallel (BASELINE.json configs[3])"
-                                                  if mtype == "cnn_rnn" else "CNNRNNModelLarge training (what example.sh:22 trains), cached-format chunks, data-parallel"),
+                          "config": {"workload": (f"CNNRNNModel training, batch={B}/GPU cached-format chunks, data-parallel (BASELINE.json configs[3] is batch=16/GPU)"
+                                                  if mtype == "cnn_rnn" else f"CNNRNNModelLarge training (what example.sh:22 trains), batch={B}/GPU cached-format chunks, data-parallel"),
                                      "batch_per_gpu": B, "frames": T,
                                      "parallelism": f"dp{world} (one RCCL all-reduce of the flat gradient per step)"},
                           "model_tflops_per_s": round(flops * K / el / 1e12, 1), "final_loss": round(float(loss.item()), 5)}))

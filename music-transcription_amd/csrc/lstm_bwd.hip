@@ -38,7 +38,6 @@
 namespace mt {
 
 constexpr int BPTT_SPIN_LIMIT_TICKS = 200000000;   // 2 s of the 100 MHz s_memrealtime clock
-constexpr int BPTT_POLL_SLEEP = 10;                // s_sleep units (64 clocks) before a step's first payload poll
 constexpr unsigned DG_POISON = 0xFFFFFFFFu;        // two bf16 NaNs with all-ones payload: f32_to_bf16 never produces it
 
 struct LstmBwdArgs {
@@ -149,16 +148,29 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
     // What the cell math needs from the forward pass (activated gates, c of the forward pass's previous step, dh from
     // above) does not depend on the recurrence: it is fetched ONE STEP AHEAD (see the issue point below).
     float gt[4][2], cprev[2], dhin[2];
+    // Buffer loads: a lane's offset inside a (step, direction) block never changes and a dead lane's is out of range (the hardware returns 0), the
+    // step enters as a SCALAR offset and the four gates as the instruction's immediate -- six loads and a handful of scalar instructions per step.
+    // (Round 4: as flat loads behind `live ? … : 0` this was ~100 instructions of address arithmetic and exec masking, and it sits between the
+    // gather and the cell math: 0.27 us of the step's chain with the 8 multiplies of the cell.)
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)gates_g, 0, (int)(g_blocks * 4096), 0x00020000);
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)cx_g, 0, (int)(g_blocks * 1024), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)dh_g, 0, (int)(g_blocks * 1024), 0x00020000);
+    int vo_g[NE], vo_c[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        vo_g[e] = live ? (kb * 1024 + (jl0 + e) * 32 + cb) * 4 : 0x7FFFF000;
+        vo_c[e] = live ? (kb * 256 + (jl0 + e) * 32 + cb) * 4 : 0x7FFFF000;
+    }
 #define BPTT_FETCH(S_)                                                                                              \
     do {                                                                                                            \
         const int t_ = d ? (S_) : (T - 1 - (S_));                                                                   \
         const int tp_ = d ? (t_ + 1) : (t_ - 1);                                                                    \
-        const size_t blk_ = ((size_t)t_ * 2 + d) * nkb + kb, blkp_ = ((size_t)tp_ * 2 + d) * nkb + kb;             \
+        const int so_ = __builtin_amdgcn_readfirstlane((t_ * 2 + d) * nkb), sp_ = __builtin_amdgcn_readfirstlane((tp_ * 2 + d) * nkb); \
         _Pragma("unroll") for (int e = 0; e < NE; ++e) {                                                            \
-            const int off_ = (jl0 + e) * 32 + cb;                                                                   \
-            _Pragma("unroll") for (int p = 0; p < 4; ++p) gt[p][e] = live ? gates_g[blk_ * 1024 + p * 256 + off_] : 0.0f; \
-            dhin[e] = live ? dh_g[blk_ * 256 + off_] : 0.0f;                                                        \
-            cprev[e] = (live && tp_ >= 0 && tp_ < T) ? cx_g[blkp_ * 256 + off_] : 0.0f;                             \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                           \
+                gt[p][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vo_g[e] + p * 1024, so_ * 4096, 0)); \
+            dhin[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(drs, vo_c[e], so_ * 1024, 0)); \
+            cprev[e] = (tp_ >= 0 && tp_ < T) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, vo_c[e], sp_ * 1024, 0)) : 0.0f; \
         }                                                                                                           \
     } while (0)
     {
@@ -261,9 +273,14 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
         // latency, in front of the retry in the wave's in-order memory queue); they have the cell math, the MFMA chain, the
         // publish and the next sleep to land
         BD_STAMP(0);
+#ifndef MT_BPTT_FETCH_AT
+#define MT_BPTT_FETCH_AT 0
+#endif
+#if MT_BPTT_FETCH_AT == 0
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < T) BPTT_FETCH(s + 1);
         __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- cell backward (lane-local)
         bf16_t (*img)[64][8] = img2[s & 1];
         bf16_t o4[4][2];
@@ -300,6 +317,9 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
             bf16x8 bfr[4];
 #pragma unroll
             for (int ks2 = 0; ks2 < 4; ++ks2) bfr[ks2] = *(const bf16x8*)(&img[2 * ks2 + (kg >> 1)][(kg & 1) * 32 + bb][0]);
+#if MT_BPTT_FETCH_AT == 1
+            if (s + 1 < T) BPTT_FETCH(s + 1);
+#endif
 #pragma unroll
             for (int mt = 0; mt < 2 * TPW; ++mt) {
                 const int wc = wv * TPW + (mt >> 1);
@@ -317,6 +337,9 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
             bf16x8 bfr[8];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) bfr[ks] = *(const bf16x8*)(&img[ks][lane][0]);
+#if MT_BPTT_FETCH_AT == 1
+            if (s + 1 < T) BPTT_FETCH(s + 1);
+#endif
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int wc = wv * TPW + i;
@@ -335,6 +358,9 @@ __global__ __launch_bounds__(512) void lstm_bptt_kernel(LstmBwdArgs a) {
                 }
             }
         }
+#if MT_BPTT_FETCH_AT == 2
+        if (s + 1 < T) BPTT_FETCH(s + 1);
+#endif
         BD_STAMP(3);
         // ---- dgates for the weight- and input-gradient GEMMs (consumed after the kernel: plain stores)
         {

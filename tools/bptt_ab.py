@@ -4,7 +4,7 @@ python tools/bptt_ab.py [B T H]"""
 import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-lib = C.CDLL(os.path.join(ROOT, "music-transcription_amd", "libmt_hip.so"))
+lib = C.CDLL(os.environ.get("MT_BPTT_AB_LIB") or os.path.join(ROOT, "music-transcription_amd", "libmt_hip.so"))   # a variant build to compare
 B, T, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (16, 937, 512)))
 vp = C.c_void_p
 for f in ("mt_lstm_cx_bytes", "mt_lstm_dgx_bytes", "mt_lstm_bwd_part_bytes"):
@@ -29,6 +29,6 @@ for it in range(8):
     e1.record(); torch.cuda.synchronize()
     assert rc == 0 and int(sync[:4].view(torch.int32).item()) == 0, (rc, hex(int(sync[:4].view(torch.int32).item())))
     ts.append(e0.elapsed_time(e1))
-env = {k: v for k, v in os.environ.items() if k.startswith("MT_BPTT")}
+env = {k: os.path.basename(v) for k, v in os.environ.items() if k.startswith("MT_BPTT")}
 chk = int(dgx.view(torch.int32).to(torch.int64).sum().item())
 print(f"{env}  B={B} T={T} H={H}: min {min(ts):.3f} ms  median {sorted(ts)[len(ts) // 2]:.3f} ms (incl. poison fill) = {1e3 * min(ts) / T:.2f} us/step  checksum {chk}")

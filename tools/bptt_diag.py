@@ -5,8 +5,10 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "music-transcription_amd", "csrc")
 so = "/tmp/libmt_bptt_diag.so"
-srcs = [os.path.join(csrc, f) for f in ("api.hip", "lstm_bwd.hip", "residency.hip")]
-subprocess.check_call(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMT_BPTT_DIAG -I{ROOT}/include -shared {' '.join(srcs)} -o {so}", shell=True)
+# the library's objects with the backward recurrence rebuilt under -DMT_BPTT_DIAG (run `make -C music-transcription_amd/csrc` first)
+objs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".o") and f != "lstm_bwd.o"]
+subprocess.check_call(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMT_BPTT_DIAG -I{ROOT}/include -c {csrc}/lstm_bwd.hip -o /tmp/lstm_bwd_diag.o "
+                      f"2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/lstm_bwd_diag.o {' '.join(objs)} -o {so}", shell=True)
 os.environ["MT_BPTT_MODE"] = "1"
 lib = C.CDLL(so)
 B, T, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (16, 937, 512)))

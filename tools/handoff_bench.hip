@@ -8,6 +8,8 @@
 //   mode 5 / 6  mode 0 / mode 3 with the slices stored producer-major (a workgroup's 16 slices contiguous);
 //   mode 7 / 8  mode 0 with a poll's 128-byte row read by consecutive lanes (lanes 32..63 repeat / are masked off);
 //   mode 9      mode 7 with 8 loads per wave: lanes 0..31 poll producers 0..7, lanes 32..63 producers 8..15;   mode 10 / 11  = 7 / 9 + the rotation of 3;
+//   mode 12     mode 0's slices polled with 4 requests of 8 B per lane (a 16-lane group = one producer's 128-byte row);
+//   mode 13     rows regrouped [consumer][consumer wave][producer]: a wave polls ONE 2-KB run (2 x 16 B per lane); a 512-byte store lands as 4 rows 2 KB apart;
 //   mode 2  all-gather with 1-KB blocks (waves 0/1 publish), polls of 2 x 16-byte loads per lane -- the forward recurrence's shape at 16 workgroups.
 // hipcc --offload-arch=gfx950 -O3 tools/handoff_bench.hip -o /tmp/handoff_bench && /tmp/handoff_bench
 #include <hip/hip_runtime.h>
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(512) void handoff_kernel(Args a) {
             for (int mt = 0; mt < 4; ++mt) {
                 const int wc = wv * 2 + (mt >> 1);
                 const int rb = (MODE == 3 || MODE == 6 || MODE == 10 || MODE == 11) ? ((4 * (mt & 1) + kg + w) & 7) : 4 * (mt & 1) + kg;      // mode 3: a slice's 128-byte rows rotated by the producer
-                const int ob = par + (PM ? w * NWG + wc : wc * NWG + w) * SLS + (rb * 16 + bb) * 8;
+                const int ob = MODE == 13 ? par + ((wc * 8 + rb) * NWG + w) * 128 + bb * 8          // [consumer][row = consumer wave][producer][128 B]
+                                          : par + (PM ? w * NWG + wc : wc * NWG + w) * SLS + (rb * 16 + bb) * 8;
                 const u32x2 v = {stamp, stamp};
                 __builtin_amdgcn_raw_buffer_store_b64(v, rs, ob, 0, 16);
             }
@@ -62,7 +65,22 @@ __global__ __launch_bounds__(512) void handoff_kernel(Args a) {
         long long t1 = 0;
         for (unsigned it = 0;; ++it) {
             bool ok = true;
-            if (MODE == 0 || MODE >= 3) {
+            if (MODE == 13) {
+                // a consumer wave's 16 rows are one 2-KB run: two 16-byte requests per lane
+                u32x4 r[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, par + ((w * 8 + wv) * NWG) * 128 + i * 1024 + lane * 16, 0, 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ok = ok && r[i][0] == stamp && r[i][1] == stamp && r[i][2] == stamp && r[i][3] == stamp;
+            } else if (MODE == 12) {
+                // 4 requests of 8 bytes per lane: a 16-lane group reads one producer's whole 128-byte row
+                const int gb = par + (w * NWG) * SLS + wv * 128 + (lane & 15) * 8;
+                u32x2 r[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, gb + (4 * i + (lane >> 4)) * SLS, 0, 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ok = ok && r[i][0] == stamp && r[i][1] == stamp;
+            } else if (MODE == 0 || MODE >= 3) {
                 const int gb = par + (PM ? w : w * NWG) * SLS + (lane & 15) * 8 + ((lane >> 5) & 1) * 4;
                 unsigned r[16];
 #pragma unroll
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(512) void handoff_kernel(Args a) {
 
 // Generic shape: PW waves of a workgroup publish NS stores of 512 B each into the workgroup's block; every wave polls NLD loads of LW bytes per lane,
 // spread over the 16 producers' blocks (at offsets that depend on the consumer, as the slices of a reduce-scatter do).
-template <int NS, int PW, int LW, int NLD>
+template <int NS, int PW, int LW, int NLD, bool SEG = false>
 __global__ __launch_bounds__(512) void handoff_generic(Args a) {
     __shared__ int abort_s;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, w = blockIdx.x;
@@ -142,7 +160,9 @@ __global__ __launch_bounds__(512) void handoff_generic(Args a) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int prod = (wv * NLD + i) & 15;
-                const int off = par + prod * PB + ((w * 131 + wv * 17 + (wv * NLD + i) / 16) * LSZ) % PB + lane * LW;
+                // SEG: the 16-column forward recurrence's pattern -- four 256-byte runs per request (lanes 16 apart are 512 B or 1 KB apart)
+                const int lo = SEG ? ((((lane >> 4) & 1) * 32 + (lane & 15)) * 16 + (lane >> 5) * 1024) : lane * LW;
+                const int off = par + prod * PB + ((w * 131 + wv * 17 + (wv * NLD + i) / 16) * (SEG ? 2048 : LSZ)) % PB + lo;
                 if (LW == 4) r[i][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 16);
                 else { const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16); for (int e = 0; e < LW / 4; ++e) r[i][e] = q[e]; }
             }
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(512) void handoff_generic(Args a) {
     if (tid == 0) { a.clk[w * 2] = t_gather; a.clk[w * 2 + 1] = polls; }
 }
 
-template <int NS, int PW, int LW, int NLD>
+template <int NS, int PW, int LW, int NLD, bool SEG = false>
 static void run_generic(Args a, size_t bytes) {
     std::vector<float> ms;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -179,7 +199,7 @@ static void run_generic(Args a, size_t bytes) {
     for (int rep = 0; rep < 5; ++rep) {
         CHECK(hipMemset(a.buf, 0, bytes)); CHECK(hipMemset(a.status, 0, 256));
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((handoff_generic<NS, PW, LW, NLD>), dim3(NWG), dim3(512), 0, 0, a);
+        hipLaunchKernelGGL((handoff_generic<NS, PW, LW, NLD, SEG>), dim3(NWG), dim3(512), 0, 0, a);
         CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
         float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
         CHECK(hipMemcpy(h, a.clk, sizeof(h), hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&st, a.status, 4, hipMemcpyDeviceToHost));
@@ -200,7 +220,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int works[][2] = {{0, 0}, {12, 16}, {24, 16}};        // sleep units of 64 clocks (~27 ns): no work / ~0.75 us / ~1.1 us per step
     for (auto& wk : works)
-        for (int mode = 0; mode < 12; ++mode) {
+        for (int mode = 0; mode < 14; ++mode) {
             std::vector<float> ms;
             unsigned long long h[NWG * 2]; unsigned st = 0;
             for (int rep = 0; rep < 5; ++rep) {
@@ -218,7 +238,9 @@ int main(int argc, char** argv) {
                 else if (mode == 8) hipLaunchKernelGGL(handoff_kernel<8>, dim3(NWG), dim3(512), 0, 0, a);
                 else if (mode == 9) hipLaunchKernelGGL(handoff_kernel<9>, dim3(NWG), dim3(512), 0, 0, a);
                 else if (mode == 10) hipLaunchKernelGGL(handoff_kernel<10>, dim3(NWG), dim3(512), 0, 0, a);
-                else hipLaunchKernelGGL(handoff_kernel<11>, dim3(NWG), dim3(512), 0, 0, a);
+                else if (mode == 11) hipLaunchKernelGGL(handoff_kernel<11>, dim3(NWG), dim3(512), 0, 0, a);
+                else if (mode == 12) hipLaunchKernelGGL(handoff_kernel<12>, dim3(NWG), dim3(512), 0, 0, a);
+                else hipLaunchKernelGGL(handoff_kernel<13>, dim3(NWG), dim3(512), 0, 0, a);
                 CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
                 float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
                 CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&st, status, 4, hipMemcpyDeviceToHost));
@@ -241,6 +263,11 @@ int main(int argc, char** argv) {
         run_generic<2, 8, 16, 2>(a, bytes);     // 8 KB publish
         run_generic<1, 8, 4, 16>(a, bytes);
         run_generic<2, 8, 4, 8>(a, bytes);
+        printf("segmented (next line) against consecutive (line above it):\n");
+        run_generic<1, 8, 16, 2>(a, bytes);
+        run_generic<1, 8, 16, 2, true>(a, bytes);
+        run_generic<1, 8, 16, 4>(a, bytes);
+        run_generic<1, 8, 16, 4, true>(a, bytes);
     }
     return 0;
 }
