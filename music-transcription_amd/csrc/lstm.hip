@@ -535,6 +535,12 @@ __global__ __launch_bounds__(320, 4) void lstm_rec16_kernel(LstmArgs a) {
     float c = 0.0f;
     char* hx_g = (char*)a.hx + (size_t)g * gd_blocks * 512;
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(hx_g, 0, (int)(gd_blocks * 512), 0x00020000);
+    // (train mode) gates_out / cx of this batch group as buffers; vo_t = this cell's byte offset inside a (step, direction, workgroup) block
+    const __amdgpu_buffer_rsrc_t gors = __builtin_amdgcn_make_buffer_rsrc(TRAIN ? (void*)(a.gates_out + (size_t)g * gd_blocks * 1024) : (void*)a.hx, 0,
+                                                                          (int)(gd_blocks * 4096), 0x00020000);
+    const __amdgpu_buffer_rsrc_t cxrs = __builtin_amdgcn_make_buffer_rsrc(TRAIN ? (void*)(a.cx + (size_t)g * gd_blocks * 256) : (void*)a.hx, 0,
+                                                                          (int)(gd_blocks * 1024), 0x00020000);
+    const int vo_t = (n < Bg) ? (jl * 32 + n) * 4 : 0x7FFFF000;
     if (tid == 0) abort_s = 0;
     if (tid < 128) ((unsigned*)&hs[0][0])[tid] = 0u;                      // (rows >= 16 stay zero)
     __syncthreads();
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(320, 4) void lstm_rec16_kernel(LstmArgs a) {
         *(f32x4*)(&red[wv][1][lane][0]) = acc[1];
         __syncthreads();
         if (abort_s) return;
+        float gate[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (owner) {
             const int mt = wv;
             const f32x4 r0 = *(const f32x4*)(&red[0][mt][lane][0]), r1 = *(const f32x4*)(&red[1][mt][lane][0]);
@@ -609,21 +616,23 @@ __global__ __launch_bounds__(320, 4) void lstm_rec16_kernel(LstmArgs a) {
             float pre[4];
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp) pre[pp] = ((r0[pp] + r1[pp]) + (r2[pp] + r3[pp])) + (n < Bg ? gxv[pp] : 0.0f);
-            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), og = sigmoidf_(pre[3]);
-            c = fmaf(fg, c, ig * gg);
-            const float hval = og * tanhf_(c);
-            if (TRAIN && n < Bg) {
-                float* go = a.gates_out + (size_t)g * gd_blocks * 1024 + (((size_t)t * 2 + d) * nkb + kb) * 1024 + jl * 32 + n;
-                go[0] = ig; go[256] = fg; go[512] = gg; go[768] = og;
-                a.cx[(size_t)g * gd_blocks * 256 + (((size_t)t * 2 + d) * nkb + kb) * 256 + jl * 32 + n] = c;
-            }
-            hs[n][jl] = (f16_t)hval;
+            gate[0] = sigmoidf_(pre[0]); gate[1] = sigmoidf_(pre[1]); gate[2] = tanhf_(pre[2]); gate[3] = sigmoidf_(pre[3]);
+            c = fmaf(gate[1], c, gate[0] * gate[2]);
+            hs[n][jl] = (f16_t)(gate[3] * tanhf_(c));
         }
         __syncthreads();                                          // the 512-B piece is assembled; every wave is done with `red`
         if (wv == 0) {
             const u32x4 piece = *(const u32x4*)(&hs[lane & 31][0]);
             const int hoff = ((t * 2 + d) * nkb) * 512 + (kb >> 1) * 1024 + ((kb & 1) * 32 + (lane & 31)) * 16;
             __builtin_amdgcn_raw_buffer_store_b128(piece, hrsrc, lane < 32 ? hoff : OOB_OFF, 0, 16 /*sc1: write-through*/);
+        }
+        if (TRAIN && owner) {
+            // what the backward pass reads: BEHIND the publish (round 4: in front of it, with their address arithmetic, these five stores were 0.18 us
+            // of a 1.40-us step), as buffer stores -- a lane's offset is fixed (out of range for the dead columns), the step enters as a scalar
+            const int so = __builtin_amdgcn_readfirstlane((t * 2 + d) * nkb + kb);
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gate[pp]), gors, vo_t + pp * 1024, so * 4096, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), cxrs, vo_t, so * 1024, 0);
         }
     }
 }
@@ -750,6 +759,7 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     const bool g16 = (flags & MT_GX_F16) != 0;
     MT_REQUIRE(!g16 || (!cx && !w_ihx), MT_EINVAL, "mt_lstm_bidir_fwd_ex: MT_GX_F16 is for plain inference launches only");
     MT_REQUIRE((size_t)T * 2 * nkb * 512 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_bidir_fwd: T*H too large for one buffer descriptor");
+    MT_REQUIRE(!cx || (size_t)T * 2 * nkb * 4096 < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_bidir_fwd_train: T*H too large for one buffer descriptor of the gates");
     MT_REQUIRE((((size_t)w_hh | (size_t)w_ihx) & 15) == 0, MT_EINVAL, "mt_lstm_bidir_fwd: weight matrices must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     MT_CHECK_HIP(hipMemsetAsync(sync_ws, 0, mt_lstm_sync_bytes(B, H), st));
