@@ -461,6 +461,20 @@ int    mt_conv2_wgrad(const void* a1, const void* dz_hi, const void* dz_lo, floa
  * What _pack_bilstm (music-transcription_amd/model.py) did with an index gather + cast per direction.                     */
 int    mt_pack_wih_cf(const float* w, void* out, long long ldo, int row0, int H, int Hp, int C, int F, int dt,
                       mt_stream_t stream);
+/* One job of mt_pack_jobs: dst rectangle [Rp][Cp] (row pitch ld elements; dt = MT_DT_BF16 | MT_DT_F16 | MT_PACK_F32) from f32 sources.
+ * With r = r1*Rn2 + r2 and c = c1*Cn2 + c2: dst[r][c] = src[r1*sr1 + r2*sr2 + c1*sc1 + c2*sc2] (+ src2[same offset] when src2 != NULL)
+ * where r1 < R1v, r2 < R2v, c1 < C1v, c2 < C2v, and 0 elsewhere (strides in elements, may be negative).  tr != 0: the source is
+ * contiguous along the dst rows.  tile0 = number of 32 x 32 tiles of the jobs in front of this one (ascending; job 0 has 0).
+ * The table replaces the per-step torch expressions of pack_train_large (music-transcription_amd/train_step_large.py), which
+ * restate what the reference keeps implicit in nn.Module parameters (/root/reference/models/cnn_rnn_model.py:186-260).          */
+#define MT_PACK_F32 2
+typedef struct mt_pack_job {
+    const void* src; const void* src2; void* dst;
+    long long ld, sr1, sr2, sc1, sc2;
+    int dt, Rp, Cp, Rn2, R1v, R2v, Cn2, C1v, C2v, tr, tile0, reserved;
+} mt_pack_job;
+/* Runs a table of njobs jobs (DEVICE memory, ntiles = total number of 32 x 32 tiles) in one launch.                        */
+int    mt_pack_jobs(const void* jobs_dev, int njobs, int ntiles, mt_stream_t stream);
 /* dst[c*ldd + r] = src[r*lds + c] (bf16), r < R, c < C; every dst element with c < Cd, r < ldd is written
  * (zero outside the source).                                                                               */
 int    mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd,

@@ -150,6 +150,7 @@ _SIGS = {
     "mt_conv2_wgrad_workgroups": (i32, []),
     "mt_conv2_wgrad": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mt_pack_wih_cf": (i32, [vp, vp, ll, i32, i32, i32, i32, i32, i32, vp]),
+    "mt_pack_jobs": (i32, [vp, i32, i32, vp]),
     "mt_transpose_bf16": (i32, [vp, ll, ll, i32, vp, ll, i32, vp]),
     "mt_gather4_f32": (i32, [vp, vp, i32, i32, i32, i32, ll, ll, ll, ll, C.c_float, vp]),
     "mt_sum_slices_f32": (i32, [vp, ll, i32, i32, vp, i32, i32, i32, vp]),

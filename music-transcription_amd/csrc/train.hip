@@ -772,6 +772,70 @@ extern "C" int mt_pack_wih_cf(const float* w, void* out, long long ldo, int row0
     return MT_OK;
 }
 
+// ---- batched operand packing (round 4).  The optimizer moves the f32 parameters every step, so every padded / transposed / re-ordered 16-bit
+// operand of the training step is rebuilt every step.  As torch expressions (zeros, slice assignment, .t(), .to(bf16), cat, flip) that was ~250
+// launches of 2-8 us for CNNRNNModelLarge; here ONE launch runs a table of jobs (mt_pack_job, include/mt_hip.h) that lives in device memory and is
+// built once per parameter set.  A job writes a dst rectangle [Rp][Cp]: element (r, c) with r = r1 * Rn2 + r2, c = c1 * Cn2 + c2 is
+// src[r1 sr1 + r2 sr2 + c1 sc1 + c2 sc2] (+ src2[same]) when r1 < R1v, r2 < R2v, c1 < C1v, c2 < C2v and zero otherwise -- two index levels per
+// axis with a valid count each cover head / gate padding, kernel-tap re-ordering and (negative strides) flipped kernels.  tr: the source is
+// contiguous along the dst ROWS (a transpose): the 32 x 32 tile goes through LDS so that both sides stay coalesced.
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const mt_pack_job* __restrict__ jobs, int njobs) {
+    __shared__ float tile[32][33];
+    __shared__ int job_s;
+    if (threadIdx.x == 0) {
+        int j = 0;
+        while (j + 1 < njobs && jobs[j + 1].tile0 <= (int)blockIdx.x) ++j;
+        job_s = j;
+    }
+    __syncthreads();
+    const mt_pack_job jb = jobs[job_s];
+    const int lt = (int)blockIdx.x - jb.tile0, tcs = (jb.Cp + 31) >> 5;
+    const int r0 = (lt / tcs) * 32, c0 = (lt % tcs) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ src = (const float*)jb.src;
+    const float* __restrict__ src2 = (const float*)jb.src2;
+    auto fetch = [&](int r, int c) -> float {
+        const int r1 = r / jb.Rn2, r2 = r - r1 * jb.Rn2, c1 = c / jb.Cn2, c2 = c - c1 * jb.Cn2;
+        if (r1 >= jb.R1v || r2 >= jb.R2v || c1 >= jb.C1v || c2 >= jb.C2v) return 0.0f;
+        const long long off = r1 * jb.sr1 + r2 * jb.sr2 + c1 * jb.sc1 + c2 * jb.sc2;
+        return src2 ? src[off] + src2[off] : src[off];
+    };
+    float v[4];
+    if (jb.tr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + tx, c = c0 + ty + 8 * k;
+            tile[ty + 8 * k][tx] = (r < jb.Rp && c < jb.Cp) ? fetch(r, c) : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = tile[tx][ty + 8 * k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            v[k] = (r < jb.Rp && c < jb.Cp) ? fetch(r, c) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < jb.Rp && c < jb.Cp) {
+            const size_t o = (size_t)r * jb.ld + c;
+            if (jb.dt == MT_PACK_F32) ((float*)jb.dst)[o] = v[k];
+            else if (jb.dt == MT_DT_F16) ((bf16_t*)jb.dst)[o] = f32_to_h16<MT_DT_F16>(v[k]);
+            else ((bf16_t*)jb.dst)[o] = f32_to_h16<MT_DT_BF16>(v[k]);
+        }
+    }
+}
+
+extern "C" int mt_pack_jobs(const void* jobs_dev, int njobs, int ntiles, mt_stream_t stream) {
+    MT_REQUIRE(jobs_dev && njobs > 0 && ntiles > 0, MT_EINVAL, "mt_pack_jobs: bad arguments");
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3(ntiles), dim3(256), 0, ST(stream), (const mt_pack_job*)jobs_dev, njobs);
+    MT_CHECK_LAUNCH();
+    return MT_OK;
+}
+
 extern "C" int mt_transpose_bf16(const void* src, long long lds, long long R, int C, void* dst, long long ldd, int Cd, mt_stream_t stream) {
     MT_REQUIRE(src && dst && R > 0 && C > 0 && lds >= C && ldd >= R && Cd >= C, MT_EINVAL, "mt_transpose_bf16: bad arguments");
     if (lds % 8 == 0 && ldd % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0)

@@ -37,140 +37,193 @@ ATTN_LAYER_ID, HEADS_LAYER_ID, D2D_LAYER_ID = 200, 300, 400
 
 
 # ---------------------------------------------------------------------------------------------------------------- packing
-def _conv_cl(w):            # [Cout][Cin][KH][KW] -> [Cout][(kh*KW + kw)*Cin + ci]
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+class _Packed:
+    """The packed operands of one parameter set: destination tensors (persistent: padding is written once, the live parts every step), the job
+    tables of pack_plan.PackPlan for the convolution stack (calling stream) and for everything above it (side stream), and the layer-0 W_ih
+    launches that keep their own kernel (mt_pack_wih_cf + one transpose)."""
+
+    def __init__(self, model, dev):
+        from .pack_plan import PackPlan, one, two
+        H, L, Hl, F = model.hidden_size, model.num_layers, model.hidden_size // 2, model.n_mels
+        Hp, Hlp, K1 = _ru(H, 16), _ru(Hl, 16), _ru(2 * H, 64)
+        F1, F2, F3 = F // 2, F // 4, F // 8
+        K0 = F3 * 256
+        comb = 2 * H + 2 * Hl
+        Cp = _ru(comb, 64)
+        dev = _norm_dev(dev)
+        f32 = dict(device=dev, dtype=torch.float32)
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        t: Dict[str, object] = {}
+        d = dict(H=H, Hp=Hp, Hl=Hl, Hlp=Hlp, L=L, F=F, F1=F1, F2=F2, F3=F3, K0=K0, K1=K1, comb=comb, Cp=Cp)
+        self.t, self.d, self.dev = t, d, dev
+        self.key = _param_key(model, dev)
+
+        def P(p):                                   # a parameter as the kernels read it: f32, on the device, contiguous -- no copy
+            q = p.detach()
+            if not (q.is_cuda and q.device == dev and q.dtype == torch.float32 and q.is_contiguous()):
+                raise RuntimeError("train_step_large: parameters must be contiguous f32 tensors on the training device")
+            return q
+
+        # ---- convolution stack (calling stream)
+        cp = self.conv_plan = PackPlan(dev)
+        t["w1"], t["b1"] = P(model.conv1[0].weight).view(32, 9), P(model.conv1[0].bias)
+        t["g1"], t["be1"] = P(model.conv1[1].weight), P(model.conv1[1].bias)
+
+        def conv_cl(dst, w, cout, cin, taps):       # [Cout][Cin][KH][KW] -> [Cout][tap*Cin + ci]
+            cp.add(dst, w, one(cout, cin * taps), two(taps, cin, cin, 1, taps))
+
+        def conv_dgrad(dst, w, cout, cin, taps, base=0, at=(0, 0), shape=None):
+            """[ci (rows padded)][tap'*Cout + co] = w[co][ci][taps - 1 - tap']: the flipped kernel (negative tap stride)"""
+            cp.add(dst, w, one(cin, taps), two(taps, cout, cout, -1, cin * taps), base=base + taps - 1, at=at, shape=shape)
+
+        for name, rb, cin, cout in (("rb1", model.res_block1, 32, 64), ("rb2", model.res_block2, 64, 128)):
+            w1, w2, ws_ = P(rb.conv1.weight), P(rb.conv2.weight), P(rb.skip[0].weight)
+            t[name + "c1_w"], t[name + "c1_b"] = torch.zeros(cout, 9 * cin, **bf), P(rb.conv1.bias)
+            conv_cl(t[name + "c1_w"], w1, cout, cin, 9)
+            t[name + "c2_w"], t[name + "c2_b"] = torch.zeros(cout, 9 * cout, **bf), P(rb.conv2.bias)
+            conv_cl(t[name + "c2_w"], w2, cout, cout, 9)
+            t[name + "s_w"], t[name + "s_b"] = torch.zeros(128, 64 if cin < 64 else cin, **bf), P(rb.skip[0].bias)   # the 1x1 skip as a GEMM (K padded to 64)
+            cp.add(t[name + "s_w"], ws_, one(cout, cin), one(cin, 1))
+            t[name + "c2_wd"] = torch.zeros(cout, 9 * cout, **bf)
+            conv_dgrad(t[name + "c2_wd"], w2, cout, cout, 9)
+            cin_p = max(cin, 64)                                                                    # conv_cl wants Cout % 64 == 0
+            t[name + "c1s_wd"] = torch.zeros(cin_p, 9 * cout + cout, **bf)                          # conv1 dgrad + skip^T in one call
+            conv_dgrad(t[name + "c1s_wd"], w1, cout, cin, 9, shape=(cin_p, 9 * cout))
+            cp.add(t[name + "c1s_wd"], ws_, one(cin, 1), one(cout, cin), tr=True, at=(0, 9 * cout), shape=(cin_p, cout))
+            for bn, tag in ((rb.bn1, "bn1"), (rb.bn2, "bn2"), (rb.skip[1], "bns")):
+                t[f"{name}{tag}_g"], t[f"{name}{tag}_b"] = P(bn.weight), P(bn.bias)
+        wf = P(model.freq_aware_conv[0].weight)                                                     # [256][128][7][3]
+        t["fa_w"], t["fa_b"] = torch.zeros(256, 21 * 128, **bf), P(model.freq_aware_conv[0].bias)
+        conv_cl(t["fa_w"], wf, 256, 128, 21)
+        t["fa_wdA"], t["fa_wdB"] = torch.zeros(128, 21 * 128, **bf), torch.zeros(128, 21 * 128, **bf)   # input gradient in two halves of the 256 output channels
+        conv_dgrad(t["fa_wdA"], wf, 128, 128, 21)
+        conv_dgrad(t["fa_wdB"], wf, 128, 128, 21, base=128 * 128 * 21)
+        t["fa_g"], t["fa_be"] = P(model.freq_aware_conv[1].weight), P(model.freq_aware_conv[1].bias)
+        t["zeros256"] = torch.zeros(256, **f32)
+        t["dims"] = d
+        cp.finalize()
+        self.conv_keys = set(t.keys())
+
+        # ---- LSTMs, attention, heads (side stream)
+        up = self.upper_plan = PackPlan(dev)
+        # layer 0 of BOTH LSTMs in one 16-bit tensor [main 8 Hp rows; local 8 Hlp rows (+ tile slack)][K0] (reference feature c*F3+f -> kernel column
+        # f*256+c: mt_pack_wih_cf), and ONE transpose of the whole = [W_ih_main; W_ih_local]^T for the input-gradient GEMM
+        R0, R1 = 8 * Hp, 8 * Hlp
+        self.R0, self.R1 = R0, R1
+        wboth = self.wboth = torch.zeros(R0 + _ru(R1, 128) + 128, K0, **bf)
+        self.wcat = torch.zeros(_ru(K0, 128), R0 + R1, **bf)                    # dX0 = [dG_main | dG_local] . [W_ih_main; W_ih_local]
+        t["ml_wihT"] = self.wcat
+        self.l0 = []                                                           # (weight, row0, H, Hp) of mt_pack_wih_cf
+
+        def lstm(rnn, layers, Hh, Hhp, row0):
+            w_ih, b_g, w_hh = [], [], []
+            for l in range(layers):
+                K = 2 * Hh
+                if l == 0:
+                    w_ih.append(wboth if row0 == 0 else wboth[row0:])
+                else:
+                    w_ih.append(torch.zeros(_ru(8 * Hhp, 128), K1, **bf))
+                b_g.append(torch.zeros(2 * 4 * Hhp, **f32))
+                w_hh.append(torch.zeros(2, 4 * Hhp, Hhp, **f32))
+                for di, suf in enumerate(("", "_reverse")):
+                    wi, wh = P(getattr(rnn, f"weight_ih_l{l}{suf}")), P(getattr(rnn, f"weight_hh_l{l}{suf}"))
+                    bi, bh = P(getattr(rnn, f"bias_ih_l{l}{suf}")), P(getattr(rnn, f"bias_hh_l{l}{suf}"))
+                    if l == 0:
+                        self.l0.append((wi, row0 + di * 4 * Hhp, Hh, Hhp))
+                    else:                                                      # gate row p*Hhp + j <- p*Hh + j, columns [fwd Hh | reverse Hh] padded to K1
+                        up.add(w_ih[l], wi, two(4, Hhp, Hh, Hh * K, K), one(K, 1), at=(di * 4 * Hhp, 0), shape=(4 * Hhp, K1))
+                    up.add(b_g[l].view(8, Hhp), bi, one(4, Hh), one(Hh, 1), src2=bh, at=(di * 4, 0), shape=(4, Hhp))
+                    up.add(w_hh[l].view(2 * 4 * Hhp, Hhp), wh, two(4, Hhp, Hh, Hh * Hh, Hh), one(Hh, 1), at=(di * 4 * Hhp, 0), shape=(4 * Hhp, Hhp))
+            return w_ih, b_g, w_hh
+
+        t["m_wih"], t["m_b"], t["m_whh"] = lstm(model.rnn_main, L, H, Hp, 0)
+        t["l_wih"], t["l_b"], t["l_whh"] = lstm(model.rnn_local, 1, Hl, Hlp, R0)
+        t["m_wihT"] = [None]
+        for l in range(1, L):                                                  # W_ih^T of the deeper layers, straight from the parameters
+            wT = torch.zeros(_ru(K1, 128), 8 * Hp, **bf)
+            for di, suf in enumerate(("", "_reverse")):
+                up.add(wT, P(getattr(model.rnn_main, f"weight_ih_l{l}{suf}")), one(2 * H, 1), two(4, Hp, H, H * 2 * H, 2 * H), tr=True,
+                       at=(0, di * 4 * Hp), shape=(wT.shape[0], 4 * Hp))
+            t["m_wihT"].append(wT)
+        if model.use_attention:
+            heads, dh = model.attention.num_heads, model.attention.head_dim
+            dp = _ru(dh, 64)
+            Ca = heads * dp
+            d.update(heads=heads, dh=dh, dp=dp, Ca=Ca, ld3=3 * Ca, scale=float(dh) ** -0.5)
+            qw, qb = P(model.attention.qkv.weight), P(model.attention.qkv.bias)            # [3][heads][dh] rows x comb
+            t["qkv_w"], t["qkv_b"] = torch.zeros(_ru(3 * Ca, 128), Cp, **bf), torch.zeros(3 * Ca, **f32)
+            up.add(t["qkv_w"], qw, two(3 * heads, dp, dh, dh * comb, comb), one(comb, 1))
+            up.add(t["qkv_b"].view(3 * heads, dp), qb, one(3 * heads, dh), one(dh, 1))
+            t["qkv_wT"] = torch.zeros(_ru(comb, 128), 3 * Ca, **bf)
+            up.add(t["qkv_wT"], qw, one(comb, 1), two(3 * heads, dp, dh, dh * comb, comb), tr=True)
+            pw = P(model.attention.proj.weight)                                             # [comb] x [heads][dh]
+            t["proj_w"], t["proj_b"] = torch.zeros(_ru(comb, 128), Ca, **bf), P(model.attention.proj.bias)
+            up.add(t["proj_w"], pw, one(comb, comb), two(heads, dp, dh, dh, 1))
+            t["proj_wT"] = torch.zeros(_ru(Ca, 128), Cp, **bf)
+            up.add(t["proj_wT"], pw, two(heads, dp, dh, dh, 1), one(comb, comb), tr=True)
+            t["ln_g"], t["ln_b"] = P(model.attention_norm.weight), P(model.attention_norm.bias)
+        if model.use_onset_offset_heads:
+            Hs = _ru(H, 64)
+            d.update(Hs=Hs)
+            sw = P(model.shared_fc.weight)                                                  # [H][comb]
+            t["shared_w"], t["shared_b"] = torch.zeros(_ru(H, 128), Cp, **bf), P(model.shared_fc.bias)
+            up.add(t["shared_w"], sw, one(H, comb), one(comb, 1))
+            t["shared_wT"] = torch.zeros(_ru(comb, 128), Hs, **bf)
+            up.add(t["shared_wT"], sw, one(comb, 1), one(H, comb), tr=True)
+            t["heads_w"], t["heads_b"] = torch.zeros(384, Hs, **bf), torch.zeros(264, **f32)
+            t["heads_wT"] = torch.zeros(_ru(Hs, 128), 384, **bf)
+            for i, m in enumerate((model.frame_head, model.onset_head, model.offset_head)):
+                hw, hb = P(m.weight), P(m.bias)                                             # [88][H], [88]
+                up.add(t["heads_w"], hw, one(88, H), one(H, 1), at=(88 * i, 0), shape=(88, Hs))
+                up.add(t["heads_b"].view(1, 264), hb, one(1, 0), one(88, 1), at=(0, 88 * i), shape=(1, 88))
+                up.add(t["heads_wT"], hw, one(H, 1), one(88, H), tr=True, at=(0, 88 * i), shape=(t["heads_wT"].shape[0], 88))
+        else:
+            fw = P(model.fc.weight)                                                         # [88][comb]
+            t["fc_w"], t["fc_b"] = torch.zeros(128, Cp, **bf), P(model.fc.bias)
+            up.add(t["fc_w"], fw, one(88, comb), one(comb, 1))
+            t["fc_wT"] = torch.zeros(_ru(comb, 128), 128, **bf)
+            up.add(t["fc_wT"], fw, one(comb, 1), one(88, comb), tr=True)
+        up.finalize()
+
+    def run_upper(self):
+        d = self.d
+        for w, row0, Hh, Hhp in self.l0:
+            check(lib.mt_pack_wih_cf(ptr(w), ptr(self.wboth), d["K0"], row0, Hh, Hhp, 256, d["F3"], _lib.DT_BF16, _st()), "mt_pack_wih_cf")
+        check(lib.mt_transpose_bf16(ptr(self.wboth), d["K0"], self.R0 + self.R1, d["K0"], ptr(self.wcat), self.R0 + self.R1, d["K0"], _st()), "mt_transpose_bf16")
+        self.upper_plan.run()
 
 
-def _conv_dgrad_w(w, rows_pad=None):
-    """Input-gradient weights of a KH x 3 convolution: [Cin (padded rows)][(kh'*3 + kw')*Cout + co] = w[co][ci][KH-1-kh'][2-kw']."""
-    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1)
-    if rows_pad and rows_pad > wd.shape[0]:
-        wd = torch.cat([wd, wd.new_zeros(rows_pad - wd.shape[0], wd.shape[1])], 0)
-    return wd
+def _norm_dev(dev):
+    dev = torch.device(dev)
+    return torch.device(dev.type, torch.cuda.current_device()) if dev.type == "cuda" and dev.index is None else dev
+
+
+def _param_key(model, dev):
+    return (str(_norm_dev(dev)), bool(model.use_attention), bool(model.use_onset_offset_heads)) + tuple(p.data_ptr() for p in model.parameters())
 
 
 def pack_train_large(model, dev, side=None) -> Dict[str, object]:
-    """bf16 operand layouts of the CURRENT parameters (redone every step: the optimizer moves them).  With `side` (a stream) everything
-    above the convolution stack -- 99 % of the bytes: LSTM, attention and head weights, the layer-0 column permutation -- is packed on
-    that stream beside the convolution stack's forward; t["_ready"] is the event to wait for before touching those entries."""
-    from .model import _pack_bilstm
-    H, L, Hl, F = model.hidden_size, model.num_layers, model.hidden_size // 2, model.n_mels
-    Hp, Hlp, K1 = _ru(H, 16), _ru(Hl, 16), _ru(2 * H, 64)
-    F1, F2, F3 = F // 2, F // 4, F // 8
-    K0 = F3 * 256
-    comb = 2 * H + 2 * Hl
-    Cp = _ru(comb, 64)
-    f32 = dict(device=dev, dtype=torch.float32)
-    bf = torch.bfloat16
-    t: Dict[str, object] = {}
-    d = dict(H=H, Hp=Hp, Hl=Hl, Hlp=Hlp, L=L, F=F, F1=F1, F2=F2, F3=F3, K0=K0, K1=K1, comb=comb, Cp=Cp)
-    g = lambda p: p.detach().to(**f32)
-    t["w1"], t["b1"] = g(model.conv1[0].weight).reshape(32, 9).contiguous(), g(model.conv1[0].bias).contiguous()
-    t["g1"], t["be1"] = g(model.conv1[1].weight).contiguous(), g(model.conv1[1].bias).contiguous()
-    for name, rb, cin, cout in (("rb1", model.res_block1, 32, 64), ("rb2", model.res_block2, 64, 128)):
-        w1, w2, ws = g(rb.conv1.weight), g(rb.conv2.weight), g(rb.skip[0].weight).reshape(cout, cin)
-        t[name + "c1_w"], t[name + "c1_b"] = _conv_cl(w1).to(bf).contiguous(), g(rb.conv1.bias).contiguous()
-        t[name + "c2_w"], t[name + "c2_b"] = _conv_cl(w2).to(bf).contiguous(), g(rb.conv2.bias).contiguous()
-        wsp = torch.zeros(128, 64 if cin < 64 else cin, **f32)             # the 1x1 skip as a GEMM (K padded to 64: see mt_gemm)
-        wsp[:cout, :cin] = ws
-        t[name + "s_w"], t[name + "s_b"] = wsp.to(bf), g(rb.skip[0].bias).contiguous()
-        t[name + "c2_wd"] = _conv_dgrad_w(w2).to(bf).contiguous()                                   # [cout][9*cout]
-        cin_p = max(cin, 64)                                                                        # conv_cl wants Cout % 64 == 0
-        wd = torch.zeros(cin_p, 9 * cout + cout, **f32)                                             # conv1 dgrad + skip^T in one call
-        wd[:cin, :9 * cout] = _conv_dgrad_w(w1)
-        wd[:cin, 9 * cout:] = ws.t()
-        t[name + "c1s_wd"] = wd.to(bf)
-        for bn, tag in ((rb.bn1, "bn1"), (rb.bn2, "bn2"), (rb.skip[1], "bns")):
-            t[f"{name}{tag}_g"], t[f"{name}{tag}_b"] = g(bn.weight).contiguous(), g(bn.bias).contiguous()
-    wf = g(model.freq_aware_conv[0].weight)
-    t["fa_w"], t["fa_b"] = _conv_cl(wf).to(bf).contiguous(), g(model.freq_aware_conv[0].bias).contiguous()
-    t["fa_wdA"] = _conv_dgrad_w(wf[:128]).to(bf).contiguous()             # input gradient in two halves of the 256 output channels
-    t["fa_wdB"] = _conv_dgrad_w(wf[128:]).to(bf).contiguous()
-    t["fa_g"], t["fa_be"] = g(model.freq_aware_conv[1].weight).contiguous(), g(model.freq_aware_conv[1].bias).contiguous()
-    t["zeros256"] = torch.zeros(256, **f32)
-    t["dims"] = d
+    """bf16 operand layouts of the CURRENT parameters (redone every step: the optimizer moves them) -- two launches of mt_pack_jobs plus layer
+    0's W_ih (four mt_pack_wih_cf, one transpose); the tables and the destination tensors are built once per parameter set (round 4: as torch
+    expressions this was ~250 small launches per step).  With `side` (a stream) everything above the convolution stack -- 99 % of the bytes --
+    is packed on that stream beside the convolution stack's forward; t["_ready"] is the event to wait for before touching those entries.
+    The returned tensors are REUSED by the next call: one step per model at a time (as the step workspace)."""
+    pk = getattr(model, "_train_packed", None)
+    if pk is None or pk.key != _param_key(model, dev):
+        pk = model._train_packed = _Packed(model, dev)
+    t = pk.t
+    pk.conv_plan.run()
     if side is None:
-        _pack_upper(model, dev, t, d)
+        pk.run_upper()
+        t.pop("_ready", None)
     else:
-        main_st = torch.cuda.current_stream(dev)
-        conv_keys = set(t.keys())
-        side.wait_stream(main_st)                       # the optimizer's update of the parameters is ordered on the calling stream
+        side.wait_stream(torch.cuda.current_stream(dev))     # the optimizer's update of the parameters is ordered on the calling stream
         with torch.cuda.stream(side):
-            _pack_upper(model, dev, t, d)
+            pk.run_upper()
             ev = torch.cuda.Event()
             ev.record(side)
-        for k_, v_ in t.items():                        # allocated under the side stream, used (and freed) under the calling one
-            if k_ in conv_keys:
-                continue
-            for t_ in (v_ if isinstance(v_, (list, tuple)) else [v_]):
-                if isinstance(t_, torch.Tensor):
-                    t_.record_stream(main_st)
         t["_ready"] = ev
     return t
-
-
-def _pack_upper(model, dev, t, d):
-    from .model import _pack_bilstm
-    H, L, Hl, Hp, Hlp, K0, K1, F3, comb, Cp = (d[k] for k in ("H", "L", "Hl", "Hp", "Hlp", "K0", "K1", "F3", "comb", "Cp"))
-    f32 = dict(device=dev, dtype=torch.float32)
-    bf = torch.bfloat16
-    g = lambda p: p.detach().to(**f32)
-    # LSTMs (layer-0 columns re-ordered: reference feature c*F3+f -> kernel column f*256+c)
-    cols = (torch.arange(256)[None, :] * F3 + torch.arange(F3)[:, None]).reshape(-1)
-    # layer 0 of BOTH LSTMs into one 16-bit tensor [main 8 Hp rows; local 8 Hlp rows (+ tile slack)][K0]: the two forward projections read
-    # their own rows, and ONE transpose of the whole gives [W_ih_main; W_ih_local]^T for the input-gradient GEMM (was: two index gathers
-    # and casts per LSTM, a zero fill of the 126-MB transposed operand and two strided copies into it, every step)
-    R0, R1 = 8 * Hp, 8 * Hlp
-    wboth = torch.empty(R0 + _ru(R1, 128) + 128, K0, device=dev, dtype=bf)
-    wboth[R0 + R1:].zero_()
-    t["m_wih"], t["m_b"], t["m_whh"] = _pack_bilstm(model.rnn_main, L, H, cols, dev, k0_cf=(256, F3), wih0_out=wboth)
-    t["l_wih"], t["l_b"], t["l_whh"] = _pack_bilstm(model.rnn_local, 1, Hl, cols, dev, k0_cf=(256, F3), wih0_out=wboth[R0:])
-    t["m_wihT"] = [None]
-    for l in range(1, L):
-        wT = torch.zeros(_ru(K1, 128), 8 * Hp, device=dev, dtype=bf)
-        wT[:K1] = t["m_wih"][l][:8 * Hp].t()
-        t["m_wihT"].append(wT)
-    wcat = torch.empty(_ru(K0, 128), R0 + R1, device=dev, dtype=bf)             # dX0 = [dG_main | dG_local] . [W_ih_main; W_ih_local]
-    if _ru(K0, 128) > K0:
-        wcat[K0:].zero_()
-    check(lib.mt_transpose_bf16(ptr(wboth), K0, R0 + R1, K0, ptr(wcat), R0 + R1, K0, _st()), "mt_transpose_bf16")
-    t["ml_wihT"] = wcat
-    if model.use_attention:
-        heads, dh = model.attention.num_heads, model.attention.head_dim
-        dp = _ru(dh, 64)
-        Ca = heads * dp
-        d.update(heads=heads, dh=dh, dp=dp, Ca=Ca, ld3=3 * Ca, scale=float(dh) ** -0.5)
-        qw = g(model.attention.qkv.weight).reshape(3, heads, dh, comb)
-        qwp = torch.zeros(3, heads, dp, Cp, **f32); qwp[:, :, :dh, :comb] = qw
-        qbp = torch.zeros(3, heads, dp, **f32); qbp[:, :, :dh] = g(model.attention.qkv.bias).reshape(3, heads, dh)
-        qfull = torch.zeros(_ru(3 * Ca, 128), Cp, **f32); qfull[:3 * Ca] = qwp.reshape(3 * Ca, Cp)
-        t["qkv_w"], t["qkv_b"] = qfull.to(bf), qbp.reshape(-1).contiguous()
-        qT = torch.zeros(_ru(comb, 128), 3 * Ca, **f32); qT[:Cp] = qfull[:3 * Ca].t()
-        t["qkv_wT"] = qT.to(bf)
-        pw = g(model.attention.proj.weight).reshape(comb, heads, dh)
-        pwp = torch.zeros(_ru(comb, 128), heads, dp, **f32); pwp[:comb, :, :dh] = pw
-        t["proj_w"], t["proj_b"] = pwp.reshape(-1, Ca).to(bf), g(model.attention.proj.bias).contiguous()
-        pT = torch.zeros(_ru(Ca, 128), Cp, **f32); pT[:Ca, :comb] = pwp.reshape(-1, Ca)[:comb].t()
-        t["proj_wT"] = pT.to(bf)
-        t["ln_g"], t["ln_b"] = g(model.attention_norm.weight).contiguous(), g(model.attention_norm.bias).contiguous()
-    if model.use_onset_offset_heads:
-        Hs = _ru(H, 64)
-        d.update(Hs=Hs)
-        sw = torch.zeros(_ru(H, 128), Cp, **f32); sw[:H, :comb] = g(model.shared_fc.weight)
-        t["shared_w"], t["shared_b"] = sw.to(bf), g(model.shared_fc.bias).contiguous()
-        swT = torch.zeros(_ru(comb, 128), Hs, **f32); swT[:comb, :H] = g(model.shared_fc.weight).t()
-        t["shared_wT"] = swT.to(bf)
-        hw = torch.zeros(384, Hs, **f32)
-        hw[:264, :H] = torch.cat([g(m.weight) for m in (model.frame_head, model.onset_head, model.offset_head)], 0)
-        t["heads_w"] = hw.to(bf)
-        t["heads_b"] = torch.cat([g(m.bias) for m in (model.frame_head, model.onset_head, model.offset_head)], 0).contiguous()
-        hwT = torch.zeros(_ru(Hs, 128), 384, **f32); hwT[:Hs] = hw.t()
-        t["heads_wT"] = hwT.to(bf)
-    else:
-        fw = torch.zeros(128, Cp, **f32); fw[:88, :comb] = g(model.fc.weight)
-        t["fc_w"], t["fc_b"] = fw.to(bf), g(model.fc.bias).contiguous()
-        fwT = torch.zeros(_ru(comb, 128), 128, **f32); fwT[:comb] = fw[:, :comb].t()
-        t["fc_wT"] = fwT.to(bf)
 
 
 # ---------------------------------------------------------------------------------------------------------------- step workspace

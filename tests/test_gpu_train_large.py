@@ -211,7 +211,8 @@ def test_conv_cl_channel_slices_and_accumulate(mta):
     B, F_, T = 2, 9, 37
     dz = _bf(torch.randn(B, F_, T, 256, generator=g))
     w = _bf(torch.randn(256, 128, 7, 3, generator=g) * 0.05)           # forward weights [co][ci][kh][kw]
-    from music_transcription_amd.train_step_large import _conv_dgrad_w
+    def _conv_dgrad_w(w_):          # [ci][(kh'*3 + kw')*Cout + co] = w[co][ci][KH-1-kh'][2-kw']
+        return w_.flip(2, 3).permute(1, 2, 3, 0).reshape(w_.shape[1], -1)
     wa, wb = _conv_dgrad_w(w[:128]).bfloat16().cuda().contiguous(), _conv_dgrad_w(w[128:]).bfloat16().cuda().contiguous()
     dzd = dz.bfloat16().cuda().contiguous()
     out = torch.empty(B * F_ * T, 128, dtype=torch.bfloat16, device="cuda")
@@ -625,3 +626,42 @@ def test_train_cnn_script_trains_the_large_model(mta, tmp_path):
         for name in ("model_epoch_1.pth", "model_best.pth", "model_final.pth"):
             ck = torch.load(os.path.join(run, "checkpoints", name))
             assert set(ck) == set(man) and all(ck[k].shape == man[k].shape for k in man), (name, set(ck) ^ set(man))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(use_attention=False), dict(use_onset_offset_heads=False)])
+def test_pack_job_tables_equal_the_torch_expressions(mta, kw):
+    """The operands of the training step as mt_pack_jobs writes them (pack_plan.py, one launch per stream and step) against the torch
+    expressions they replace (tests/tools/pack_reference_large.py): every tensor bit for bit, twice -- the second call re-packs moved
+    parameters into the SAME destination tensors."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from pack_reference_large import pack_train_large_torch
+    from music_transcription_amd.train_step_large import pack_train_large
+    m, _ = _hip_large(mta, 64, 24, 3, seed=5, **kw)
+    net = m.model
+
+    def flat(t):
+        out = {}
+        for k, v in t.items():
+            if isinstance(v, torch.Tensor):
+                out[k] = v
+            elif isinstance(v, (list, tuple)):
+                for i, u in enumerate(v):
+                    if isinstance(u, torch.Tensor):
+                        out[f"{k}[{i}]"] = u
+        return out
+
+    for rnd in range(2):
+        got, want = flat(pack_train_large(net, "cuda")), flat(pack_train_large_torch(net, torch.device("cuda")))
+        torch.cuda.synchronize()
+        assert set(want) <= set(got), set(want) - set(got)
+        for k, w in want.items():
+            g = got[k]
+            if k == "m_wih[0]" or k == "l_wih[0]":          # (views of one tensor: compare the rows the reference returns)
+                g = g[:w.shape[0]]
+            assert g.shape == w.shape and g.dtype == w.dtype, (k, g.shape, w.shape, g.dtype, w.dtype)
+            assert torch.equal(g, w), (rnd, k, float((g.float() - w.float()).abs().max()))
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(torch.randn_like(p) * 0.01)

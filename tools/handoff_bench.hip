@@ -10,6 +10,7 @@
 //   mode 9      mode 7 with 8 loads per wave: lanes 0..31 poll producers 0..7, lanes 32..63 producers 8..15;   mode 10 / 11  = 7 / 9 + the rotation of 3;
 //   mode 12     mode 0's slices polled with 4 requests of 8 B per lane (a 16-lane group = one producer's 128-byte row);
 //   mode 13     rows regrouped [consumer][consumer wave][producer]: a wave polls ONE 2-KB run (2 x 16 B per lane); a 512-byte store lands as 4 rows 2 KB apart;
+//   mode 14     mode 0's slices polled with 2 requests of 16 B per lane (an 8-lane group = one producer's row);
 //   mode 2  all-gather with 1-KB blocks (waves 0/1 publish), polls of 2 x 16-byte loads per lane -- the forward recurrence's shape at 16 workgroups.
 // hipcc --offload-arch=gfx950 -O3 tools/handoff_bench.hip -o /tmp/handoff_bench && /tmp/handoff_bench
 #include <hip/hip_runtime.h>
@@ -65,7 +66,15 @@ __global__ __launch_bounds__(512) void handoff_kernel(Args a) {
         long long t1 = 0;
         for (unsigned it = 0;; ++it) {
             bool ok = true;
-            if (MODE == 13) {
+            if (MODE == 14) {
+                // 2 requests of 16 bytes per lane: an 8-lane group reads one producer's 128-byte row
+                const int gb = par + (w * NWG) * SLS + wv * 128 + (lane & 7) * 16;
+                u32x4 r[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, gb + (8 * i + (lane >> 3)) * SLS, 0, 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ok = ok && r[i][0] == stamp && r[i][1] == stamp && r[i][2] == stamp && r[i][3] == stamp;
+            } else if (MODE == 13) {
                 // a consumer wave's 16 rows are one 2-KB run: two 16-byte requests per lane
                 u32x4 r[2];
 #pragma unroll
@@ -220,7 +229,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int works[][2] = {{0, 0}, {12, 16}, {24, 16}};        // sleep units of 64 clocks (~27 ns): no work / ~0.75 us / ~1.1 us per step
     for (auto& wk : works)
-        for (int mode = 0; mode < 14; ++mode) {
+        for (int mode = 0; mode < 15; ++mode) {
             std::vector<float> ms;
             unsigned long long h[NWG * 2]; unsigned st = 0;
             for (int rep = 0; rep < 5; ++rep) {
@@ -240,7 +249,8 @@ int main(int argc, char** argv) {
                 else if (mode == 10) hipLaunchKernelGGL(handoff_kernel<10>, dim3(NWG), dim3(512), 0, 0, a);
                 else if (mode == 11) hipLaunchKernelGGL(handoff_kernel<11>, dim3(NWG), dim3(512), 0, 0, a);
                 else if (mode == 12) hipLaunchKernelGGL(handoff_kernel<12>, dim3(NWG), dim3(512), 0, 0, a);
-                else hipLaunchKernelGGL(handoff_kernel<13>, dim3(NWG), dim3(512), 0, 0, a);
+                else if (mode == 13) hipLaunchKernelGGL(handoff_kernel<13>, dim3(NWG), dim3(512), 0, 0, a);
+                else hipLaunchKernelGGL(handoff_kernel<14>, dim3(NWG), dim3(512), 0, 0, a);
                 CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
                 float t; CHECK(hipEventElapsedTime(&t, e0, e1)); ms.push_back(t);
                 CHECK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&st, status, 4, hipMemcpyDeviceToHost));
