@@ -34,46 +34,104 @@ def _st():
     return _lib.stream_ptr()
 
 
-def pack_train(model, dev, part: str = "all") -> Dict[str, object]:
-    """Device-side operand layouts of the CURRENT parameters (re-done every step: the optimizer moves them).
-    part = "conv" (what the step needs first), "rnn" (LSTM + fc, packed on the side stream beside the convolutions) or "all"."""
-    from .model import _pack_bilstm
-    H, L, F = model.hidden_size, model.num_layers, model.n_mels
-    Hp, K1, Fo2 = _ru(H, 16), _ru(2 * H, 64), (F // 2) // 2
-    K0 = Fo2 * 64
-    f32 = dict(device=dev, dtype=torch.float32)
-    t: Dict[str, object] = {}
-    t["dims"] = dict(H=H, Hp=Hp, L=L, F=F, F1=F // 2, Fo2=Fo2, K0=K0, K1=K1)
-    if part in ("all", "conv"):
+class _PackedSmall:
+    """The packed operands of one parameter set of CNNRNNModel: persistent destination tensors and the two job tables of pack_plan.PackPlan
+    (convolutions: what the step needs first; LSTM + fc: packed on the side stream beside the convolutions).  Layer 0's W_ih keeps its own
+    kernel (mt_pack_wih_cf: the feature re-ordering) and its transpose."""
+
+    def __init__(self, model, dev):
+        from .pack_plan import PackPlan, one, two
+        dev = _norm_dev(dev)
+        H, L, F = model.hidden_size, model.num_layers, model.n_mels
+        Hp, K1, Fo2 = _ru(H, 16), _ru(2 * H, 64), (F // 2) // 2
+        K0 = Fo2 * 64
+        f32 = dict(device=dev, dtype=torch.float32)
+        bf = dict(device=dev, dtype=torch.bfloat16)
+        self.key = _param_key(model, dev)
+        self.conv: Dict[str, object] = {}
+        self.rnn: Dict[str, object] = {}
+        self.dims = dict(H=H, Hp=Hp, L=L, F=F, F1=F // 2, Fo2=Fo2, K0=K0, K1=K1)
+
+        def P(p):                                   # a parameter as the kernels read it: f32, on the device, contiguous -- no copy
+            q = p.detach()
+            if not (q.is_cuda and q.device == dev and q.dtype == torch.float32 and q.is_contiguous()):
+                raise RuntimeError("train_step: parameters must be contiguous f32 tensors on the training device")
+            return q
+
+        t, cp = self.conv, PackPlan(dev)
         c1, bn1, c2, bn2 = model.cnn[0], model.cnn[1], model.cnn[4], model.cnn[5]
-        t["w1"] = c1.weight.detach().to(**f32).reshape(32, 9).contiguous()
-        t["b1"] = c1.bias.detach().to(**f32).contiguous()
-        w2 = c2.weight.detach().to(**f32)
-        t["w2"] = w2.permute(0, 2, 3, 1).reshape(64, 288).to(torch.bfloat16).contiguous()           # [co][tap*32 + ci]
-        t["b2"] = c2.bias.detach().to(**f32).contiguous()
-        wd = torch.zeros(64, 576, **f32)                                                             # dgrad: [ci (pad 64)][tap'*64 + co]
-        wd[:32] = w2.flip(2, 3).permute(1, 2, 3, 0).reshape(32, 576)
-        t["w2d"] = wd.to(torch.bfloat16)
+        t["w1"], t["b1"] = P(c1.weight).view(32, 9), P(c1.bias)
+        w2 = P(c2.weight)                                                                            # [64][32][3][3]
+        t["w2"], t["b2"] = torch.zeros(64, 288, **bf), P(c2.bias)                                    # [co][tap*32 + ci]
+        cp.add(t["w2"], w2, one(64, 288), two(9, 32, 32, 1, 9))
+        t["w2d"] = torch.zeros(64, 576, **bf)                                                        # dgrad: [ci (pad 64)][tap'*64 + co] = w2[co][ci][8 - tap']
+        cp.add(t["w2d"], w2, one(32, 9), two(9, 64, 64, -1, 288), base=8)
         t["zero64"] = torch.zeros(64, **f32)
         for i, bn in ((1, bn1), (2, bn2)):
-            t[f"g{i}"] = bn.weight.detach().to(**f32).contiguous()
-            t[f"be{i}"] = bn.bias.detach().to(**f32).contiguous()
-    if part in ("all", "rnn"):
-        cols = (torch.arange(64)[None, :] * Fo2 + torch.arange(Fo2)[:, None]).reshape(-1)             # kernel col f*64+c -> ref col c*Fo2+f
-        t["w_ih"], t["b_g"], t["w_hh"] = _pack_bilstm(model.rnn, L, H, cols, dev, k0_cf=(64, K0 // 64))
-        t["w_ihT"] = []
+            t[f"g{i}"], t[f"be{i}"] = P(bn.weight), P(bn.bias)
+        self.conv_plan = cp.finalize()
+
+        t, up = self.rnn, PackPlan(dev)
+        self.K0, self.Hp, self.H = K0, Hp, H
+        t["w_ih"], t["b_g"], t["w_hh"], t["w_ihT"] = [], [], [], []
+        self.l0 = []
         for l in range(L):
-            K = K0 if l == 0 else K1
-            wT = torch.zeros(_ru(K, 128), 8 * Hp, device=dev, dtype=torch.bfloat16)
-            wT[:K] = t["w_ih"][l][:8 * Hp].t()
-            t["w_ihT"].append(wT)
-        fw = torch.zeros(128, K1, **f32)
-        fw[:88, :2 * H] = model.fc.weight.detach().to(**f32)
-        t["fc_w"] = fw.to(torch.bfloat16)
-        fwT = torch.zeros(_ru(K1, 128), 128, device=dev, dtype=torch.bfloat16)
-        fwT[:K1] = t["fc_w"].t()
-        t["fc_wT"] = fwT
-        t["fc_b"] = model.fc.bias.detach().to(**f32).contiguous()
+            K, Kp = (K0, K0) if l == 0 else (2 * H, K1)
+            t["w_ih"].append(torch.zeros(_ru(8 * Hp, 128), Kp, **bf))
+            t["b_g"].append(torch.zeros(2 * 4 * Hp, **f32))
+            t["w_hh"].append(torch.zeros(2, 4 * Hp, Hp, **f32))
+            t["w_ihT"].append(torch.zeros(_ru(Kp, 128), 8 * Hp, **bf))
+            for di, suf in enumerate(("", "_reverse")):
+                wi, wh = P(getattr(model.rnn, f"weight_ih_l{l}{suf}")), P(getattr(model.rnn, f"weight_hh_l{l}{suf}"))
+                bi, bh = P(getattr(model.rnn, f"bias_ih_l{l}{suf}")), P(getattr(model.rnn, f"bias_hh_l{l}{suf}"))
+                if l == 0:                                                                           # reference column c*Fo2+f -> kernel column f*64+c
+                    self.l0.append((wi, di * 4 * Hp))
+                else:
+                    up.add(t["w_ih"][l], wi, two(4, Hp, H, H * K, K), one(K, 1), at=(di * 4 * Hp, 0), shape=(4 * Hp, Kp))
+                    up.add(t["w_ihT"][l], wi, one(K, 1), two(4, Hp, H, H * K, K), tr=True, at=(0, di * 4 * Hp), shape=(t["w_ihT"][l].shape[0], 4 * Hp))
+                up.add(t["b_g"][l].view(8, Hp), bi, one(4, H), one(H, 1), src2=bh, at=(di * 4, 0), shape=(4, Hp))
+                up.add(t["w_hh"][l].view(2 * 4 * Hp, Hp), wh, two(4, Hp, H, H * H, H), one(H, 1), at=(di * 4 * Hp, 0), shape=(4 * Hp, Hp))
+        fw = P(model.fc.weight)                                                                      # [88][2H]
+        t["fc_w"], t["fc_b"] = torch.zeros(128, K1, **bf), P(model.fc.bias)
+        up.add(t["fc_w"], fw, one(88, 2 * H), one(2 * H, 1))
+        t["fc_wT"] = torch.zeros(_ru(K1, 128), 128, **bf)
+        up.add(t["fc_wT"], fw, one(2 * H, 1), one(88, 2 * H), tr=True)
+        self.rnn_plan = up.finalize()
+
+    def run(self, part):
+        if part in ("all", "conv"):
+            self.conv_plan.run()
+        if part in ("all", "rnn"):
+            w0, wT0 = self.rnn["w_ih"][0], self.rnn["w_ihT"][0]
+            for w, row0 in self.l0:
+                check(lib.mt_pack_wih_cf(ptr(w), ptr(w0), self.K0, row0, self.H, self.Hp, 64, self.K0 // 64, _lib.DT_BF16, _st()), "mt_pack_wih_cf")
+            check(lib.mt_transpose_bf16(ptr(w0), self.K0, 8 * self.Hp, self.K0, ptr(wT0), 8 * self.Hp, self.K0, _st()), "mt_transpose_bf16")
+            self.rnn_plan.run()
+
+
+def _norm_dev(dev):
+    dev = torch.device(dev)
+    return torch.device(dev.type, torch.cuda.current_device()) if dev.type == "cuda" and dev.index is None else dev
+
+
+def _param_key(model, dev):
+    return (str(_norm_dev(dev)),) + tuple(p.data_ptr() for p in model.parameters())
+
+
+def pack_train(model, dev, part: str = "all") -> Dict[str, object]:
+    """Device-side operand layouts of the CURRENT parameters (re-done every step: the optimizer moves them) on the current stream: one
+    mt_pack_jobs launch per part (round 4: ~60 torch launches before), layer 0's W_ih by mt_pack_wih_cf + one transpose.
+    part = "conv" (what the step needs first), "rnn" (LSTM + fc, packed on the side stream beside the convolutions) or "all".
+    The returned tensors are REUSED by the next call (one step per model at a time)."""
+    pk = getattr(model, "_train_packed", None)
+    if pk is None or pk.key != _param_key(model, dev):
+        pk = model._train_packed = _PackedSmall(model, dev)
+    pk.run(part)
+    t: Dict[str, object] = {"dims": pk.dims}
+    if part in ("all", "conv"):
+        t.update(pk.conv)
+    if part in ("all", "rnn"):
+        t.update(pk.rnn)
     return t
 
 

@@ -694,3 +694,27 @@ def test_mt_allreduce_with_a_single_rank_rccl_communicator(mta):
         rccl.ncclCommDestroy(comm)
     assert lib.mt_init(0) == 0 and lib.mt_init(99) < 0
     assert lib.mt_workspace_bytes(5, 16, 937, 512) == lib.mt_lstm_bwd_part_bytes(16, 937, 512) == 937 * 2 * 16 * 16 * 1024
+
+
+@pytest.mark.gpu
+def test_pack_job_tables_equal_the_torch_expressions_small_model(mta):
+    """CNNRNNModel's training operands as mt_pack_jobs writes them (train_step.pack_train) against the torch expressions they replace
+    (tests/tools/pack_reference_small.py): bit for bit, before and after the parameters move."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from pack_reference_small import pack_train_torch
+    from music_transcription_amd.train_step import pack_train
+    m = mta.TranscriptionModel(model_type="cnn_rnn", n_mels=64, hidden_size=24, num_layers=3, dropout=0.0, device="cuda")
+    net = m.model
+    for rnd in range(2):
+        got, want = pack_train(net, "cuda"), pack_train_torch(net, torch.device("cuda"))
+        torch.cuda.synchronize()
+        for k, w in want.items():
+            for i, (g_, w_) in enumerate(zip(got[k], w) if isinstance(w, (list, tuple)) else [(got[k], w)]):
+                if not isinstance(w_, torch.Tensor):
+                    continue
+                assert g_.shape == w_.shape and g_.dtype == w_.dtype, (k, i, g_.shape, w_.shape)
+                assert torch.equal(g_, w_), (rnd, k, i, float((g_.float() - w_.float()).abs().max()))
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(torch.randn_like(p) * 0.01)
