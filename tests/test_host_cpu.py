@@ -491,3 +491,19 @@ def test_workspace_query_and_allreduce_argument_checks(mta):
     assert lib.mt_workspace_bytes(7, 320, 0, 0) == lib.mt_mel_plan_bytes(320) and lib.mt_workspace_bytes(8, 0, 0, 0) == lib.mt_adam_workspace_bytes()
     assert lib.mt_workspace_bytes(99, 1, 1, 1) == 0 and "unknown kind" in _lib.last_error()
     assert lib.mt_allreduce(None, 4, 0, None, None) == _lib_code("MT_EINVAL")
+
+
+def test_pack_job_record_matches_the_c_struct(tmp_path):
+    """pack_plan.JOB_DTYPE is the byte layout of mt_pack_job (include/mt_hip.h): size and every field offset, read from the C compiler."""
+    import subprocess
+    from music_transcription_amd.pack_plan import JOB_DTYPE, one, two
+    fields = [n for n in JOB_DTYPE.names]
+    src = tmp_path / "o.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mt_hip.h"\nint main(void) { printf("%zu", sizeof(mt_pack_job));\n'
+                   + "".join(f'printf(" %zu", offsetof(mt_pack_job, {n}));\n' for n in fields) + "return 0; }\n")
+    exe = tmp_path / "o"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == JOB_DTYPE.itemsize
+    assert out[1:] == [JOB_DTYPE.fields[n][1] for n in fields]
+    assert one(5, 3) == (1, 1 << 30, 5, 0, 3) and two(4, 32, 24, 7, 1) == (4, 32, 24, 7, 1)
