@@ -699,6 +699,14 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             return torch.empty(*shape, **f32)
         direct.add(name)
         return t
+
+    def zerog(name, *shape):
+        # an analytically zero gradient (a convolution bias in front of a BatchNorm): the flat gradient buffer is zero since zero_grad()
+        t = tgt(name, shape) if tgt is not None else None
+        if t is None:
+            return torch.zeros(*shape, **f32)
+        direct.add(name)
+        return t
     feat = sv["feat"]
     ph = 1.5 * p_drop
     with torch.cuda.device(dev):
@@ -734,12 +742,11 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             check(lib.mt_transpose_bf16(ptr(sh), Hs, M, Hs, ptr(shT), Mpad, Hs, _st()), "mt_transpose_bf16")
             gh = torch.empty(384, Hs, **f32)
             _gemm(dLT, Mpad, shT, Mpad, gh, Hs, 264, Hs, Mpad)
-            ghb = torch.empty(264, **f32)
-            check(lib.mt_rowsum_bf16(ptr(dLT), Mpad, M, ptr(ghb), 264, _st()), "mt_rowsum_bf16")
             for i, n in enumerate(("frame", "onset", "offset")):
-                w = torch.empty(88, H, **f32)
+                w, hb = newg(f"{n}_head.weight", 88, H), newg(f"{n}_head.bias", 88)
                 _gather4(gh, i * 88 * Hs, w, (1, 1, 88, H), (0, 0, Hs, 1))
-                g[f"{n}_head.weight"], g[f"{n}_head.bias"] = w, ghb[i * 88:(i + 1) * 88].clone()
+                check(lib.mt_rowsum_bf16(ptr(dLT[i * 88:]), Mpad, M, ptr(hb), 88, _st()), "mt_rowsum_bf16")
+                g[f"{n}_head.weight"], g[f"{n}_head.bias"] = w, hb
             dsh = torch.empty(M, Hs, **f32)
             _gemm(dL, 384, pk["heads_wT"], 384, dsh, Hs, M, Hs, 384)
             dzs = ws.zeros("dzs", Mpad, Hs, **bf)
@@ -774,9 +781,9 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             part = torch.zeros(nsl, 2, comb, **f32)
             check(lib.mt_layernorm_residual_bwd(ptr(sv["r32"]), comb, ptr(sv["proj"]), comb, ptr(pk["ln_g"]), ptr(sv["ln_stats"]), ptr(dfeat), comb,
                                                 ptr(dxln), comb, ptr(part), M, comb, _st()), "mt_layernorm_residual_bwd")
-            lng = torch.empty(2, comb, **f32)
-            check(lib.mt_sum_slices_f32(ptr(part), 2 * comb, comb, nsl, ptr(lng), comb, 2, comb, _st()), "mt_sum_slices_f32")
-            g["attention_norm.weight"], g["attention_norm.bias"] = lng[0].clone(), lng[1].clone()
+            g["attention_norm.weight"], g["attention_norm.bias"] = newg("attention_norm.weight", comb), newg("attention_norm.bias", comb)
+            for i_, k_ in enumerate(("attention_norm.weight", "attention_norm.bias")):
+                check(lib.mt_sum_slices_f32(ptr(part[0, i_]), 2 * comb, comb, nsl, ptr(g[k_]), comb, 1, comb, _st()), "mt_sum_slices_f32")
             # proj
             dpb = ws.zeros("dpb", Mpad, Cp, **bf)
             check(lib.mt_f32_to_bf16_rows(ptr(dxln), comb, ptr(dpb), Cp, M, comb, 1.0, _st()), "mt_f32_to_bf16_rows")
@@ -928,14 +935,14 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
         z256 = pk["zeros256"]
         dzf = torch.empty(B * F2 * T, 256, **bf)
         dzf_lo = lo_like(dzf)
-        g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"] = torch.empty(256, **f32), torch.empty(256, **f32)
+        g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"] = newg("freq_aware_conv.1.weight", 256), newg("freq_aware_conv.1.bias", 256)
         _bn_act_bwd(None, 0, dX0, K0, sv["zf"], sv["sf"], None, None, masks[2], dzf, None,
                     (g["freq_aware_conv.1.weight"], g["freq_aware_conv.1.bias"], None, None), B, F2, T, 256, 1, 1, dev, dza_lo=dzf_lo)
         dr2 = torch.empty(B * F2 * T, 128, **bf)
         _conv(dzf, None, pk["fa_wdA"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256)
         _conv(dzf.reshape(-1)[128:], None, pk["fa_wdB"], z256, dr2, B, F2, T, 128, 0, 128, 7, pitchA=256, accum=1)
         wgrad("freq_aware_conv.0.weight", dzf, dzf_lo, 256, sv["r2"], 128, F2, 256, 128, 7, 3)
-        g["freq_aware_conv.0.bias"] = torch.zeros(256, **f32)          # a conv bias in front of a BatchNorm: analytically zero
+        g["freq_aware_conv.0.bias"] = zerog("freq_aware_conv.0.bias", 256)          # a conv bias in front of a BatchNorm: analytically zero
         # ---- residual blocks, top down
         dout = dr2
         for name, mask_i in (("rb2", 1), ("rb1", 0)):
@@ -944,11 +951,11 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             N = B * Fin * T
             dz2, dzs = torch.empty(N, cout, **bf), torch.empty(N, cout, **bf)
             dz2_lo, dzs_lo = lo_like(dz2), lo_like(dzs)
-            gr = {k: torch.empty(cout, **f32) for k in ("bn2.weight", "bn2.bias", "skip.1.weight", "skip.1.bias", "bn1.weight", "bn1.bias")}
+            pfx = "res_block1" if name == "rb1" else "res_block2"
+            gr = {k: newg(f"{pfx}.{k}", cout) for k in ("bn2.weight", "bn2.bias", "skip.1.weight", "skip.1.bias", "bn1.weight", "bn1.bias")}
             _bn_act_bwd(dout, cout, None, 0, st["z2"], st["s2"], st["zs"], st["ss"], st["mask"], dz2, dzs,
                         (gr["bn2.weight"], gr["bn2.bias"], gr["skip.1.weight"], gr["skip.1.bias"]), B, Fin, T, cout, 1, pool, dev,
                         dza_lo=dz2_lo, dzb_lo=dzs_lo)
-            pfx = "res_block1" if name == "rb1" else "res_block2"
             wgrad(pfx + ".conv2.weight", dz2, dz2_lo, cout, st["y1"], cout, Fin, cout, cout, 3, 3)
             wgrad(pfx + ".skip.0.weight", dzs, dzs_lo, cout, xin, cin, Fin, cout, cin, 1, 1)
             dy1 = torch.empty(N, cout, **bf)
@@ -962,13 +969,13 @@ def backward_train_large(model, sv, dlogits: torch.Tensor) -> Dict[str, torch.Te
             _conv(dz1, dzs, pk[name + "c1s_wd"], z256, dxin, B, Fin, T, cout, cout, cin_p, 3)
             wgrad(pfx + ".conv1.weight", dz1, dz1_lo, cout, xin, cin, Fin, cout, cin, 3, 3)
             for k in ("conv1.bias", "conv2.bias", "skip.0.bias"):
-                g[f"{pfx}.{k}"] = torch.zeros(cout, **f32)
+                g[f"{pfx}.{k}"] = zerog(f"{pfx}.{k}", cout)
             for k, v in gr.items():
                 g[f"{pfx}.{k}"] = v
             dout = dxin
         # ---- conv1 (z1 recomputed from the input); dout = d a1, [B][F1][T][64] with channels 0..31 valid
-        g["conv1.0.weight"], g["conv1.0.bias"] = torch.empty(32, 1, 3, 3, **f32), torch.empty(32, **f32)
-        g["conv1.1.weight"], g["conv1.1.bias"] = torch.empty(32, **f32), torch.empty(32, **f32)
+        g["conv1.0.weight"], g["conv1.0.bias"] = newg("conv1.0.weight", 32, 1, 3, 3), newg("conv1.0.bias", 32)
+        g["conv1.1.weight"], g["conv1.1.bias"] = newg("conv1.1.weight", 32), newg("conv1.1.bias", 32)
         sums = torch.zeros(512, device=dev, dtype=torch.float64)
         check(lib.mt_conv1_bwd(ptr(x), ptr(pk["w1"]), ptr(pk["b1"]), ptr(sv["mean1"]), ptr(sv["rstd1"]), ptr(pk["g1"]), ptr(pk["be1"]),
                                ptr(dout), 64, ptr(sums[128:]), ptr(g["conv1.0.weight"]), ptr(g["conv1.0.bias"]), ptr(g["conv1.1.weight"]),
