@@ -213,8 +213,12 @@ def bench_train(args):
     # the side streams the step runs fastest with (every rank the same number of steps)
     from music_transcription_amd.train_step_large import autotune_side_streams
     autotune_side_streams(lambda: step(0), dev, candidates=4, steps=1)
-    for _ in range(2):                                 # (allocator pools of the chosen side streams settle: a device allocation is ~80 ms)
-        step(0)
+    # untimed steps on the chosen streams, queued back to back as the timed region queues them (the host runs a step ahead of the device, so
+    # blocks that a side stream still holds are not back yet when the next step asks: the allocator's pools must have grown to THAT pattern
+    # -- a device allocation inside the timed region costs up to 80 ms)
+    for _ in range(2):
+        for j in range(3):
+            step(j)
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -540,8 +544,9 @@ def section_train(mta, dev, cores, do_cpu):
         step()
     from music_transcription_amd.train_step_large import autotune_side_streams
     tuned = autotune_side_streams(step, dev, candidates=4, steps=2)     # (see section_train_large)
-    for _ in range(2):
-        step()
+    for _ in range(2):                                 # (back to back, as the timed region queues them: see bench_train)
+        for _j in range(3):
+            step()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -619,8 +624,9 @@ def section_train_large(mta, dev, cores, do_cpu):
     # they are decides whether their work overlaps the calling stream's; by now this process has used a dozen streams)
     from music_transcription_amd.train_step_large import autotune_side_streams
     tuned = autotune_side_streams(step, dev, candidates=4, steps=1)
-    for _ in range(2):                                 # (untimed steps on the chosen streams, each behind a device synchronisation as the timed region
-        step()                                         #  is: the allocator's per-stream pools settle -- a device allocation costs up to 80 ms)
+    for _ in range(2):                                 # (untimed steps on the chosen streams, queued back to back as the timed region queues them: the
+        for _j in range(3):                            #  allocator's per-stream pools settle to the pattern of a host that runs a step ahead -- a device
+            step()                                     #  allocation inside the timed region costs up to 80 ms)
         torch.cuda.synchronize()
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
