@@ -6,8 +6,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(ROOT, "music-transcription_amd", "csrc")
 so = "/tmp/libmt_hip_diag.so"
 extra = os.environ.get("MT_DIAG_FLAGS", "")
-srcs = [os.path.join(csrc, f) for f in ("api.hip", "lstm.hip", "residency.hip")]
-subprocess.check_call(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMT_LSTM_DIAG {extra} -I{ROOT}/include -shared {' '.join(srcs)} -o {so}", shell=True)
+# the library's objects with the recurrence rebuilt under -DMT_LSTM_DIAG (run `make -C music-transcription_amd/csrc` first)
+objs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".o") and f != "lstm.o"]
+subprocess.check_call(f"/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DMT_LSTM_DIAG {extra} -I{ROOT}/include -c {csrc}/lstm.hip -o /tmp/lstm_diag.o "
+                      f"2>/dev/null && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/lstm_diag.o {' '.join(objs)} -o {so}", shell=True)
 lib = C.CDLL(so)
 B, T, H = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (32, 938, 512)))
 vp = C.c_void_p
