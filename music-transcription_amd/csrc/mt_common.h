@@ -101,4 +101,31 @@ template <int DT> __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x
 }
 #define MT_REQUIRE_DT(dt, who) MT_REQUIRE((dt) == MT_DT_BF16 || (dt) == MT_DT_F16, MT_EINVAL, who ": operand dtype must be MT_DT_BF16 or MT_DT_F16")
 
+// ---- position index -> (b, f, t) without integer division.  x / d for 0 <= x < 2^31 as one multiply-high and a shift: m = floor(2^(31 + l) / d) + 1,
+// l = ceil(log2 d) (Granlund-Montgomery; exact on 31 bits).  The elementwise training kernels turned a linear position index into its three
+// coordinates with 64-bit divisions -- a few hundred instructions per position in front of a handful of loads.
+struct Div3 { unsigned T, F, mT, sT, mF, sF; };
+static inline void div_magic(unsigned d, unsigned* m, unsigned* s) {
+    if (d <= 1) { *m = 0; *s = 0; return; }
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    *m = (unsigned)(((1ull << (31 + l)) / d) + 1);
+    *s = l - 1;
+}
+static inline Div3 make_div3(int T, int F) {
+    Div3 d{(unsigned)T, (unsigned)F, 0, 0, 0, 0};
+    div_magic(d.T, &d.mT, &d.sT);
+    div_magic(d.F, &d.mF, &d.sF);
+    return d;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned x, unsigned d, unsigned m, unsigned s) { return d <= 1 ? x : (__umulhi(x, m) >> s); }
+// i < 2^31 -> t = i % T, f = (i / T) % F, b = i / (T * F)
+__device__ __forceinline__ void div3(unsigned i, const Div3& d, int& t, int& f, int& b) {
+    const unsigned q = fast_div(i, d.T, d.mT, d.sT);
+    t = (int)(i - q * d.T);
+    const unsigned q2 = fast_div(q, d.F, d.mF, d.sF);
+    f = (int)(q - q2 * d.F);
+    b = (int)q2;
+}
+
 }  // namespace mt

@@ -39,14 +39,15 @@ __device__ __forceinline__ void block_sum_atomic(float (&acc)[NV], double* dst, 
 // every (b, f, t); z = conv(x)[c] + bias[c].
 __global__ __launch_bounds__(256) void conv1_stats_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, double* __restrict__ sums,
-                                                          int B, int F, int T) {
+                                                          int B, int F, int T, Div3 dv) {
     __shared__ float lds[4][64];
     float sq[64];                                     // [0..31] sum z, [32..63] sum z^2
 #pragma unroll
     for (int c = 0; c < 64; ++c) sq[c] = 0.0f;
     const long long n = (long long)B * F * T;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int t = (int)(i % T), f = (int)((i / T) % F), b = (int)(i / ((long long)T * F));
+        int t, f, b;
+        div3((unsigned)i, dv, t, f, b);
         const float* m = x + (size_t)b * F * T;
         float p[9];
 #pragma unroll
@@ -140,15 +141,44 @@ __global__ __launch_bounds__(256) void bn_stats_cl_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256) void bn_relu_pool_apply_kernel(const bf16_t* __restrict__ z, const float* __restrict__ mean,
                                                                  const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, bf16_t* __restrict__ X, int ldx,
-                                                                 int B, int F, int T) {
-    const int c = threadIdx.x & 63, Fo = F >> 1;
-    const float sc = gamma[c] * rstd[c], sh = beta[c] - mean[c] * sc;
-    const long long n = (long long)B * Fo * T;
-    for (long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long long)gridDim.x * 4) {
-        const int t = (int)(i % T), fo = (int)((i / T) % Fo), b = (int)(i / ((long long)T * Fo));
-        const size_t p0 = (((size_t)b * F + 2 * fo) * T + t) * 64 + c;
-        const float v0 = fmaf(bf16_to_f32(z[p0]), sc, sh), v1 = fmaf(bf16_to_f32(z[p0 + (size_t)T * 64]), sc, sh);
-        X[((size_t)t * B + b) * ldx + (size_t)fo * 64 + c] = f32_to_bf16(fmaxf(fmaxf(v0, v1), 0.0f));
+                                                                 int B, int F, int T, Div3 dv) {
+    // one thread = EIGHT channels (one 16-byte load per pre-pool row) of a pooled position, two positions per loop pass with their four loads
+    // issued first (round 4; the first version moved one 2-byte value per thread and load, behind three 64-bit divisions per position: 1.4 TB/s)
+    const int cg = threadIdx.x & 7, c0 = cg * 8, Fo = F >> 1;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = gamma[c0 + j] * rstd[c0 + j]; sh[j] = beta[c0 + j] - mean[c0 + j] * sc[j]; }
+    const unsigned n = (unsigned)B * Fo * T, stride = gridDim.x * 32;
+    for (unsigned i0 = blockIdx.x * 32 + (threadIdx.x >> 3); i0 < n; i0 += 2 * stride) {
+        uint4 r0[2], r1[2];
+        size_t po[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned i = i0 + u * stride;
+            r0[u] = r1[u] = make_uint4(0, 0, 0, 0);
+            po[u] = 0;
+            if (i >= n) continue;
+            int t, fo, b;
+            div3(i, dv, t, fo, b);
+            const size_t p0 = (((size_t)b * F + 2 * fo) * T + t) * 64 + c0;
+            r0[u] = *(const uint4*)(z + p0);
+            r1[u] = *(const uint4*)(z + p0 + (size_t)T * 64);
+            po[u] = ((size_t)t * B + b) * ldx + (size_t)fo * 64 + c0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (i0 + u * stride >= n) continue;
+            const unsigned w0[4] = {r0[u].x, r0[u].y, r0[u].z, r0[u].w}, w1[4] = {r1[u].x, r1[u].y, r1[u].z, r1[u].w};
+            unsigned o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a0 = fmaf(__uint_as_float(w0[j] << 16), sc[2 * j], sh[2 * j]), a1 = fmaf(__uint_as_float(w1[j] << 16), sc[2 * j], sh[2 * j]);
+                const float b0 = fmaf(__uint_as_float(w0[j] & 0xFFFF0000u), sc[2 * j + 1], sh[2 * j + 1]);
+                const float b1 = fmaf(__uint_as_float(w1[j] & 0xFFFF0000u), sc[2 * j + 1], sh[2 * j + 1]);
+                o[j] = (unsigned)f32_to_bf16(fmaxf(fmaxf(a0, a1), 0.0f)) | ((unsigned)f32_to_bf16(fmaxf(fmaxf(b0, b1), 0.0f)) << 16);
+            }
+            *(uint4*)(X + po[u]) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
@@ -164,7 +194,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           double* __restrict__ sums, bf16_t* __restrict__ dz, bf16_t* __restrict__ dz_lo,
-                                                          const unsigned* __restrict__ tie, int B, int F, int T) {
+                                                          const unsigned* __restrict__ tie, int B, int F, int T, Div3 dv) {
     // one thread = FOUR channels of one pooled position (two pre-pool rows), two positions per loop pass with all their loads issued
     // first (8-byte loads of z, 16-byte loads of dX; the first version moved one 2-byte value per thread and round trip: 25 % of the HBM rate)
     __shared__ float red[8][256];
@@ -194,7 +224,8 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const float* __restric
 #pragma unroll
             for (int j = 0; j < 4; ++j) g4[u][j] = 0.0f;
             if (!act[u]) continue;
-            const int t = (int)(i % T), fo = (int)((i / T) % Fh), b = (int)(i / ((long long)T * Fh));
+            int t, fo, b;
+            div3((unsigned)i, dv, t, fo, b);
             pp[u] = (((size_t)b * F + 2 * fo) * T + t) * 64 + c0;
             pr[u] = fo < Fo;
             r0[u] = *(const uint2*)(z + pp[u]);
@@ -554,7 +585,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const bf16_t* __restrict__ da, int ldc, double* __restrict__ sums,
-                                                        double* __restrict__ wacc, int B, int F, int T) {
+                                                        double* __restrict__ wacc, int B, int F, int T, Div3 dv) {
     const int Fo = F >> 1, Fh = (F + 1) >> 1;
     const int cg = WGRAD ? blockIdx.y * 8 : 0;
     constexpr int NC = WGRAD ? 8 : 32;
@@ -570,7 +601,8 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
     }
     const long long n = (long long)B * Fh * T;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const int t = (int)(i % T), fo = (int)((i / T) % Fh), b = (int)(i / ((long long)T * Fh));
+        int t, fo, b;
+        div3((unsigned)i, dv, t, fo, b);
         const bool pair = fo < Fo;
         const float* m = x + (size_t)b * F * T;
         float p[4][3];
@@ -661,7 +693,8 @@ extern "C" int mt_conv1_stats(const float* x, const float* w, const float* bias,
     MT_CHECK_HIP(hipMemsetAsync(sums64, 0, 64 * sizeof(double), ST(stream)));
     const long long n = (long long)B * F * T;
     const int grid = (int)((n + 256 * 16 - 1) / (256 * 16) < 512 ? (n + 256 * 16 - 1) / (256 * 16) : 512);
-    hipLaunchKernelGGL(conv1_stats_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, ST(stream), x, w, bias, sums64, B, F, T);
+    MT_REQUIRE(n < ((long long)1 << 31), MT_EUNSUPPORTED, "mt_conv1_stats: more than 2^31 positions");
+    hipLaunchKernelGGL(conv1_stats_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, ST(stream), x, w, bias, sums64, B, F, T, make_div3(T, F));
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
@@ -691,10 +724,12 @@ extern "C" int mt_bn_stats_cl(const void* z, long long N, int C, double* sums, m
 extern "C" int mt_bn_relu_pool_apply(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                      void* X, int ldx, int B, int F, int T, mt_stream_t stream) {
     MT_REQUIRE(z && mean && rstd && gamma && beta && X && B > 0 && F >= 2 && T > 0 && ldx >= (F / 2) * 64, MT_EINVAL, "mt_bn_relu_pool_apply: bad arguments");
+    MT_REQUIRE(ldx % 8 == 0 && ((size_t)X & 15) == 0 && ((size_t)z & 15) == 0, MT_EINVAL, "mt_bn_relu_pool_apply: X rows and z must be 16-byte aligned (ldx %% 8 == 0)");
+    MT_REQUIRE((long long)B * (F / 2) * T < ((long long)1 << 31), MT_EUNSUPPORTED, "mt_bn_relu_pool_apply: more than 2^31 positions");
     long long g = ((long long)B * (F / 2) * T + 63) / 64;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(bn_relu_pool_apply_kernel, dim3((unsigned)g), dim3(256), 0, ST(stream), (const bf16_t*)z, mean, rstd, gamma, beta,
-                       (bf16_t*)X, ldx, B, F, T);
+                       (bf16_t*)X, ldx, B, F, T, make_div3(T, F / 2));
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
@@ -705,12 +740,13 @@ extern "C" int mt_bn_pool_bwd_tie(const float* dX, int ldd, const void* z, const
     MT_REQUIRE(dX && z && mean && rstd && gamma && beta && sums128 && dz && B > 0 && F >= 2 && T > 0, MT_EINVAL, "mt_bn_pool_bwd: bad arguments");
     MT_REQUIRE(ldd % 4 == 0 && ((size_t)dX & 15) == 0, MT_EINVAL, "mt_bn_pool_bwd: dX rows must be 16-byte aligned (ldd %% 4 == 0)");
     MT_CHECK_HIP(hipMemsetAsync(sums128, 0, 128 * sizeof(double), ST(stream)));
+    MT_REQUIRE((long long)B * ((F + 1) / 2) * T < ((long long)1 << 31), MT_EUNSUPPORTED, "mt_bn_pool_bwd: more than 2^31 positions");
     long long g = ((long long)B * ((F + 1) / 2) * T + 127) / 128;     // 16 positions per workgroup and pass, a few passes per thread
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(bn_pool_bwd_kernel<false>, dim3((unsigned)g), dim3(256), 0, ST(stream), dX, ldd, (const bf16_t*)z, mean, rstd, gamma, beta,
-                       sums128, (bf16_t*)nullptr, (bf16_t*)nullptr, tie, B, F, T);
+                       sums128, (bf16_t*)nullptr, (bf16_t*)nullptr, tie, B, F, T, make_div3(T, (F + 1) / 2));
     hipLaunchKernelGGL(bn_pool_bwd_kernel<true>, dim3((unsigned)g), dim3(256), 0, ST(stream), dX, ldd, (const bf16_t*)z, mean, rstd, gamma, beta,
-                       sums128, (bf16_t*)dz, (bf16_t*)dz_lo, tie, B, F, T);
+                       sums128, (bf16_t*)dz, (bf16_t*)dz_lo, tie, B, F, T, make_div3(T, (F + 1) / 2));
     if (dgamma && dbeta) hipLaunchKernelGGL(bn_param_grads_kernel, dim3(1), dim3(64), 0, ST(stream), sums128, dgamma, dbeta, 64);
     MT_CHECK_LAUNCH();
     return MT_OK;
@@ -887,15 +923,16 @@ extern "C" int mt_conv1_bwd(const float* x, const float* w, const float* bias, c
     MT_REQUIRE(B > 0 && F >= 2 && T > 0 && ldc >= 32 && ldc % 8 == 0, MT_EINVAL, "mt_conv1_bwd: bad dims (ldc: >= 32, multiple of 8)");
     MT_CHECK_HIP(hipMemsetAsync(scratch384, 0, 384 * sizeof(double), ST(stream)));
     const long long n = (long long)B * ((F + 1) / 2) * T;
+    MT_REQUIRE(n < ((long long)1 << 31), MT_EUNSUPPORTED, "mt_conv1_bwd: more than 2^31 positions");
     long long g = (n + 256 * 8 - 1) / (256 * 8);
     if (g > 512) g = 512;
     if (g < 1) g = 1;
     double* sums = scratch384;
     double* wacc = scratch384 + 64;
     hipLaunchKernelGGL(conv1_bwd_kernel<false>, dim3((unsigned)g), dim3(256), 0, ST(stream), x, w, bias, mean, rstd, gamma, beta,
-                       (const bf16_t*)da, ldc, sums, wacc, B, F, T);
+                       (const bf16_t*)da, ldc, sums, wacc, B, F, T, make_div3(T, (F + 1) / 2));
     hipLaunchKernelGGL(conv1_bwd_kernel<true>, dim3((unsigned)g, 4), dim3(256), 0, ST(stream), x, w, bias, mean, rstd, gamma, beta,
-                       (const bf16_t*)da, ldc, sums, wacc, B, F, T);
+                       (const bf16_t*)da, ldc, sums, wacc, B, F, T, make_div3(T, (F + 1) / 2));
     hipLaunchKernelGGL(conv1_wgrad_out_kernel, dim3(1), dim3(320), 0, ST(stream), wacc, dW, db);
     hipLaunchKernelGGL(bn_param_grads_kernel, dim3(1), dim3(64), 0, ST(stream), sums, dgamma, dbeta, 32);
     MT_CHECK_LAUNCH();

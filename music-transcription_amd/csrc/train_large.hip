@@ -55,7 +55,8 @@ struct BnActArgs {
     double* sums;                                       // [3][C]: sum dy, sum dy*xhat_a, sum dy*xhat_b
     bf16_t* dza; int pa; bf16_t* dzb; int pb;           // outputs [B][F][T][pitch] (channel c at +c)
     bf16_t* dza_lo; bf16_t* dzb_lo;                     // optional second bf16 pieces (rounding remainders; same pitches)
-};
+    Div3 dv;                                            // position index -> (b, f, t) without integer division (mt_common.h; round 4: the
+};                                                      // streaming BatchNorm passes' statistics halves ran 1.5x as long with 64-bit divisions)
 
 // one thread = 8 channels of one output position (one or two pre-pool rows)
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs a) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(BnActArgs a) {
             tt[u] = ff[u] = bb[u] = 0;
             ra[u][0] = ra[u][1] = rb[u][0] = rb[u][1] = make_uint4(0, 0, 0, 0);
             if (i >= n) continue;
-            tt[u] = (int)(i % a.T); ff[u] = (int)((i / a.T) % Fo); bb[u] = (int)(i / ((long long)a.T * Fo));
+            div3((unsigned)i, a.dv, tt[u], ff[u], bb[u]);
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 if (rr >= nrow) break;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(BnActArgs a) {
             r.za[0] = r.za[1] = r.zb[0] = r.zb[1] = make_uint2(0, 0);
             r.g = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (!act[u]) continue;
-            r.t = (int)(i % a.T); r.fh = (int)((i / a.T) % Fh); r.b = (int)(i / ((long long)a.T * Fh));
+            div3((unsigned)i, a.dv, r.t, r.fh, r.b);
             r.has_out = r.fh < Fo;                       // (pool with odd F: the last row has no pooled output)
             const int nrow = (POOL && r.has_out) ? 2 : 1;
 #pragma unroll
@@ -591,6 +592,8 @@ extern "C" int mt_bn_act_fwd(const void* za, const float* mean_a, const float* r
     const int Fo = pool ? F / 2 : F;
     MT_REQUIRE(out && (out_mode == 0 || (out_mode == 1 && ldx >= Fo * C && ldx % 8 == 0)), MT_EINVAL, "mt_bn_act_fwd: bad output arguments");
     const long long n = (long long)B * Fo * T;
+    MT_REQUIRE(n < ((long long)1 << 31), MT_EUNSUPPORTED, "mt_bn_act_fwd: more than 2^31 positions");
+    a.dv = make_div3(T, Fo);
     const int ppb = 256 / (C / 8);
     long long g = (n + 2 * ppb - 1) / (2 * ppb);
     if (g > 8192) g = 8192;
@@ -623,6 +626,8 @@ extern "C" int mt_bn_act_bwd(const void* dout_cl, int ldd_cl, const float* dout_
     MT_CHECK_HIP(hipMemsetAsync(sums, 0, 3 * (size_t)C * sizeof(double), ST(stream)));
     const int Fh = pool ? (F + 1) / 2 : F;
     const long long n = (long long)B * Fh * T;
+    MT_REQUIRE(n < ((long long)1 << 31), MT_EUNSUPPORTED, "mt_bn_act_bwd: more than 2^31 positions");
+    a.dv = make_div3(T, Fh);
     const int ppb = 256 / (C / 4);                // positions per workgroup and pass (a thread = 4 channels), two passes per loop trip
     long long g = (n + 2 * ppb - 1) / (2 * ppb);
     if (g > 2048) g = 2048;                       // (pass 1 ends in 8 - 12 C/4 f64 atomics per workgroup)
