@@ -644,14 +644,14 @@ __global__ __launch_bounds__(320, 4) void lstm_rec16_kernel(LstmArgs a) {
 // the value as fp32 to Y (residual / LayerNorm input of the Large model).
 template <int DT>
 __global__ void lstm_relayout_kernel(const f16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, float* __restrict__ Y, int ldy,
-                                     int col_off, int B, int T, int H, int Hv) {
+                                     int col_off, int B, int T, int H, int Hv, Div3 dv, unsigned mB, unsigned sB) {
     const int nkb = H >> 3, nkv = (Hv + 7) >> 3;
-    const size_t total = (size_t)T * B * 2 * nkv;
-    for (size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        const int kb = id % nkv;
-        const int d = (id / nkv) & 1;
-        const size_t m = id / (2 * nkv);
-        const int t = m / B, b = m - (size_t)t * B, g = b >> 5, bl = b & 31;
+    const unsigned total = (unsigned)T * B * 2 * nkv;
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        int kb, d, mi;
+        div3(id, dv, kb, d, mi);                        // id = (m * 2 + d) * nkv + kb, without integer division (mt_common.h)
+        const size_t m = (size_t)mi;
+        const int t = (int)fast_div((unsigned)mi, (unsigned)B, mB, sB), b = mi - t * B, g = b >> 5, bl = b & 31;
         const f16_t* src = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 256 + (size_t)(kb >> 1) * 512 + ((kb & 1) * 32 + bl) * 8;
         const int c0 = col_off + d * Hv + kb * 8;
         const f16x8 h8 = *(const f16x8*)src;
@@ -827,13 +827,17 @@ extern "C" int mt_lstm_relayout_dt(const float* hx, void* X, int ldx, float* Y, 
     MT_REQUIRE((!X || (ldx >= col_off + 2 * Hv && ldx % 8 == 0)) && (!Y || ldy >= col_off + 2 * Hv), MT_EINVAL, "mt_lstm_relayout_ex: bad leading dimension");
     MT_REQUIRE_DT(dt, "mt_lstm_relayout");
     const size_t total = (size_t)T * B * 2 * ((Hv + 7) >> 3);
+    MT_REQUIRE(total < ((size_t)1 << 31), MT_EUNSUPPORTED, "mt_lstm_relayout: more than 2^31 pieces");
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const Div3 dv = make_div3((Hv + 7) >> 3, 2);
+    unsigned mB, sB;
+    div_magic((unsigned)B, &mB, &sB);
     if (dt == MT_DT_F16)
         hipLaunchKernelGGL(lstm_relayout_kernel<MT_DT_F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, Y, ldy,
-                           col_off, B, T, H, Hv);
+                           col_off, B, T, H, Hv, dv, mB, sB);
     else
         hipLaunchKernelGGL(lstm_relayout_kernel<MT_DT_BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, Y, ldy,
-                           col_off, B, T, H, Hv);
+                           col_off, B, T, H, Hv, dv, mB, sB);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }

@@ -428,18 +428,33 @@ __global__ __launch_bounds__(256) void lstm_hprevT_kernel(const f16_t* __restric
 // hx (f16 h) -> X[(t*B+b)*ldx + d*Hv + j] bf16 with inverted dropout (nn.LSTM's
 // inter-layer dropout; the mask is a counter-based hash of (seed, layer, element), regenerated in the backward pass)
 __global__ void lstm_relayout_train_kernel(const f16_t* __restrict__ hx, bf16_t* __restrict__ X, int ldx, int B, int T, int H, int Hv,
-                                           float p, unsigned seed, unsigned layer) {
-    const int nkb = H >> 3;
-    const long long n = (long long)T * B * 2 * Hv;
+                                           float p, unsigned seed, unsigned layer, Div3 dv, unsigned mB, unsigned sB) {
+    // one thread = 8 units of one (t, b, direction): one 16-byte read of the hx image, one 16-byte store (round 4: one thread per ELEMENT, two
+    // 64-bit divisions and a 2-byte gather each, before).  The dropout hash keeps its element index m * 2 Hv + column (mt_lstm_dh_relayout
+    // regenerates the mask from it).
+    const int nkb = H >> 3, nkv = (Hv + 7) >> 3;
+    const unsigned total = (unsigned)T * B * 2 * nkv;
     const float scale = p > 0.0f ? 1.0f / (1.0f - p) : 1.0f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int col = (int)(i % (2 * Hv));
-        const long long m = i / (2 * Hv);
-        const int bq = (int)(m % B), t = (int)(m / B), d = col / Hv, jj = col - d * Hv, g = bq >> 5, bl = bq & 31;
-        const f16_t* blk = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 256 + (size_t)(jj >> 4) * 512;
-        float v = (float)blk[(((jj >> 3) & 1) * 32 + bl) * 8 + (jj & 7)];
-        if (p > 0.0f) v = dropout_keep(seed, layer, (unsigned long long)i, p) ? v * scale : 0.0f;
-        X[(size_t)m * ldx + col] = f32_to_bf16(v);
+    const bool vec = (Hv & 7) == 0 && (ldx & 7) == 0;
+    for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        int kb, d, mi;
+        div3(id, dv, kb, d, mi);                        // id = (m * 2 + d) * nkv + kb
+        const unsigned m = (unsigned)mi, t = fast_div(m, (unsigned)B, mB, sB), bq = m - t * (unsigned)B, g = bq >> 5, bl = bq & 31;
+        const f16_t* src = hx + ((((size_t)g * T + t) * 2 + d) * nkb) * 256 + (size_t)(kb >> 1) * 512 + ((kb & 1) * 32 + bl) * 8;
+        const f16x8 h8 = *(const f16x8*)src;
+        const int col0 = d * Hv + kb * 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (float)h8[j];
+            if (p > 0.0f) v[j] = dropout_keep(seed, layer, (unsigned long long)m * (2 * Hv) + col0 + j, p) ? v[j] * scale : 0.0f;
+        }
+        bf16_t* o = X + (size_t)m * ldx + col0;
+        if (vec) {
+            *(uint4*)o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        } else {
+            for (int j = 0; j < 8 && kb * 8 + j < Hv; ++j) o[j] = f32_to_bf16(v[j]);
+        }
     }
 }
 
@@ -579,9 +594,15 @@ extern "C" int mt_lstm_hprev_t(const float* hx, void* HT, long long ld, int rows
 extern "C" int mt_lstm_relayout_train(const float* hx, void* X, int ldx, int B, int T, int H, int Hv, float p, unsigned seed, unsigned layer,
                                       mt_stream_t stream) {
     MT_REQUIRE(hx && X && B > 0 && T > 0 && H % 16 == 0 && Hv > 0 && Hv <= H && ldx >= 2 * Hv && p >= 0.0f && p < 1.0f, MT_EINVAL, "mt_lstm_relayout_train: bad arguments");
-    long long g = ((long long)T * B * 2 * Hv + 255) / 256;
+    const int nkv = (Hv + 7) / 8;
+    const long long total = (long long)T * B * 2 * nkv;
+    MT_REQUIRE(total < ((long long)1 << 31), MT_EUNSUPPORTED, "mt_lstm_relayout_train: more than 2^31 pieces");
+    long long g = (total + 255) / 256;
     if (g > 16384) g = 16384;
-    hipLaunchKernelGGL(lstm_relayout_train_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, B, T, H, Hv, p, seed, layer);
+    unsigned mB, sB;
+    div_magic((unsigned)B, &mB, &sB);
+    hipLaunchKernelGGL(lstm_relayout_train_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const f16_t*)hx, (bf16_t*)X, ldx, B, T, H, Hv, p, seed, layer,
+                       make_div3(nkv, 2), mB, sB);
     MT_CHECK_LAUNCH();
     return MT_OK;
 }
