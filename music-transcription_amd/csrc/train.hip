@@ -818,10 +818,13 @@ extern "C" int mt_pack_wih_cf(const float* w, void* out, long long ldo, int row0
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const mt_pack_job* __restrict__ jobs, int njobs) {
     __shared__ float tile[32][33];
     __shared__ int job_s;
-    if (threadIdx.x == 0) {
-        int j = 0;
-        while (j + 1 < njobs && jobs[j + 1].tile0 <= (int)blockIdx.x) ++j;
-        job_s = j;
+    if (threadIdx.x == 0) {                             // the last job whose first tile is <= this block (tile0 ascends): bisection
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        job_s = lo;
     }
     __syncthreads();
     const mt_pack_job jb = jobs[job_s];
