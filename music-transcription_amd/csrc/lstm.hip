@@ -86,6 +86,11 @@ __device__ __forceinline__ float tanhf_(float x) { return fmaf(2.0f, __builtin_a
 constexpr int OOB_OFF = 0x7FFFFF00;           // a buffer offset beyond every resource here: such loads return 0, such stores are dropped
 constexpr unsigned H_POISON = 0xFFFFFFFFu;   // never the bit pattern of a hidden state (|h| < 1)
 constexpr int PAYLOAD_POLL_SLEEP = 10;       // s_sleep units (64 clocks) before a step's first payload poll: 8..14 measured equal, 24+ slower
+constexpr int PAYLOAD_POLL_SLEEP_BUSY = 18;  // inference with OTHER persistent launches pending on the GPU (forwards in flight on other streams: their kernels share the CUs
+                                             // and the producers' data lands later).  Round 4, one batch of 32 per forward on 3 streams (BASELINE configs[1] as written):
+                                             // 7 430 chunks/s at 10, 7 760 at 14, 7 950 at 18, 7 900 at 22, 7 610 at 26; alone on the GPU 18 costs 8 % (4 570 against 4 980).
+                                             // CNNRNNModelLarge, one batch of 16 per forward on 3 streams: 2 126 at 10, 2 190 at 16, 2 176 at 20.  Not for the fused-projection
+                                             // variant (two forwards in flight: 7 810 at 10, 7 510 at 18: its step is longer).
 constexpr int PAYLOAD_POLL_SLEEP_TRAIN = 12; // train mode (a step ends in five more stores): round 4, tools/lstm_fwd_ab.py on three boxes, B = 16, H = 512:
                                              // 1.27 - 1.29 ms per launch at 10, 1.23 - 1.25 at 12 / 13, 1.25 at 14.  (A per-wave controller of the delay --
                                              // longer after a failed first poll, shorter after a run of good ones -- was built and is NOT better than the
@@ -773,7 +778,8 @@ static int lstm_fwd_impl(const float* gx, const float* w_hh, float* hx, void* sy
     static const int env_retry = getenv("MT_LSTM_POLL_RETRY") ? atoi(getenv("MT_LSTM_POLL_RETRY")) : -1;
     LstmArgs a{gx, w_hh, hx, (unsigned*)sync_ws, B, T, H, 0, 0,
                cx ? const_cast<float*>(gx) : nullptr, cx, w_ihx, bias, hx_prev,
-               env_first >= 0 ? env_first : (cx ? PAYLOAD_POLL_SLEEP_TRAIN : PAYLOAD_POLL_SLEEP), env_retry >= 0 ? env_retry : 0};
+               env_first >= 0 ? env_first : (cx ? PAYLOAD_POLL_SLEEP_TRAIN : ((!w_ihx && mt_persistent_cus_in_flight(stream) > 0) ? PAYLOAD_POLL_SLEEP_BUSY : PAYLOAD_POLL_SLEEP)),
+               env_retry >= 0 ? env_retry : 0};
     // every workgroup of a launch must be resident (they wait on each other): at most 256 workgroups (one per CU) per launch --
     // for plain inference each set of 2 H/8 workgroups carries up to 4 batch groups interleaved (lstm_rec_kernel, NG), the
     // training / fused-projection variants one.  Further groups run as further launches.
