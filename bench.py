@@ -374,7 +374,7 @@ def section_coscheduled(mta, dev, net, fe, wave32):
     import torch
     T = mta.num_frames(N_SAMPLES, HOP)
     out = {}
-    for combo in os.environ.get("MT_BENCH_COSCHED", "32x3,96x4,128x1").split(","):
+    for combo in os.environ.get("MT_BENCH_COSCHED", "32x3,32x4,96x4,128x1").split(","):
         B, NS = (int(v) for v in combo.split("x"))
         K = int(os.environ.get("MT_BENCH_COSCHED_FORWARDS", max(6, 1152 // B)))
         wave = torch.cat([wave32] * (B // 32))
@@ -1116,12 +1116,15 @@ def main():
                 log(f"section {name}: {time.perf_counter() - t1:.1f} s")
                 torch.cuda.empty_cache()
 
-        # the LITERAL configs[1] schedule, first-class: one batch of 32 chunks per forward (3 forwards in flight; and one alone)
-        lit = (sections.get("configs1_other_schedules") or {}).get("b32_streams_3")
+        # the LITERAL configs[1] schedule, first-class: one batch of 32 chunks per forward (3 or 4 forwards in flight, the faster of the two; and one alone)
+        cands = [(ns_, (sections.get("configs1_other_schedules") or {}).get(f"b32_streams_{ns_}")) for ns_ in (3, 4)]
+        good = [(ns_, c_) for ns_, c_ in cands if isinstance(c_, dict) and "value" in c_]
+        lit_ns, lit = max(good, key=lambda nc: nc[1]["value"]) if good else cands[0]
         if isinstance(lit, dict) and "value" in lit:
             sections["configs1_literal_b32"] = {
                 "workload": "CNNRNNModel inference, ONE batch of 32 chunks per forward (BASELINE.json configs[1] as written), mel + forward",
-                "value": lit["value"], "unit": "chunks/s", "ms_per_step": lit["ms_per_forward"], "streams": 3,
+                "value": lit["value"], "unit": "chunks/s", "ms_per_step": lit["ms_per_forward"], "streams": lit_ns,
+                "by_streams": {str(ns_): c_["value"] for ns_, c_ in good},
                 "one_in_flight": round(1e3 * B / sum(one_ms[1]), 1) if 1 in one_ms else None}
         elif isinstance(lit, dict):
             sections["configs1_literal_b32"] = lit

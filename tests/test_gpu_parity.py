@@ -906,7 +906,7 @@ def test_bench_line_contract(tmp_path):
     # every kernel's roofline fraction in one compact object, for the three workloads
     assert {"all", "all_large", "all_train"} <= set(rf) and len(rf["all"]) >= 9 and all(0.0 < v < 1.0 for v in rf["all"].values())
     lit = d["configs1_literal_b32"]                                               # BASELINE configs[1] as written: one batch of 32 per forward
-    assert lit["value"] > 1000 and lit["streams"] == 3 and lit["one_in_flight"] > 1000
+    assert lit["value"] > 1000 and lit["streams"] in (3, 4) and lit["one_in_flight"] > 1000
     assert {"configs2_large_b16", "configs3_train_b16", "train_large_b16", "configs4_corpus", "configs4_corpus_from_pcm"} <= set(d["sections"])
     for sec, o in d["sections"].items():
         assert "error" not in o and o["value"] > 0, (sec, o)
