@@ -389,20 +389,37 @@ __global__ __launch_bounds__(256) void lstm_dg_unpack_kernel(const bf16_t* __res
     ((uint4*)&img[0][0][0])[threadIdx.x] = src[threadIdx.x];
     ((uint4*)&img[0][0][0])[threadIdx.x + 256] = src[threadIdx.x + 256];
     __syncthreads();
-    if (dG) {   // dG rows: thread (u = tid & 31, row slot = tid >> 5)
-        const int u = threadIdx.x & 31, jj = 32 * w + u;
-        for (int c = threadIdx.x >> 5; c < 128; c += 8) {
-            const int bb = c >> 2, p = c & 3;
-            if (bb < Bg && jj < H)
-                dG[((size_t)t * B + g * 32 + bb) * ldg + (size_t)d * 4 * H + (size_t)p * H + jj] = img[2 * p + (u >> 4)][((u >> 3) & 1) * 32 + bb][u & 7];
+    if (dG) {
+        // dG rows: a thread moves 8 consecutive units (one 16-byte image piece) of one (batch, gate): piece id = (bb * 4 + p) * 4 + q, units 8q .. 8q + 7
+        // (round 4: one 2-byte store per unit before)
+        const bool vec = (ldg & 7) == 0 && (H & 7) == 0;
+        for (int c = threadIdx.x; c < 512; c += 256) {
+            const int q = c & 3, p = (c >> 2) & 3, bb = c >> 4, jj = 32 * w + 8 * q;
+            if (bb < Bg && jj < H) {
+                const uint4 v = *(const uint4*)(&img[2 * p + (q >> 1)][(q & 1) * 32 + bb][0]);
+                bf16_t* o = dG + ((size_t)t * B + g * 32 + bb) * ldg + (size_t)d * 4 * H + (size_t)p * H + jj;
+                if (vec && jj + 8 <= H) *(uint4*)o = v;
+                else {
+                    const bf16_t* e = (const bf16_t*)&v;
+                    for (int j = 0; j < 8 && jj + j < H; ++j) o[j] = e[j];
+                }
+            }
         }
     }
-    if (dGT) {  // dGT rows: thread (batch = tid & 31, slot = tid >> 5)
-        const int bb = threadIdx.x & 31;
-        for (int c = threadIdx.x >> 5; c < 128; c += 8) {
-            const int p = c >> 5, u = c & 31, jj = 32 * w + u;
-            if (bb < Bg && jj < H)
-                dGT[((size_t)d * 4 * H + (size_t)p * H + jj) * ldt + (size_t)t * B + g * 32 + bb] = img[2 * p + (u >> 4)][((u >> 3) & 1) * 32 + bb][u & 7];
+    if (dGT) {
+        // dGT rows: a thread moves 8 consecutive batch columns of one gate row: piece id = row * 4 + batch octet
+        const bool vec = (ldt & 7) == 0 && (B & 7) == 0;
+        for (int c = threadIdx.x; c < 512; c += 256) {
+            const int bo = c & 3, row = c >> 2, p = row >> 5, u = row & 31, jj = 32 * w + u;
+            if (8 * bo < Bg && jj < H) {
+                bf16_t e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = img[2 * p + (u >> 4)][((u >> 3) & 1) * 32 + 8 * bo + j][u & 7];
+                bf16_t* o = dGT + ((size_t)d * 4 * H + (size_t)p * H + jj) * ldt + (size_t)t * B + g * 32 + 8 * bo;
+                if (vec && 8 * bo + 8 <= Bg) *(uint4*)o = *(const uint4*)e;
+                else
+                    for (int j = 0; j < 8 && 8 * bo + j < Bg; ++j) o[j] = e[j];
+            }
         }
     }
 }
@@ -418,10 +435,19 @@ __global__ __launch_bounds__(256) void lstm_hprevT_kernel(const f16_t* __restric
     const int tp = d ? (t + 1) : (t - 1);
     const bool have = tp >= 0 && tp < T;
     const f16_t* src = hx + ((((size_t)g * T + (have ? tp : 0)) * 2 + d) * nkb) * 256 + (size_t)ks * 512;   // block of k-step ks
-    const int bb = threadIdx.x & 31;
-    for (int kl = threadIdx.x >> 5; kl < 16; kl += 8) {
-        const bf16_t v = have ? f32_to_bf16((float)src[((kl >> 3) * 32 + bb) * 8 + (kl & 7)]) : (bf16_t)0;
-        if (bb < Bg) HT[((size_t)d * rows_per_dir + ks * 16 + kl) * ld + (size_t)t * B + g * 32 + bb] = v;
+    // a thread moves 8 consecutive batch columns of one k row (16 bytes out; round 4: one 2-byte store per element before); threads 0..63
+    const bool vec = (ld & 7) == 0 && (B & 7) == 0;
+    if (threadIdx.x < 64) {
+        const int bo = threadIdx.x & 3, kl = threadIdx.x >> 2;
+        if (8 * bo < Bg) {
+            bf16_t e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = have ? f32_to_bf16((float)src[((kl >> 3) * 32 + 8 * bo + j) * 8 + (kl & 7)]) : (bf16_t)0;
+            bf16_t* o = HT + ((size_t)d * rows_per_dir + ks * 16 + kl) * ld + (size_t)t * B + g * 32 + 8 * bo;
+            if (vec && 8 * bo + 8 <= Bg) *(uint4*)o = *(const uint4*)e;
+            else
+                for (int j = 0; j < 8 && 8 * bo + j < Bg; ++j) o[j] = e[j];
+        }
     }
 }
 
@@ -585,7 +611,7 @@ extern "C" int mt_lstm_dg_unpack(const void* dgx, void* dG, int ldg, void* dGT, 
 
 extern "C" int mt_lstm_hprev_t(const float* hx, void* HT, long long ld, int rows_per_dir, int B, int T, int H, mt_stream_t stream) {
     MT_REQUIRE(hx && HT && B > 0 && T > 0 && H % 16 == 0 && rows_per_dir >= H && ld >= (long long)T * B, MT_EINVAL, "mt_lstm_hprev_t: bad arguments");
-    hipLaunchKernelGGL(lstm_hprevT_kernel, dim3(H / 16, 2 * T, (B + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(lstm_hprevT_kernel, dim3(H / 16, 2 * T, (B + 31) / 32), dim3(64), 0, (hipStream_t)stream,
                        (const f16_t*)hx, (bf16_t*)HT, ld, rows_per_dir, B, T, H);
     MT_CHECK_LAUNCH();
     return MT_OK;
